@@ -1,0 +1,176 @@
+/*
+ * rtuf.h -- C ABI of the MI355X-native realtime URDF depth self-filter.
+ *
+ * This is the drop-in boundary for the hot path of blodow/realtime_urdf_filter:
+ *   RealtimeURDFFilter::filter() -> textureBufferFromDepthBuffer() -> render()
+ *   -> URDFRenderer::render() -> Renderable*::render() -> urdf_filter.{vert,frag}
+ *   -> glGetTexImage read-back.
+ * Every entry point cites the reference interface it replaces (paths relative to
+ * the reference checkout).  The reference has no C ABI of its own -- its boundary
+ * is the C++ class surface of include/realtime_urdf_filter/urdf_filter.h:51-143 and
+ * urdf_renderer.h:45-73 -- so these are the calls a C++ facade (include/
+ * realtime_urdf_filter_amd/urdf_filter.hpp), a ROS adapter or a ctypes/cgo/JNI stub
+ * binds (INTEGRATION.md shows the bindings).
+ *
+ * Conventions: plain pointers and sizes only; every function returns an int status
+ * (RTUF_OK = 0, negative = error) and never throws; rtuf_last_error() returns the
+ * message of the last failure on that context (or of rtuf_create when ctx == NULL).
+ * The caller owns every host buffer; the library owns device memory.  One context is
+ * bound to one GPU and used from one host thread at a time; several contexts (one per
+ * GPU) may run concurrently.  All matrices are OpenGL style: 16 values, column-major.
+ *
+ * There is NO CPU fallback: without a visible gfx950 device rtuf_create() fails
+ * with RTUF_ERR_NO_DEVICE.
+ */
+#ifndef RTUF_H_
+#define RTUF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTUF_ABI_VERSION 1
+
+typedef struct rtuf_context rtuf_context;
+
+enum {
+  RTUF_OK = 0,
+  RTUF_ERR_INVALID = -1,      /* bad argument / call order                      */
+  RTUF_ERR_NO_DEVICE = -2,    /* no usable HIP device (no CPU fallback exists)  */
+  RTUF_ERR_HIP = -3,          /* HIP runtime error, see rtuf_last_error         */
+  RTUF_ERR_OOM = -4,          /* host or device allocation failed               */
+  RTUF_ERR_CAPACITY = -5,     /* a per-tile bin overflowed even after regrowth  */
+  RTUF_ERR_STATE = -6         /* models not finalised / frame not ready         */
+};
+
+/* Matrix operation a renderable applies between glMultMatrixd(link) and its draw call
+ * (src/renderable.cpp:95 glTranslatef for cylinders, :128 / :427 glScalef for the second
+ * box and for meshes). */
+enum { RTUF_OP_NONE = 0, RTUF_OP_SCALE = 1, RTUF_OP_TRANSLATE = 2 };
+
+/* rtuf_params.flags */
+enum {
+  RTUF_FLAG_BACKGROUND_QUAD = 1u << 0,  /* draw the background quad at 0.99*far (src/urdf_filter.cpp:591-596); reference behaviour */
+  RTUF_FLAG_TWO_KERNEL      = 1u << 1,  /* rasteriser writes the z-surface to HBM and a separate compare kernel consumes it
+                                           (default: compare fused into the tile kernel, the z-surface never leaves LDS)        */
+  RTUF_FLAG_DEFAULT = RTUF_FLAG_BACKGROUND_QUAD
+};
+
+/* Replaces the constructor's rosparam parsing (src/urdf_filter.cpp:43-118) and the
+ * hard-coded clip planes (:53-54). */
+typedef struct {
+  float near_plane;                 /* 0.1  */
+  float far_plane;                  /* 8.0  */
+  float depth_distance_threshold;   /* rosparam depth_distance_threshold -> shader uniform max_diff (:630) */
+  float filter_replace_value;       /* rosparam filter_replace_value     -> shader uniform replace_value (:631) */
+  uint32_t flags;                   /* RTUF_FLAG_* */
+  uint32_t bin_capacity;            /* triangles per (stream, screen tile) bin; 0 = automatic */
+  uint32_t max_inflight_streams;    /* streams rasterised per internal launch group; 0 = automatic */
+  uint32_t reserved[5];
+} rtuf_params;
+
+void rtuf_default_params(rtuf_params *p);
+int rtuf_abi_version(void);
+
+/* ctor + initGL() + initFrameBufferObject() (src/urdf_filter.cpp:43-118, :386-456):
+ * binds a GPU, allocates the per-stream frame resources for `max_streams` concurrent
+ * width x height depth streams.  No GL / X11 context exists anywhere. */
+int rtuf_create(rtuf_context **out, int device_id, int width, int height, int max_streams,
+                const rtuf_params *params);
+void rtuf_destroy(rtuf_context *ctx);
+const char *rtuf_last_error(const rtuf_context *ctx);
+
+/* Uniforms can change between frames like the public data members of the reference
+ * (include/realtime_urdf_filter/urdf_filter.h:112-135). */
+int rtuf_set_params(rtuf_context *ctx, const rtuf_params *params);
+
+/* ---- geometry: loaded once into device buffers ------------------------------------
+ * loadModels() -> URDFRenderer ctor -> process_link -> Renderable* ctor
+ * (src/urdf_filter.cpp:127-197, src/urdf_renderer.cpp:44-169, src/renderable.cpp:100-170,
+ * :306-415).  A model is one `models[i]` entry (one URDFRenderer); a link is one
+ * Renderable (one glPushMatrix/glPopMatrix bracket, posed per frame by its
+ * link_to_fixed * link_offset matrix); a draw is one GL draw call inside that bracket.
+ * Geometry is already tessellated into indexed triangles, in draw order. */
+int rtuf_add_model(rtuf_context *ctx);                       /* returns model id >= 0 */
+int rtuf_add_link(rtuf_context *ctx, int model);             /* returns link id >= 0 (index within the model) */
+int rtuf_add_draw(rtuf_context *ctx, int model, int link, int pre_op, const float op_xyz[3],
+                  const float *vertices_xyz, int n_vertices,
+                  const uint32_t *triangles, int n_triangles);
+/* Uploads everything added so far (VBO/IBO creation, src/renderable.cpp:167-169, :343-349). */
+int rtuf_finalize_models(rtuf_context *ctx);
+int rtuf_num_links(const rtuf_context *ctx, int model);
+int64_t rtuf_num_triangles(const rtuf_context *ctx);
+
+/* Which models a stream renders (default: all).  Lets independent robots share a context
+ * (BASELINE config 5); the reference renders every loaded model for its single stream. */
+int rtuf_set_stream_models(rtuf_context *ctx, int stream, const int *model_ids, int n_models);
+
+/* ---- per-frame pose inputs -------------------------------------------------------- */
+/* Camera of one stream: projection = getProjectionMatrix() result (src/urdf_filter.cpp:459-501);
+ * camera_offset_inv = inverse(camera_offset).getOpenGLMatrix() (:602-604);
+ * camera_tf = camera_transform.getOpenGLMatrix() after the tx/ty origin shift (:607-614).
+ * Composed on the device in float32 in OpenGL matrix-stack order. */
+int rtuf_set_camera(rtuf_context *ctx, int stream, const double projection[16],
+                    const double camera_offset_inv[16], const double camera_tf[16]);
+/* K (fx,fy,cx,cy,Tx,Ty) -> projection[16] and camera_tx/ty, exactly getProjectionMatrix. */
+void rtuf_projection_from_intrinsics(double fx, double fy, double cx, double cy, double Tx, double Ty,
+                                     int width, int height, double near_plane, double far_plane,
+                                     double projection_out[16], double *camera_tx, double *camera_ty);
+/* Link poses of one model for one stream: n_links matrices
+ * (link_to_fixed * link_offset).getOpenGLMatrix(), i.e. what Renderable::applyTransform
+ * passes to glMultMatrixd (src/renderable.cpp:59-68) after URDFRenderer::update_link_transforms
+ * (src/urdf_renderer.cpp:173-190). */
+int rtuf_set_link_poses(rtuf_context *ctx, int stream, int model, const double *link_tf, int n_links);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+/* filter() for n streams at once (stream ids 0..n-1), host buffers:
+ * depth_in[s]: width*height float32 metres, row 0 first (src/urdf_filter.cpp:233-234);
+ * masked_out[s]: width*height float32 (getMaskedDepth()); mask_out may be NULL, or
+ * mask_out[s] NULL (need_mask_ == false, :226-230), else width*height bytes 0/255. */
+int rtuf_filter_batch(rtuf_context *ctx, int n_streams, const float *const *depth_in,
+                      float *const *masked_out, uint8_t *const *mask_out);
+/* Same with device-resident planes: depth/masked are [n][H][W] float32, mask [n][H][W] u8 or
+ * NULL.  Asynchronous on the context's stream; rtuf_sync() waits. */
+int rtuf_filter_batch_device(rtuf_context *ctx, int n_streams, const float *d_depth,
+                             float *d_masked, uint8_t *d_mask);
+/* Exact single-stream shape of RealtimeURDFFilter::filter(buffer, glTf, w, h)
+ * (include/realtime_urdf_filter/urdf_filter.h:70-72): stream 0, projection given per call,
+ * results kept in library-owned host buffers like masked_depth_/mask_. */
+int rtuf_filter(rtuf_context *ctx, const unsigned char *buffer, const double *projection,
+                int width, int height);
+const float *rtuf_get_masked_depth(const rtuf_context *ctx);      /* getMaskedDepth() */
+const uint8_t *rtuf_get_mask(const rtuf_context *ctx);            /* mask_ */
+
+int rtuf_sync(rtuf_context *ctx);
+/* The HIP stream all work of this context is enqueued on (for callers that time with HIP events). */
+void *rtuf_stream(rtuf_context *ctx);
+
+/* Counters of the last batch and kernel timings measured with HIP events on the context's
+ * stream (replaces the wall-clock statistics of src/urdf_filter.cpp:239-266). */
+typedef struct {
+  uint64_t triangles_submitted;     /* triangles x streams handed to set-up            */
+  uint64_t triangles_binned;        /* (sub-)triangles that reached at least one tile  */
+  uint64_t bin_entries;             /* records written to tile bins                    */
+  uint64_t triangles_clipped;       /* triangles that went through the clipper         */
+  uint32_t max_bin_fill;            /* largest bin of the last batch                   */
+  uint32_t bin_capacity;
+  uint32_t regrowths;               /* times the bins were enlarged and a batch re-run */
+  uint32_t reserved;
+  float ms_pose, ms_setup, ms_raster, ms_compare, ms_total;   /* last timed batch       */
+} rtuf_stats;
+int rtuf_get_stats(rtuf_context *ctx, rtuf_stats *out);
+/* Enable/disable per-kernel HIP-event timing (off by default: events serialise nothing but
+ * cost a few microseconds each). */
+int rtuf_enable_timing(rtuf_context *ctx, int on);
+
+/* Debug / test access: copy the z-surface of the last batch (float window z of the winning
+ * fragment per pixel, [n][H][W]) to the host.  Only valid with RTUF_FLAG_TWO_KERNEL. */
+int rtuf_debug_read_zsurface(rtuf_context *ctx, int n_streams, float *host_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTUF_H_ */

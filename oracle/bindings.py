@@ -1,0 +1,112 @@
+"""ctypes binding of the CPU oracle (oracle/rtuf_oracle.c).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the
+product package realtime_urdf_filter_amd."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "librtuf_oracle.so")
+
+OP_NONE, OP_SCALE, OP_TRANSLATE = 0, 1, 2
+
+
+class Draw(ctypes.Structure):
+    _fields_ = [("link_tf", ctypes.c_double * 16), ("pre_op", ctypes.c_int32), ("op", ctypes.c_float * 3),
+                ("verts", ctypes.c_void_p), ("nverts", ctypes.c_int32), ("tris", ctypes.c_void_p),
+                ("ntris", ctypes.c_int32)]
+
+
+class Frame(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("depth", ctypes.c_void_p),
+                ("z_near", ctypes.c_float), ("z_far", ctypes.c_float), ("max_diff", ctypes.c_float),
+                ("replace_value", ctypes.c_float), ("projection", ctypes.c_double * 16),
+                ("camera_offset_inv", ctypes.c_double * 16), ("camera_tf", ctypes.c_double * 16),
+                ("draws", ctypes.c_void_p), ("ndraws", ctypes.c_int32)]
+
+
+class Debug(ctypes.Structure):
+    _fields_ = [("zwin", ctypes.c_void_p), ("prim", ctypes.c_void_p), ("n_tris_in", ctypes.c_long),
+                ("n_tris_setup", ctypes.c_long), ("n_frags", ctypes.c_long)]
+
+
+class Variants(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("vs_fma", "vp_fma", "clip_vp_fma", "interp_fma", "frag_div_rcp",
+                                              "cw_swap_12", "edge_rule_flip", "clip_old_t")]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "_build/librtuf_oracle.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.rtuf_oracle_filter.argtypes = [ctypes.POINTER(Frame), ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Debug)]
+        _lib.rtuf_oracle_compose_mvp.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    return _lib
+
+
+def set_variants(**kw):
+    v = Variants()
+    lib().rtuf_oracle_get_variants(ctypes.byref(v))
+    for k, x in kw.items():
+        setattr(v, k, x)
+    lib().rtuf_oracle_set_variants(ctypes.byref(v))
+
+
+IDENTITY = np.eye(4).T.reshape(16).copy()
+
+
+def filter_frame(depth, projection, draws, camera_offset_inv=None, camera_tf=None, z_near=0.1, z_far=8.0,
+                 max_diff=0.05, replace_value=0.0, want_debug=False):
+    """One frame through the oracle.
+
+    draws: list of (link_tf[16] f64 column-major, pre_op, op[3], verts [N,3] f32, tris [M,3] u32).
+    Returns (masked f32 [H,W], mask u8 [H,W]) or, with want_debug, additionally
+    (zwin f32 [H,W], prim i32 [H,W], (tris_in, tris_setup, frags)).
+    """
+    depth = np.ascontiguousarray(depth, np.float32)
+    H, W = depth.shape
+    keep = []
+    arr = (Draw * max(len(draws), 1))()
+    for i, (tf, pre, op, v, t) in enumerate(draws):
+        v = np.ascontiguousarray(v, np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(t, np.uint32).reshape(-1, 3)
+        keep += [v, t]
+        arr[i].link_tf[:] = list(np.asarray(tf, np.float64).reshape(16))
+        arr[i].pre_op = int(pre)
+        arr[i].op[:] = [float(x) for x in op]
+        arr[i].verts = v.ctypes.data
+        arr[i].nverts = len(v)
+        arr[i].tris = t.ctypes.data
+        arr[i].ntris = len(t)
+    fr = Frame()
+    fr.width, fr.height, fr.depth = W, H, depth.ctypes.data
+    fr.z_near, fr.z_far, fr.max_diff, fr.replace_value = z_near, z_far, max_diff, replace_value
+    fr.projection[:] = list(np.asarray(projection, np.float64).reshape(16))
+    fr.camera_offset_inv[:] = list(IDENTITY if camera_offset_inv is None else np.asarray(camera_offset_inv, np.float64).reshape(16))
+    fr.camera_tf[:] = list(IDENTITY if camera_tf is None else np.asarray(camera_tf, np.float64).reshape(16))
+    fr.draws = ctypes.addressof(arr)
+    fr.ndraws = len(draws)
+    masked = np.zeros((H, W), np.float32)
+    mask = np.zeros((H, W), np.uint8)
+    dbg = Debug()
+    if want_debug:
+        zwin = np.zeros((H, W), np.float32)
+        prim = np.zeros((H, W), np.int32)
+        dbg.zwin, dbg.prim = zwin.ctypes.data, prim.ctypes.data
+    rc = lib().rtuf_oracle_filter(ctypes.byref(fr), masked.ctypes.data, mask.ctypes.data, ctypes.byref(dbg))
+    if rc != 0:
+        raise RuntimeError("oracle failed: %d" % rc)
+    if want_debug:
+        return masked, mask, zwin, prim, (dbg.n_tris_in, dbg.n_tris_setup, dbg.n_frags)
+    return masked, mask

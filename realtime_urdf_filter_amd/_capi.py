@@ -1,0 +1,241 @@
+"""ctypes binding of the C ABI in include/rtuf.h (librtuf.so, built by csrc/build.sh).
+
+This is the same binding a maintainer of the reference would write for a Python host
+(INTEGRATION.md); the C++ facade binds the identical symbols.  The library is the product
+path: if it is missing or no GPU is visible, construction fails loudly -- there is no CPU
+fallback anywhere in this package.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librtuf.so")
+
+RTUF_OK = 0
+RTUF_ERR_NO_DEVICE = -2
+OP_NONE, OP_SCALE, OP_TRANSLATE = 0, 1, 2
+FLAG_BACKGROUND_QUAD = 1
+FLAG_TWO_KERNEL = 2
+
+#: every symbol include/rtuf.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "rtuf_default_params", "rtuf_abi_version", "rtuf_create", "rtuf_destroy", "rtuf_last_error",
+    "rtuf_set_params", "rtuf_add_model", "rtuf_add_link", "rtuf_add_draw", "rtuf_finalize_models",
+    "rtuf_num_links", "rtuf_num_triangles", "rtuf_set_stream_models", "rtuf_set_camera",
+    "rtuf_projection_from_intrinsics", "rtuf_set_link_poses", "rtuf_filter_batch",
+    "rtuf_filter_batch_device", "rtuf_filter", "rtuf_get_masked_depth", "rtuf_get_mask", "rtuf_sync",
+    "rtuf_stream", "rtuf_get_stats", "rtuf_enable_timing", "rtuf_debug_read_zsurface",
+]
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("near_plane", ctypes.c_float), ("far_plane", ctypes.c_float),
+                ("depth_distance_threshold", ctypes.c_float), ("filter_replace_value", ctypes.c_float),
+                ("flags", ctypes.c_uint32), ("bin_capacity", ctypes.c_uint32),
+                ("max_inflight_streams", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 5)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("triangles_submitted", ctypes.c_uint64), ("triangles_binned", ctypes.c_uint64),
+                ("bin_entries", ctypes.c_uint64), ("triangles_clipped", ctypes.c_uint64),
+                ("max_bin_fill", ctypes.c_uint32), ("bin_capacity", ctypes.c_uint32),
+                ("regrowths", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("ms_pose", ctypes.c_float), ("ms_setup", ctypes.c_float), ("ms_raster", ctypes.c_float),
+                ("ms_compare", ctypes.c_float), ("ms_total", ctypes.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class RtufError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("rtuf error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads librtuf.so (no GPU needed for loading; rtuf_create needs one)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIB_PATH
+    if not os.path.exists(p):
+        raise RtufError(-100, "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)" % p)
+    lib = ctypes.CDLL(p)
+    vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    lib.rtuf_default_params.argtypes = [ctypes.POINTER(Params)]
+    lib.rtuf_default_params.restype = None
+    lib.rtuf_abi_version.restype = ci
+    lib.rtuf_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, ctypes.POINTER(Params)]
+    lib.rtuf_destroy.argtypes = [vp]
+    lib.rtuf_destroy.restype = None
+    lib.rtuf_last_error.argtypes = [vp]
+    lib.rtuf_last_error.restype = ctypes.c_char_p
+    lib.rtuf_set_params.argtypes = [vp, ctypes.POINTER(Params)]
+    lib.rtuf_add_model.argtypes = [vp]
+    lib.rtuf_add_link.argtypes = [vp, ci]
+    lib.rtuf_add_draw.argtypes = [vp, ci, ci, ci, vp, vp, ci, vp, ci]
+    lib.rtuf_finalize_models.argtypes = [vp]
+    lib.rtuf_num_links.argtypes = [vp, ci]
+    lib.rtuf_num_triangles.argtypes = [vp]
+    lib.rtuf_num_triangles.restype = ctypes.c_int64
+    lib.rtuf_set_stream_models.argtypes = [vp, ci, vp, ci]
+    lib.rtuf_set_camera.argtypes = [vp, ci, vp, vp, vp]
+    lib.rtuf_projection_from_intrinsics.argtypes = [cd, cd, cd, cd, cd, cd, ci, ci, cd, cd, vp, vp, vp]
+    lib.rtuf_projection_from_intrinsics.restype = None
+    lib.rtuf_set_link_poses.argtypes = [vp, ci, ci, vp, ci]
+    lib.rtuf_filter_batch.argtypes = [vp, ci, vp, vp, vp]
+    lib.rtuf_filter_batch_device.argtypes = [vp, ci, vp, vp, vp]
+    lib.rtuf_filter.argtypes = [vp, vp, vp, ci, ci]
+    lib.rtuf_get_masked_depth.argtypes = [vp]
+    lib.rtuf_get_masked_depth.restype = ctypes.POINTER(ctypes.c_float)
+    lib.rtuf_get_mask.argtypes = [vp]
+    lib.rtuf_get_mask.restype = ctypes.POINTER(ctypes.c_uint8)
+    lib.rtuf_sync.argtypes = [vp]
+    lib.rtuf_stream.argtypes = [vp]
+    lib.rtuf_stream.restype = vp
+    lib.rtuf_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    lib.rtuf_enable_timing.argtypes = [vp, ci]
+    lib.rtuf_debug_read_zsurface.argtypes = [vp, ci, vp]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def default_params():
+    p = Params()
+    load_library().rtuf_default_params(ctypes.byref(p))
+    return p
+
+
+def projection_from_intrinsics(fx, fy, cx, cy, width, height, near=0.1, far=8.0, Tx=0.0, Ty=0.0):
+    """getProjectionMatrix (reference src/urdf_filter.cpp:459-501). Returns (P[16], camera_tx, camera_ty)."""
+    P = np.zeros(16, np.float64)
+    tx, ty = ctypes.c_double(), ctypes.c_double()
+    load_library().rtuf_projection_from_intrinsics(fx, fy, cx, cy, Tx, Ty, width, height, near, far,
+                                                   P.ctypes.data, ctypes.byref(tx), ctypes.byref(ty))
+    return P, tx.value, ty.value
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class Context:
+    """Thin object wrapper over an rtuf_context handle."""
+
+    def __init__(self, width, height, max_streams=1, device=0, params=None):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        self.width, self.height, self.max_streams = width, height, max_streams
+        p = params if params is not None else default_params()
+        rc = self._lib.rtuf_create(ctypes.byref(self._h), device, width, height, max_streams, ctypes.byref(p))
+        if rc != RTUF_OK:
+            raise RtufError(rc, self._lib.rtuf_last_error(None).decode())
+        self.params = p
+
+    def _check(self, rc):
+        if rc < 0:
+            raise RtufError(rc, self._lib.rtuf_last_error(self._h).decode())
+        return rc
+
+    def close(self):
+        if self._h:
+            self._lib.rtuf_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # geometry
+    def add_model(self):
+        return self._check(self._lib.rtuf_add_model(self._h))
+
+    def add_link(self, model):
+        return self._check(self._lib.rtuf_add_link(self._h, model))
+
+    def add_draw(self, model, link, verts, tris, pre_op=OP_NONE, op=(0.0, 0.0, 0.0)):
+        v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
+        o = np.asarray(op, np.float32)
+        return self._check(self._lib.rtuf_add_draw(self._h, model, link, pre_op, _ptr(o), _ptr(v), len(v), _ptr(t), len(t)))
+
+    def finalize_models(self):
+        self._check(self._lib.rtuf_finalize_models(self._h))
+
+    def num_triangles(self):
+        return int(self._lib.rtuf_num_triangles(self._h))
+
+    def set_stream_models(self, stream, model_ids):
+        m = np.ascontiguousarray(model_ids, np.int32)
+        self._check(self._lib.rtuf_set_stream_models(self._h, stream, _ptr(m), len(m)))
+
+    def set_params(self, params):
+        self._check(self._lib.rtuf_set_params(self._h, ctypes.byref(params)))
+        self.params = params
+
+    # poses
+    def set_camera(self, stream, projection=None, camera_offset_inv=None, camera_tf=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, np.float64).reshape(16)
+                for a in (projection, camera_offset_inv, camera_tf)]
+        self._check(self._lib.rtuf_set_camera(self._h, stream, *[_ptr(a) for a in arrs]))
+
+    def set_link_poses(self, stream, model, link_tf):
+        a = np.ascontiguousarray(link_tf, np.float64).reshape(-1, 16)
+        self._check(self._lib.rtuf_set_link_poses(self._h, stream, model, _ptr(a), len(a)))
+
+    # hot path
+    def filter_batch(self, depth, want_mask=True):
+        """depth: [n,H,W] float32 host array -> (masked [n,H,W] f32, mask [n,H,W] u8 or None)."""
+        d = np.ascontiguousarray(depth, np.float32).reshape(-1, self.height, self.width)
+        n = d.shape[0]
+        masked = np.empty_like(d)
+        mask = np.empty(d.shape, np.uint8) if want_mask else None
+        PP = ctypes.c_void_p * n
+        din = PP(*[d[i].ctypes.data for i in range(n)])
+        mout = PP(*[masked[i].ctypes.data for i in range(n)])
+        kout = PP(*[mask[i].ctypes.data for i in range(n)]) if want_mask else None
+        self._check(self._lib.rtuf_filter_batch(self._h, n, din, mout, kout))
+        return masked, mask
+
+    def filter_batch_device(self, n, d_depth, d_masked, d_mask=None):
+        """Device pointers (ints): enqueue only; call sync()."""
+        self._check(self._lib.rtuf_filter_batch_device(self._h, n, ctypes.c_void_p(d_depth), ctypes.c_void_p(d_masked),
+                                                       ctypes.c_void_p(d_mask) if d_mask else None))
+
+    def filter(self, buffer, projection):
+        """RealtimeURDFFilter::filter(buffer, glTf, w, h) + getMaskedDepth()/mask_."""
+        b = np.ascontiguousarray(buffer, np.float32).reshape(self.height, self.width)
+        P = np.ascontiguousarray(projection, np.float64).reshape(16)
+        self._check(self._lib.rtuf_filter(self._h, _ptr(b), _ptr(P), self.width, self.height))
+        n = self.width * self.height
+        md = np.ctypeslib.as_array(self._lib.rtuf_get_masked_depth(self._h), shape=(n,)).reshape(self.height, self.width).copy()
+        mk = np.ctypeslib.as_array(self._lib.rtuf_get_mask(self._h), shape=(n,)).reshape(self.height, self.width).copy()
+        return md, mk
+
+    def sync(self):
+        self._check(self._lib.rtuf_sync(self._h))
+
+    def stream_handle(self):
+        return self._lib.rtuf_stream(self._h)
+
+    def enable_timing(self, on=True):
+        self._check(self._lib.rtuf_enable_timing(self._h, 1 if on else 0))
+
+    def stats(self):
+        s = Stats()
+        self._check(self._lib.rtuf_get_stats(self._h, ctypes.byref(s)))
+        return s.as_dict()
+
+    def read_zsurface(self, n):
+        out = np.empty((n, self.height, self.width), np.float32)
+        self._check(self._lib.rtuf_debug_read_zsurface(self._h, n, _ptr(out)))
+        return out

@@ -1,0 +1,665 @@
+// rtuf_api.cpp -- host side of the C ABI declared in include/rtuf.h.
+//
+// Owns device memory, uploads geometry once, stages per-frame poses, and enqueues the
+// kernels of rtuf_kernels.hip on one HIP stream per context.  There is no CPU compute
+// path in this library: without a HIP device rtuf_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rtuf.h"
+#include "rtuf_device.h"
+
+
+using namespace rtuf;
+
+namespace {
+
+struct HostDraw {
+  int pre_op;
+  float op[3];
+  std::vector<float> verts;       // xyz
+  std::vector<uint32_t> tris;     // 3 per triangle, local vertex ids
+};
+struct HostLink { std::vector<HostDraw> draws; };
+struct HostModel { std::vector<HostLink> links; int link_base = 0; };
+
+char g_create_error[512] = "";
+
+}  // namespace
+
+struct rtuf_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int width = 0, height = 0, tiles_x = 0, tiles_y = 0, max_streams = 0;
+  rtuf_params params{};
+  std::string error;
+
+  // models (host)
+  std::vector<HostModel> models;
+  bool finalized = false;
+  int n_links = 0, n_draws = 0, n_chunks = 0;
+  int64_t n_tris = 0;
+  uint32_t bg_chunk = 0;
+
+  // static geometry (device)
+  float4* d_verts = nullptr; uint4* d_tris = nullptr; Chunk* d_chunks = nullptr; Draw* d_draws = nullptr;
+
+  // per-frame pose staging
+  Camera* h_cams = nullptr;            // pinned [max_streams]
+  double* h_link_tf = nullptr;         // pinned [max_streams][n_links][16]
+  uint64_t* h_model_mask = nullptr;    // pinned [max_streams]
+  Camera* d_cams = nullptr; double* d_link_tf = nullptr; uint64_t* d_model_mask = nullptr;
+  float* d_mvp = nullptr; float* d_bg_z = nullptr; uint32_t* d_bg_mode = nullptr;
+
+  // rasteriser working set
+  int group = 0;                       // in-flight streams per launch group
+  uint32_t capacity = 0, clip_capacity = 0;
+  TriRec* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr;
+  Counters* d_counters = nullptr; Counters* h_counters = nullptr;
+  float* d_zsurface = nullptr;
+
+  // staging for the host-pointer API
+  float* d_depth = nullptr; float* d_masked = nullptr; uint8_t* d_mask = nullptr;
+  size_t staged_streams = 0;
+
+  // single-stream outputs (masked_depth_ / mask_ of the reference)
+  std::vector<float> single_masked; std::vector<uint8_t> single_mask;
+
+  // last device batch (for overflow re-run at sync time)
+  bool pending = false;
+  int last_n = 0; const float* last_depth = nullptr; float* last_masked = nullptr; uint8_t* last_mask = nullptr;
+
+  rtuf_stats stats{};
+  bool timing = false;
+  std::vector<hipEvent_t> events;
+
+  int fail(int code, const char* fmt, ...)
+  {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    error = buf;
+    return code;
+  }
+};
+
+#define HIP_TRY(ctx, expr)                                                                 \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return (ctx)->fail(e_ == hipErrorOutOfMemory ? RTUF_ERR_OOM : RTUF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" {
+
+int rtuf_abi_version(void) { return RTUF_ABI_VERSION; }
+
+void rtuf_default_params(rtuf_params* p)
+{
+  if (!p) return;
+  memset(p, 0, sizeof *p);
+  p->near_plane = 0.1f;                  // src/urdf_filter.cpp:54
+  p->far_plane = 8.0f;                   // src/urdf_filter.cpp:53
+  p->depth_distance_threshold = 0.05f;   // launch/filter_parameters.yaml:14
+  p->filter_replace_value = 0.0f;        // src/urdf_filter.cpp:106 default
+  p->flags = RTUF_FLAG_DEFAULT;
+}
+
+const char* rtuf_last_error(const rtuf_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error; }
+
+int rtuf_create(rtuf_context** out, int device_id, int width, int height, int max_streams,
+                const rtuf_params* params)
+{
+  if (!out) return RTUF_ERR_INVALID;
+  *out = nullptr;
+  if (width <= 0 || height <= 0 || width > 4096 || height > 4096 || max_streams <= 0) {
+    snprintf(g_create_error, sizeof g_create_error, "invalid size %dx%d or stream count %d", width, height, max_streams);
+    return RTUF_ERR_INVALID;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) {
+    snprintf(g_create_error, sizeof g_create_error,
+             "no usable HIP device (count=%d, requested %d): %s -- this library has no CPU fallback",
+             ndev, device_id, e == hipSuccess ? "ok" : hipGetErrorString(e));
+    return RTUF_ERR_NO_DEVICE;
+  }
+  rtuf_context* c = new (std::nothrow) rtuf_context();
+  if (!c) return RTUF_ERR_OOM;
+  c->device = device_id;
+  c->width = width; c->height = height; c->max_streams = max_streams;
+  c->tiles_x = (width + kTileW - 1) / kTileW;
+  c->tiles_y = (height + kTileH - 1) / kTileH;
+  if (params) c->params = *params; else rtuf_default_params(&c->params);
+  e = hipSetDevice(device_id);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    snprintf(g_create_error, sizeof g_create_error, "hip init failed: %s", hipGetErrorString(e));
+    delete c;
+    return RTUF_ERR_HIP;
+  }
+  *out = c;
+  return RTUF_OK;
+}
+
+static void free_frame_buffers(rtuf_context* c)
+{
+  hipSetDevice(c->device);
+  auto dfree = [](auto*& p) { if (p) { hipFree(p); p = nullptr; } };
+  auto hfree = [](auto*& p) { if (p) { hipHostFree(p); p = nullptr; } };
+  dfree(c->d_cams); dfree(c->d_link_tf); dfree(c->d_model_mask); dfree(c->d_mvp); dfree(c->d_bg_z); dfree(c->d_bg_mode);
+  dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_clip_list); dfree(c->d_counters); dfree(c->d_zsurface);
+  dfree(c->d_depth); dfree(c->d_masked); dfree(c->d_mask);
+  hfree(c->h_cams); hfree(c->h_link_tf); hfree(c->h_model_mask); hfree(c->h_counters);
+  c->staged_streams = 0;
+}
+
+void rtuf_destroy(rtuf_context* c)
+{
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  free_frame_buffers(c);
+  auto dfree = [](auto*& p) { if (p) { hipFree(p); p = nullptr; } };
+  dfree(c->d_verts); dfree(c->d_tris); dfree(c->d_chunks); dfree(c->d_draws);
+  for (hipEvent_t ev : c->events) hipEventDestroy(ev);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int rtuf_set_params(rtuf_context* c, const rtuf_params* p)
+{
+  if (!c || !p) return RTUF_ERR_INVALID;
+  const uint32_t keep_cap = c->params.bin_capacity, keep_inf = c->params.max_inflight_streams;
+  const bool two_before = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
+  c->params = *p;
+  c->params.bin_capacity = keep_cap;
+  c->params.max_inflight_streams = keep_inf;
+  const bool two_now = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
+  if (c->finalized && two_now && !two_before && !c->d_zsurface) {
+    hipSetDevice(c->device);
+    HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));
+  }
+  return RTUF_OK;
+}
+
+// ---- geometry -------------------------------------------------------------------------
+int rtuf_add_model(rtuf_context* c)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (c->finalized) return c->fail(RTUF_ERR_STATE, "models already finalised");
+  if (c->models.size() >= 64) return c->fail(RTUF_ERR_INVALID, "at most 64 models per context");
+  c->models.emplace_back();
+  return (int)c->models.size() - 1;
+}
+
+int rtuf_add_link(rtuf_context* c, int model)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (c->finalized) return c->fail(RTUF_ERR_STATE, "models already finalised");
+  if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
+  c->models[model].links.emplace_back();
+  return (int)c->models[model].links.size() - 1;
+}
+
+int rtuf_add_draw(rtuf_context* c, int model, int link, int pre_op, const float op_xyz[3],
+                  const float* vertices_xyz, int n_vertices, const uint32_t* triangles, int n_triangles)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (c->finalized) return c->fail(RTUF_ERR_STATE, "models already finalised");
+  if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
+  HostModel& m = c->models[model];
+  if (link < 0 || link >= (int)m.links.size()) return c->fail(RTUF_ERR_INVALID, "bad link id %d", link);
+  if (pre_op < RTUF_OP_NONE || pre_op > RTUF_OP_TRANSLATE) return c->fail(RTUF_ERR_INVALID, "bad pre_op %d", pre_op);
+  if (n_vertices < 0 || n_triangles < 0 || (n_vertices && !vertices_xyz) || (n_triangles && !triangles))
+    return c->fail(RTUF_ERR_INVALID, "bad geometry arrays");
+  for (int i = 0; i < 3 * n_triangles; i++)
+    if (triangles[i] >= (uint32_t)n_vertices) return c->fail(RTUF_ERR_INVALID, "triangle index %u out of range", triangles[i]);
+  HostDraw d;
+  d.pre_op = pre_op;
+  for (int k = 0; k < 3; k++) d.op[k] = (pre_op != RTUF_OP_NONE && op_xyz) ? op_xyz[k] : 0.0f;
+  d.verts.assign(vertices_xyz, vertices_xyz + 3 * (size_t)n_vertices);
+  d.tris.assign(triangles, triangles + 3 * (size_t)n_triangles);
+  m.links[link].draws.push_back(std::move(d));
+  return (int)m.links[link].draws.size() - 1;
+}
+
+int rtuf_num_links(const rtuf_context* c, int model)
+{
+  if (!c || model < 0 || model >= (int)c->models.size()) return RTUF_ERR_INVALID;
+  return (int)c->models[model].links.size();
+}
+
+int64_t rtuf_num_triangles(const rtuf_context* c) { return c ? c->n_tris : 0; }
+
+static int alloc_frame_buffers(rtuf_context* c)
+{
+  const int N = c->max_streams;
+  const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
+  const size_t L = (size_t)std::max(c->n_links, 1);
+  HIP_TRY(c, hipHostMalloc(&c->h_cams, sizeof(Camera) * N));
+  HIP_TRY(c, hipHostMalloc(&c->h_link_tf, sizeof(double) * 16 * L * N));
+  HIP_TRY(c, hipHostMalloc(&c->h_model_mask, sizeof(uint64_t) * N));
+  HIP_TRY(c, hipHostMalloc(&c->h_counters, sizeof(Counters)));
+  HIP_TRY(c, hipMalloc(&c->d_cams, sizeof(Camera) * N));
+  HIP_TRY(c, hipMalloc(&c->d_link_tf, sizeof(double) * 16 * L * N));
+  HIP_TRY(c, hipMalloc(&c->d_model_mask, sizeof(uint64_t) * N));
+  HIP_TRY(c, hipMalloc(&c->d_mvp, sizeof(float) * 16 * (size_t)(c->n_draws + 1) * N));
+  HIP_TRY(c, hipMalloc(&c->d_bg_z, sizeof(float) * N));
+  HIP_TRY(c, hipMalloc(&c->d_bg_mode, sizeof(uint32_t) * N));
+  HIP_TRY(c, hipMalloc(&c->d_counters, sizeof(Counters)));
+  HIP_TRY(c, hipMemset(c->d_counters, 0, sizeof(Counters)));
+  // identity defaults
+  static const double I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (int s = 0; s < N; s++) {
+    memcpy(c->h_cams[s].projection, I, sizeof I);
+    memcpy(c->h_cams[s].offset_inv, I, sizeof I);
+    memcpy(c->h_cams[s].cam_tf, I, sizeof I);
+    for (size_t l = 0; l < L; l++) memcpy(c->h_link_tf + ((size_t)s * L + l) * 16, I, sizeof I);
+    c->h_model_mask[s] = ~0ull;
+  }
+  // rasteriser working set
+  int G = c->params.max_inflight_streams ? (int)c->params.max_inflight_streams : 256;
+  G = std::min(G, N);
+  uint32_t cap = c->params.bin_capacity;
+  if (!cap) cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->n_tris + 16, 256), 4096);
+  // keep the bins under ~24 GiB by shrinking the in-flight group
+  const size_t budget = (size_t)24 << 30;
+  while (G > 1 && (size_t)G * tiles * cap * sizeof(TriRec) > budget) G = (G + 1) / 2;
+  c->group = G;
+  c->capacity = cap;
+  c->clip_capacity = (uint32_t)std::min<size_t>((size_t)G * 8192, (size_t)1 << 24);
+  HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(TriRec)));
+  HIP_TRY(c, hipMalloc(&c->d_bin_count, (size_t)G * tiles * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemset(c->d_bin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * sizeof(ClipItem)));
+  if (c->params.flags & RTUF_FLAG_TWO_KERNEL)
+    HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)G * c->width * c->height * sizeof(float)));
+  return RTUF_OK;
+}
+
+int rtuf_finalize_models(rtuf_context* c)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (c->finalized) return c->fail(RTUF_ERR_STATE, "models already finalised");
+  hipSetDevice(c->device);
+  std::vector<float4> verts;
+  std::vector<uint4> tris;
+  std::vector<Chunk> chunks;
+  std::vector<Draw> draws;
+  int link_base = 0;
+  for (size_t mi = 0; mi < c->models.size(); mi++) {
+    HostModel& m = c->models[mi];
+    m.link_base = link_base;
+    for (size_t li = 0; li < m.links.size(); li++) {
+      for (const HostDraw& hd : m.links[li].draws) {
+        Draw d{};
+        d.link = (uint32_t)(link_base + li);
+        d.pre_op = (uint32_t)hd.pre_op;
+        d.op[0] = hd.op[0]; d.op[1] = hd.op[1]; d.op[2] = hd.op[2];
+        d.model = (uint32_t)mi;
+        const uint32_t draw_id = (uint32_t)draws.size();
+        draws.push_back(d);
+        const uint32_t vbase = (uint32_t)verts.size();
+        for (size_t v = 0; v + 2 < hd.verts.size(); v += 3)
+          verts.push_back(make_float4(hd.verts[v], hd.verts[v + 1], hd.verts[v + 2], 1.0f));
+        const uint32_t nt = (uint32_t)(hd.tris.size() / 3);
+        for (uint32_t t = 0; t < nt; t += kBlock) {
+          Chunk ch{};
+          ch.tri_begin = (uint32_t)tris.size() + t;
+          ch.tri_count = std::min<uint32_t>(kBlock, nt - t);
+          ch.draw = draw_id;
+          ch.model = (uint32_t)mi;
+          chunks.push_back(ch);
+        }
+        for (uint32_t t = 0; t < nt; t++) {
+          const uint32_t order = (uint32_t)tris.size() + 1;   // draw-order sequence, background is 0
+          tris.push_back(make_uint4(vbase + hd.tris[3 * t], vbase + hd.tris[3 * t + 1], vbase + hd.tris[3 * t + 2], order));
+        }
+      }
+    }
+    link_base += (int)m.links.size();
+  }
+  c->n_links = link_base;
+  c->n_draws = (int)draws.size();
+  c->n_tris = (int64_t)tris.size();
+  // background quad as the hidden last draw (used only when a stream's projection does not make
+  // it a constant full-screen plane): GL_QUADS -> (0,1,3), (1,2,3); both with order 0
+  {
+    const float zq = (float)((double)c->params.far_plane * 0.99);
+    const uint32_t vbase = (uint32_t)verts.size();
+    verts.push_back(make_float4(-100.0f, -100.0f, zq, 1.0f));
+    verts.push_back(make_float4(100.0f, -100.0f, zq, 1.0f));
+    verts.push_back(make_float4(100.0f, 100.0f, zq, 1.0f));
+    verts.push_back(make_float4(-100.0f, 100.0f, zq, 1.0f));
+    Chunk ch{};
+    ch.tri_begin = (uint32_t)tris.size(); ch.tri_count = 2; ch.draw = (uint32_t)c->n_draws; ch.model = 0;
+    c->bg_chunk = (uint32_t)chunks.size();
+    chunks.push_back(ch);
+    tris.push_back(make_uint4(vbase + 0, vbase + 1, vbase + 3, 0));
+    tris.push_back(make_uint4(vbase + 1, vbase + 2, vbase + 3, 0));
+  }
+  c->n_chunks = (int)chunks.size();
+  if (draws.empty()) draws.push_back(Draw{});
+  HIP_TRY(c, hipMalloc(&c->d_verts, verts.size() * sizeof(float4)));
+  HIP_TRY(c, hipMalloc(&c->d_tris, tris.size() * sizeof(uint4)));
+  HIP_TRY(c, hipMalloc(&c->d_chunks, chunks.size() * sizeof(Chunk)));
+  HIP_TRY(c, hipMalloc(&c->d_draws, draws.size() * sizeof(Draw)));
+  HIP_TRY(c, hipMemcpy(c->d_verts, verts.data(), verts.size() * sizeof(float4), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_tris, tris.data(), tris.size() * sizeof(uint4), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_draws, draws.data(), draws.size() * sizeof(Draw), hipMemcpyHostToDevice));
+  const int rc = alloc_frame_buffers(c);
+  if (rc != RTUF_OK) return rc;
+  // host copies of the geometry are no longer needed
+  for (HostModel& m : c->models)
+    for (HostLink& l : m.links)
+      for (HostDraw& d : l.draws) { d.verts.clear(); d.verts.shrink_to_fit(); d.tris.clear(); d.tris.shrink_to_fit(); }
+  c->finalized = true;
+  return RTUF_OK;
+}
+
+int rtuf_set_stream_models(rtuf_context* c, int stream, const int* model_ids, int n_models)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (stream < 0 || stream >= c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream %d", stream);
+  uint64_t mask = 0;
+  for (int i = 0; i < n_models; i++) {
+    if (model_ids[i] < 0 || model_ids[i] >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model_ids[i]);
+    mask |= 1ull << model_ids[i];
+  }
+  c->h_model_mask[stream] = mask;
+  return RTUF_OK;
+}
+
+// ---- poses ----------------------------------------------------------------------------
+int rtuf_set_camera(rtuf_context* c, int stream, const double projection[16], const double camera_offset_inv[16],
+                    const double camera_tf[16])
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (stream < 0 || stream >= c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream %d", stream);
+  Camera& cam = c->h_cams[stream];
+  if (projection) memcpy(cam.projection, projection, sizeof cam.projection);
+  if (camera_offset_inv) memcpy(cam.offset_inv, camera_offset_inv, sizeof cam.offset_inv);
+  if (camera_tf) memcpy(cam.cam_tf, camera_tf, sizeof cam.cam_tf);
+  return RTUF_OK;
+}
+
+// getProjectionMatrix, src/urdf_filter.cpp:459-501
+void rtuf_projection_from_intrinsics(double fx, double fy, double cx, double cy, double Tx, double Ty, int width,
+                                     int height, double near_plane, double far_plane, double P[16],
+                                     double* camera_tx, double* camera_ty)
+{
+  if (camera_tx) *camera_tx = -1 * (Tx / fx);
+  if (camera_ty) *camera_ty = -1 * (Ty / fy);
+  for (int i = 0; i < 16; i++) P[i] = 0.0;
+  P[0] = -2.0 * fx / width;
+  P[5] = 2.0 * fy / height;
+  P[8] = 2.0 * (0.5 - cx / width);
+  P[9] = 2.0 * (cy / height - 0.5);
+  P[10] = -(far_plane + near_plane) / (far_plane - near_plane);
+  P[14] = -2.0 * far_plane * near_plane / (far_plane - near_plane);
+  P[11] = -1;
+}
+
+int rtuf_set_link_poses(rtuf_context* c, int stream, int model, const double* link_tf, int n_links)
+{
+  if (!c || !link_tf) return RTUF_ERR_INVALID;
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (stream < 0 || stream >= c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream %d", stream);
+  if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
+  const HostModel& m = c->models[model];
+  if (n_links != (int)m.links.size()) return c->fail(RTUF_ERR_INVALID, "model %d has %d links, got %d", model, (int)m.links.size(), n_links);
+  memcpy(c->h_link_tf + ((size_t)stream * c->n_links + m.link_base) * 16, link_tf, sizeof(double) * 16 * (size_t)n_links);
+  return RTUF_OK;
+}
+
+// ---- the hot path ---------------------------------------------------------------------
+static hipEvent_t get_event(rtuf_context* c, size_t i)
+{
+  while (c->events.size() <= i) {
+    hipEvent_t ev; hipEventCreate(&ev); c->events.push_back(ev);
+  }
+  return c->events[i];
+}
+
+static int grow_bins(rtuf_context* c, uint32_t needed)
+{
+  const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
+  uint32_t cap = c->capacity;
+  while (cap < needed) cap *= 2;
+  hipFree(c->d_bins); c->d_bins = nullptr;
+  int G = c->group;
+  const size_t budget = (size_t)48 << 30;
+  while (G > 1 && (size_t)G * tiles * cap * sizeof(TriRec) > budget) G = (G + 1) / 2;
+  if ((size_t)G * tiles * cap * sizeof(TriRec) > ((size_t)160 << 30)) return c->fail(RTUF_ERR_CAPACITY, "bin capacity %u too large", cap);
+  c->group = G;
+  c->capacity = cap;
+  HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(TriRec)));
+  c->stats.regrowths++;
+  return RTUF_OK;
+}
+
+static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask)
+{
+  hipStream_t st = c->stream;
+  const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
+  const size_t L = (size_t)std::max(c->n_links, 1);
+  const size_t plane = (size_t)c->width * c->height;
+  size_t ev = 0;
+  if (c->timing) hipEventRecord(get_event(c, ev++), st);
+  HIP_TRY(c, hipMemcpyAsync(c->d_cams, c->h_cams, sizeof(Camera) * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(c->d_link_tf, c->h_link_tf, sizeof(double) * 16 * L * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(c->d_model_mask, c->h_model_mask, sizeof(uint64_t) * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(Counters), st));
+  PoseArgs pa{};
+  pa.cams = c->d_cams; pa.link_tf = c->d_link_tf; pa.draws = c->d_draws; pa.mvp = c->d_mvp;
+  pa.bg_z = c->d_bg_z; pa.bg_mode = c->d_bg_mode;
+  pa.n_streams = n; pa.n_draws = c->n_draws; pa.n_links = (int)L; pa.z_far = c->params.far_plane;
+  pa.width = c->width; pa.height = c->height;
+  launch_pose(pa, st);
+  if (c->timing) hipEventRecord(get_event(c, ev++), st);
+  for (int base = 0; base < n; base += c->group) {
+    const int gs = std::min(c->group, n - base);
+    // clip list is per group
+    HIP_TRY(c, hipMemsetAsync(&c->d_counters->clip_count, 0, sizeof(unsigned int), st));
+    SetupArgs sa{};
+    sa.verts = c->d_verts; sa.tris = c->d_tris; sa.chunks = c->d_chunks; sa.mvp = c->d_mvp;
+    sa.model_mask = c->d_model_mask; sa.bg_mode = c->d_bg_mode; sa.bins = c->d_bins; sa.bin_count = c->d_bin_count;
+    sa.clip_list = c->d_clip_list; sa.counters = c->d_counters; sa.group_base = base; sa.group_size = gs;
+    sa.n_draws = c->n_draws; sa.width = c->width; sa.height = c->height; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
+    sa.capacity = c->capacity; sa.clip_capacity = c->clip_capacity; sa.bg_chunk = c->bg_chunk;
+    launch_setup(sa, c->n_chunks, st);
+    launch_clip(sa, st);
+    if (c->timing) hipEventRecord(get_event(c, ev++), st);
+    TileArgs ta{};
+    ta.bins = c->d_bins; ta.bin_count = c->d_bin_count; ta.depth = d_depth; ta.masked = d_masked; ta.mask = d_mask;
+    ta.zsurface = c->d_zsurface; ta.bg_z = c->d_bg_z; ta.bg_mode = c->d_bg_mode; ta.counters = c->d_counters;
+    ta.group_base = base; ta.group_size = gs; ta.width = c->width; ta.height = c->height;
+    ta.tiles_x = c->tiles_x; ta.tiles_y = c->tiles_y; ta.capacity = c->capacity; ta.flags = c->params.flags;
+    ta.z_near = c->params.near_plane; ta.z_far = c->params.far_plane;
+    ta.max_diff = c->params.depth_distance_threshold; ta.replace_value = c->params.filter_replace_value;
+    launch_tile(ta, two, st);
+    if (c->timing) hipEventRecord(get_event(c, ev++), st);
+    if (two) {
+      CompareArgs ca{};
+      ca.depth = d_depth + (size_t)base * plane; ca.zsurface = c->d_zsurface;
+      ca.masked = d_masked + (size_t)base * plane; ca.mask = d_mask ? d_mask + (size_t)base * plane : nullptr;
+      ca.n_pixels = (size_t)gs * plane;
+      ca.z_near = ta.z_near; ca.z_far = ta.z_far; ca.max_diff = ta.max_diff; ca.replace_value = ta.replace_value;
+      launch_compare(ca, st);
+    }
+    if (c->timing) hipEventRecord(get_event(c, ev++), st);
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipGetLastError());
+  return RTUF_OK;
+}
+
+int rtuf_filter_batch_device(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (n <= 0 || n > c->max_streams || !d_depth || !d_masked) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
+  hipSetDevice(c->device);
+  if ((c->params.flags & RTUF_FLAG_TWO_KERNEL) && !c->d_zsurface)
+    HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));
+  if (c->pending) { const int rc = rtuf_sync(c); if (rc != RTUF_OK) return rc; }
+  c->last_n = n; c->last_depth = d_depth; c->last_masked = d_masked; c->last_mask = d_mask;
+  const int rc = enqueue_batch(c, n, d_depth, d_masked, d_mask);
+  if (rc == RTUF_OK) c->pending = true;
+  return rc;
+}
+
+int rtuf_sync(rtuf_context* c)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  hipSetDevice(c->device);
+  for (int attempt = 0; attempt < 8; attempt++) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!c->pending) return RTUF_OK;
+    const Counters& k = *c->h_counters;
+    c->stats.triangles_submitted = (uint64_t)c->n_tris * (uint64_t)c->last_n;
+    c->stats.triangles_binned = k.tris_binned;
+    c->stats.bin_entries = k.bin_entries;
+    c->stats.triangles_clipped = k.clip_count;
+    c->stats.max_bin_fill = k.max_bin_fill;
+    c->stats.bin_capacity = c->capacity;
+    const bool bin_over = k.max_bin_fill > c->capacity;
+    const bool clip_over = k.clip_overflow != 0;
+    if (!bin_over && !clip_over) {
+      c->pending = false;
+      if (c->timing && c->events.size() >= 2) {
+        // events: [start, pose_end, (setup_end, tile_end, compare_end) per group ...]
+        float ms = 0;
+        c->stats.ms_pose = c->stats.ms_setup = c->stats.ms_raster = c->stats.ms_compare = 0;
+        hipEventElapsedTime(&ms, c->events[0], c->events[1]); c->stats.ms_pose = ms;
+        size_t e = 1;
+        for (int base = 0; base < c->last_n; base += c->group) {
+          hipEventElapsedTime(&ms, c->events[e], c->events[e + 1]); c->stats.ms_setup += ms;
+          hipEventElapsedTime(&ms, c->events[e + 1], c->events[e + 2]); c->stats.ms_raster += ms;
+          hipEventElapsedTime(&ms, c->events[e + 2], c->events[e + 3]); c->stats.ms_compare += ms;
+          e += 3;
+        }
+        hipEventElapsedTime(&ms, c->events[0], c->events[e]); c->stats.ms_total = ms;
+      }
+      return RTUF_OK;
+    }
+    // overflow: enlarge and run the batch again (inputs are still resident)
+    if (bin_over) { const int rc = grow_bins(c, k.max_bin_fill); if (rc != RTUF_OK) { c->pending = false; return rc; } }
+    if (clip_over) {
+      hipFree(c->d_clip_list); c->d_clip_list = nullptr;
+      c->clip_capacity *= 4;
+      HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * sizeof(ClipItem)));
+      c->stats.regrowths++;
+    }
+    if (c->d_zsurface && (c->params.flags & RTUF_FLAG_TWO_KERNEL)) {
+      // group may have shrunk; the surface is sized for the old (larger) group, still fine
+    }
+    const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
+    HIP_TRY(c, hipMemsetAsync(c->d_bin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->stream));
+    const int rc = enqueue_batch(c, c->last_n, c->last_depth, c->last_masked, c->last_mask);
+    if (rc != RTUF_OK) { c->pending = false; return rc; }
+  }
+  c->pending = false;
+  return c->fail(RTUF_ERR_CAPACITY, "tile bins still overflow after regrowth");
+}
+
+void* rtuf_stream(rtuf_context* c) { return c ? (void*)c->stream : nullptr; }
+
+static int ensure_staging(rtuf_context* c, size_t n)
+{
+  if (c->staged_streams >= n) return RTUF_OK;
+  const size_t plane = (size_t)c->width * c->height;
+  if (c->d_depth) { hipFree(c->d_depth); hipFree(c->d_masked); hipFree(c->d_mask); c->d_depth = nullptr; c->d_masked = nullptr; c->d_mask = nullptr; }
+  HIP_TRY(c, hipMalloc(&c->d_depth, n * plane * sizeof(float)));
+  HIP_TRY(c, hipMalloc(&c->d_masked, n * plane * sizeof(float)));
+  HIP_TRY(c, hipMalloc(&c->d_mask, n * plane));
+  c->staged_streams = n;
+  return RTUF_OK;
+}
+
+int rtuf_filter_batch(rtuf_context* c, int n, const float* const* depth_in, float* const* masked_out,
+                      uint8_t* const* mask_out)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (n <= 0 || n > c->max_streams || !depth_in || !masked_out) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
+  hipSetDevice(c->device);
+  int rc = ensure_staging(c, (size_t)n);
+  if (rc != RTUF_OK) return rc;
+  const size_t plane = (size_t)c->width * c->height;
+  for (int s = 0; s < n; s++) {
+    if (!depth_in[s] || !masked_out[s]) return c->fail(RTUF_ERR_INVALID, "null plane for stream %d", s);
+    HIP_TRY(c, hipMemcpyAsync(c->d_depth + s * plane, depth_in[s], plane * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  }
+  bool any_mask = false;
+  if (mask_out) for (int s = 0; s < n; s++) any_mask |= mask_out[s] != nullptr;
+  rc = rtuf_filter_batch_device(c, n, c->d_depth, c->d_masked, any_mask ? c->d_mask : nullptr);
+  if (rc != RTUF_OK) return rc;
+  rc = rtuf_sync(c);
+  if (rc != RTUF_OK) return rc;
+  for (int s = 0; s < n; s++) {
+    HIP_TRY(c, hipMemcpyAsync(masked_out[s], c->d_masked + s * plane, plane * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (mask_out && mask_out[s])
+      HIP_TRY(c, hipMemcpyAsync(mask_out[s], c->d_mask + s * plane, plane, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return RTUF_OK;
+}
+
+int rtuf_filter(rtuf_context* c, const unsigned char* buffer, const double* projection, int width, int height)
+{
+  if (!c || !buffer) return RTUF_ERR_INVALID;
+  if (width != c->width || height != c->height)
+    return c->fail(RTUF_ERR_INVALID, "image size %dx%d differs from the context's %dx%d (the reference re-runs initGL here; create a new context instead)",
+                   width, height, c->width, c->height);
+  if (projection) { const int rc = rtuf_set_camera(c, 0, projection, nullptr, nullptr); if (rc != RTUF_OK) return rc; }
+  const size_t plane = (size_t)width * height;
+  c->single_masked.resize(plane);
+  c->single_mask.resize(plane);
+  const float* in = reinterpret_cast<const float*>(buffer);
+  float* mo = c->single_masked.data();
+  uint8_t* mk = c->single_mask.data();
+  return rtuf_filter_batch(c, 1, &in, &mo, &mk);
+}
+
+const float* rtuf_get_masked_depth(const rtuf_context* c) { return (c && !c->single_masked.empty()) ? c->single_masked.data() : nullptr; }
+const uint8_t* rtuf_get_mask(const rtuf_context* c) { return (c && !c->single_mask.empty()) ? c->single_mask.data() : nullptr; }
+
+int rtuf_get_stats(rtuf_context* c, rtuf_stats* out)
+{
+  if (!c || !out) return RTUF_ERR_INVALID;
+  *out = c->stats;
+  out->bin_capacity = c->capacity;
+  return RTUF_OK;
+}
+
+int rtuf_enable_timing(rtuf_context* c, int on)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  c->timing = on != 0;
+  return RTUF_OK;
+}
+
+int rtuf_debug_read_zsurface(rtuf_context* c, int n, float* host_out)
+{
+  if (!c || !host_out) return RTUF_ERR_INVALID;
+  if (!(c->params.flags & RTUF_FLAG_TWO_KERNEL) || !c->d_zsurface) return c->fail(RTUF_ERR_STATE, "z-surface exists only in two-kernel mode");
+  if (n <= 0 || n > c->group) return c->fail(RTUF_ERR_INVALID, "z-surface holds the last in-flight group (%d streams)", c->group);
+  hipSetDevice(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(host_out, c->d_zsurface, (size_t)n * c->width * c->height * sizeof(float), hipMemcpyDeviceToHost));
+  return RTUF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+// rtuf_device.h -- device-side data layout shared by the HIP kernels and the host API.
+//
+// HBM layout (all arrays owned by one rtuf_context, one GPU):
+//   static geometry, uploaded once by rtuf_finalize_models()
+//     verts  float4[V]   object-space positions (w unused)            16 B / vertex
+//     tris   uint4[T]    absolute vertex ids i0,i1,i2 + draw-order     16 B / triangle
+//                        sequence number (>= 1; 0 is the background)
+//     chunks Chunk[C]    <= 256 consecutive triangles of ONE draw call
+//     draws  Draw[D]     link id + the glScalef/glTranslatef of the draw
+//   per frame, per stream s (slot within the batch)
+//     cams   Camera[N]   projection / camera_offset_inv / camera_tf as f64
+//     link_tf f64[N][L][16]
+//     mvp    f32[N][D][16]  written by pose_kernel
+//     depth  f32[N][H][W] in, masked f32[N][H][W] + mask u8[N][H][W] out
+//   rasteriser working set, per in-flight stream g and screen tile
+//     bin_count u32[G][tiles], bins TriRec[G][tiles][capacity]
+//     clip_list ClipItem[], zsurface f32[G][H][W] (two-kernel mode only)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtuf {
+
+constexpr int kTileW = 64;
+constexpr int kTileH = 64;
+constexpr int kBlock = 256;
+
+struct alignas(16) TriRec {     // 64 B: one rasterisable triangle inside one tile bin
+  int32_t A[3];                 // edge i is inside  <=>  A[i]*px + B[i]*py + C[i] > 0
+  int32_t B[3];
+  int32_t C[3];
+  float a0, dzdx, dzdy;         // z(px,py) = fma(dzdy, py, fma(dzdx, px, a0))
+  uint32_t bbx;                 // x0 | x1 << 16   (inclusive pixel bounds)
+  uint32_t bby;                 // y0 | y1 << 16
+  uint32_t order;               // draw-order sequence number of the source triangle
+  uint32_t pad;
+};
+static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
+
+struct Chunk {
+  uint32_t tri_begin;
+  uint32_t tri_count;
+  uint32_t draw;
+  uint32_t model;
+};
+
+struct Draw {
+  uint32_t link;                // global link index (row of link_tf)
+  uint32_t pre_op;              // RTUF_OP_*
+  float op[3];
+  uint32_t model;
+  uint32_t pad[2];
+};
+
+struct Camera {
+  double projection[16];
+  double offset_inv[16];
+  double cam_tf[16];
+};
+
+struct ClipItem {
+  uint32_t slot;                // stream slot within the in-flight group
+  uint32_t tri;                 // global triangle index
+  uint32_t draw;
+  uint32_t pad;
+};
+
+struct Counters {               // device-side statistics / overflow detection
+  unsigned long long tris_binned;
+  unsigned long long bin_entries;
+  unsigned int clip_count;      // entries in clip_list
+  unsigned int max_bin_fill;
+  unsigned int clip_overflow;
+  unsigned int pad;
+};
+
+struct FrameConsts {
+  int width, height;
+  int tiles_x, tiles_y;
+  float z_near, z_far, max_diff, replace_value;
+  float bg_z;                   // window z of the background quad (constant plane)
+  uint32_t bg_key_hi;           // its 24-bit depth value
+  uint32_t flags;
+  uint32_t capacity;
+};
+
+
+// kernel argument blocks (passed by value) and host-callable launchers (rtuf_kernels.hip)
+struct PoseArgs {
+  const Camera* cams;        // [n_streams]
+  const double* link_tf;     // [n_streams][n_links][16]
+  const Draw* draws;         // [n_draws]
+  float* mvp;                // [n_streams][n_draws + 1][16]
+  float* bg_z;               // [n_streams]  window z of the background quad
+  uint32_t* bg_mode;         // [n_streams]  1 = constant full-screen plane (analytic), 0 = draw it as geometry
+  int n_streams, n_draws, n_links;
+  float z_far;
+  int width, height;
+};
+
+struct SetupArgs {
+  const float4* verts;
+  const uint4* tris;
+  const Chunk* chunks;
+  const float* mvp;              // [n_streams][n_draws + 1][16]
+  const uint64_t* model_mask;    // [n_streams] bit m set: stream renders model m
+  const uint32_t* bg_mode;       // [n_streams]
+  TriRec* bins;                  // [G][tiles][capacity]
+  uint32_t* bin_count;           // [G][tiles]
+  ClipItem* clip_list;
+  Counters* counters;
+  int group_base;                // first stream slot of this in-flight group
+  int group_size;
+  int n_draws;
+  int width, height, tiles_x, tiles_y;
+  uint32_t capacity;
+  uint32_t clip_capacity;
+  uint32_t bg_chunk;             // index of the background-quad chunk
+};
+
+struct TileArgs {
+  const TriRec* bins;
+  uint32_t* bin_count;           // reset to 0 by this kernel after use
+  const float* depth;            // [n][H][W]
+  float* masked;                 // [n][H][W]
+  uint8_t* mask;                 // [n][H][W] or nullptr
+  float* zsurface;               // [G][H][W]  (two-kernel mode)
+  const float* bg_z;             // [n]
+  const uint32_t* bg_mode;       // [n]
+  Counters* counters;
+  int group_base, group_size;
+  int width, height, tiles_x, tiles_y;
+  uint32_t capacity;
+  uint32_t flags;
+  float z_near, z_far, max_diff, replace_value;
+};
+
+struct CompareArgs {
+  const float* depth;     // group base
+  const float* zsurface;  // group base
+  float* masked;
+  uint8_t* mask;          // may be nullptr
+  size_t n_pixels;        // multiple of 4 handled vectorised, tail scalar
+  float z_near, z_far, max_diff, replace_value;
+};
+
+
+void launch_pose(const PoseArgs& a, hipStream_t st);
+void launch_setup(const SetupArgs& a, int n_chunks, hipStream_t st);
+void launch_clip(const SetupArgs& a, hipStream_t st);
+void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st);
+void launch_compare(const CompareArgs& a, hipStream_t st);
+
+}  // namespace rtuf

@@ -1,0 +1,716 @@
+// rtuf_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the depth self-filter.
+//
+// Pipeline per batch of camera streams (all on one HIP stream):
+//   pose_kernel     float32 OpenGL matrix stack per (stream, draw)      replaces urdf_filter.cpp:576-614,
+//                                                                       renderable.cpp:59-68, :95, :128, :427
+//   setup_kernel    one lane per triangle: vertex transform, clip test,  replaces urdf_filter.vert + the GL
+//                   viewport, 1/256-px snap, integer edge functions,     driver's primitive assembly / set-up
+//                   z plane, tile binning (64-B records)
+//   clip_kernel     the few triangles that cross a frustum plane:        (GL driver clipper)
+//                   Sutherland-Hodgman in clip space, fan, same set-up
+//   tile_kernel     one workgroup per (stream, 64x64 tile): the tile's   replaces GL rasterisation + 24-bit
+//                   depth keys live in LDS, fragments resolve with       GL_LESS depth test + urdf_filter.frag
+//                   64-bit LDS atomicMin, then the per-pixel compare     + glGetTexImage conversions
+//                   is done in place (fused) or the z-surface is written
+//   compare_kernel  two-kernel mode only: z-surface + sensor -> outputs  replaces urdf_filter.frag:19-36
+//
+// Exactness: results must equal the reference's GLSL running on Mesa llvmpipe bit for bit
+// (see oracle/rtuf_oracle.c for what that pins).  Every float operation whose rounding matters
+// is an explicit __f*_rn intrinsic, and the file is built with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rtuf_device.h"
+
+namespace rtuf {
+
+// ---------------------------------------------------------------------------------------
+// float32 matrix stack (GL semantics: every glMultMatrixd rounds its argument to float and
+// multiplies in float32, products accumulated left to right, no fused multiply-add)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void matmul4(float* __restrict__ out, const float* a, const float* b)
+{
+  float p[16];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float ai0 = a[i], ai1 = a[4 + i], ai2 = a[8 + i], ai3 = a[12 + i];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float s = __fmul_rn(ai0, b[4 * j]);
+      s = __fadd_rn(s, __fmul_rn(ai1, b[4 * j + 1]));
+      s = __fadd_rn(s, __fmul_rn(ai2, b[4 * j + 2]));
+      s = __fadd_rn(s, __fmul_rn(ai3, b[4 * j + 3]));
+      p[4 * j + i] = s;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) out[k] = p[k];
+}
+
+__device__ __forceinline__ void mult_d(float* top, const double* m)
+{
+  float f[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) f[k] = (float)m[k];
+  matmul4(top, top, f);
+}
+
+__device__ __forceinline__ void vs_position(const float* __restrict__ M, float x, float y, float z, float* c)
+{
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    float s = __fmul_rn(M[r], x);
+    s = __fadd_rn(s, __fmul_rn(M[4 + r], y));
+    s = __fadd_rn(s, __fmul_rn(M[8 + r], z));
+    s = __fadd_rn(s, M[12 + r]);
+    c[r] = s;
+  }
+}
+
+__device__ __forceinline__ unsigned clipmask_of(const float* c)
+{
+  unsigned m = 0;
+  if (c[0] > c[3]) m |= 1u;
+  if (0.0f > __fadd_rn(c[0], c[3])) m |= 2u;
+  if (c[1] > c[3]) m |= 4u;
+  if (0.0f > __fadd_rn(c[1], c[3])) m |= 8u;
+  if (0.0f > __fadd_rn(c[2], c[3])) m |= 16u;
+  if (c[2] > c[3]) m |= 32u;
+  return m;
+}
+
+struct Win { float x, y, z; };
+
+// viewport transform of a shaded vertex (fused multiply-add form)
+__device__ __forceinline__ Win viewport_vs(const float* c, float sx, float sy)
+{
+  const float rhw = __fdiv_rn(1.0f, c[3]);
+  Win w;
+  w.x = __fmaf_rn(__fmul_rn(c[0], rhw), sx, sx);
+  w.y = __fmaf_rn(__fmul_rn(c[1], rhw), sy, sy);
+  w.z = __fmaf_rn(__fmul_rn(c[2], rhw), 0.5f, 0.5f);
+  return w;
+}
+
+// viewport transform of a vertex made by the clipper (separate multiply and add)
+__device__ __forceinline__ Win viewport_clip(const float* c, float sx, float sy)
+{
+  const float oow = __fdiv_rn(1.0f, c[3]);
+  Win w;
+  w.x = __fadd_rn(__fmul_rn(__fmul_rn(c[0], oow), sx), sx);
+  w.y = __fadd_rn(__fmul_rn(__fmul_rn(c[1], oow), sy), sy);
+  w.z = __fadd_rn(__fmul_rn(__fmul_rn(c[2], oow), 0.5f), 0.5f);
+  return w;
+}
+
+// ---------------------------------------------------------------------------------------
+// pose_kernel: one thread per (stream, draw).  Draw index == n_draws is the background quad.
+// ---------------------------------------------------------------------------------------
+
+__global__ void pose_kernel(PoseArgs a)
+{
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per = a.n_draws + 1;
+  if (gid >= a.n_streams * per) return;
+  const int s = gid / per, d = gid - s * per;
+  const Camera& cam = a.cams[s];
+
+  float proj[16], mv[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) proj[k] = mv[k] = (k % 5 == 0) ? 1.0f : 0.0f;
+  mult_d(proj, cam.projection);
+  {
+    // gluLookAt(0,0,0, 0,0,1, 0,1,0) == diag(-1,1,-1,1), then glTranslated(-0,-0,-0)
+    const float la[16] = {-1, 0, 0, 0, 0, 1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 1};
+    matmul4(mv, mv, la);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float t = __fmul_rn(mv[r], -0.0f);
+      t = __fadd_rn(t, __fmul_rn(mv[4 + r], -0.0f));
+      t = __fadd_rn(t, __fmul_rn(mv[8 + r], -0.0f));
+      mv[12 + r] = __fadd_rn(t, mv[12 + r]);
+    }
+  }
+  float* out = a.mvp + ((size_t)s * per + d) * 16;
+  if (d == a.n_draws) {
+    // background quad (urdf_filter.cpp:591-596): drawn before the camera transforms
+    float m[16];
+    matmul4(m, proj, mv);
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[k] = m[k];
+    const float zq = (float)((double)a.z_far * 0.99);
+    const float qx[4] = {-100.0f, 100.0f, 100.0f, -100.0f};
+    const float qy[4] = {-100.0f, -100.0f, 100.0f, 100.0f};
+    float c0[4];
+    bool constant = true, covers = true;
+    unsigned andm = ~0u;
+    for (int i = 0; i < 4; i++) {
+      float c[4];
+      vs_position(m, qx[i], qy[i], zq, c);
+      if (i == 0) { c0[0] = c[0]; c0[1] = c[1]; c0[2] = c[2]; c0[3] = c[3]; }
+      if (c[2] != c0[2] || c[3] != c0[3]) constant = false;
+      const unsigned cm = clipmask_of(c);
+      if (cm & 48u) constant = false;               // must lie strictly inside near/far
+      if (!(c[3] > 0.0f)) constant = false;
+      // corner i must be outside the frustum sideways by a wide margin in both x and y
+      if (!(fabsf(c[0]) > 2.0f * c[3] && fabsf(c[1]) > 2.0f * c[3])) covers = false;
+      andm &= cm;
+    }
+    // the four corners must lie in four different xy quadrants (quad surrounds the frustum axis)
+    float cA[4], cB[4], cC[4];
+    vs_position(m, qx[1], qy[1], zq, cA);
+    vs_position(m, qx[2], qy[2], zq, cB);
+    vs_position(m, qx[3], qy[3], zq, cC);
+    const bool quadrants = (c0[0] < 0) != (cA[0] < 0) && (cA[1] < 0) != (cB[1] < 0) &&
+                           (cB[0] < 0) != (cC[0] < 0) && (cC[1] < 0) != (c0[1] < 0);
+    const bool ok = constant && covers && quadrants && andm == 0;
+    // constant plane: every clipped vertex keeps z_clip and w, so its window z is (z/w)*0.5+0.5
+    const float zw = __fadd_rn(__fmul_rn(__fmul_rn(c0[2], __fdiv_rn(1.0f, c0[3])), 0.5f), 0.5f);
+    a.bg_z[s] = zw;
+    a.bg_mode[s] = ok ? 1u : 0u;
+    return;
+  }
+  const Draw dr = a.draws[d];
+  mult_d(mv, cam.offset_inv);
+  mult_d(mv, cam.cam_tf);
+  mult_d(mv, a.link_tf + ((size_t)s * a.n_links + dr.link) * 16);
+  if (dr.pre_op == 1) {            // glScalef
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      mv[r] = __fmul_rn(mv[r], dr.op[0]);
+      mv[4 + r] = __fmul_rn(mv[4 + r], dr.op[1]);
+      mv[8 + r] = __fmul_rn(mv[8 + r], dr.op[2]);
+    }
+  } else if (dr.pre_op == 2) {     // glTranslatef
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float t = __fmul_rn(mv[r], dr.op[0]);
+      t = __fadd_rn(t, __fmul_rn(mv[4 + r], dr.op[1]));
+      t = __fadd_rn(t, __fmul_rn(mv[8 + r], dr.op[2]));
+      mv[12 + r] = __fadd_rn(t, mv[12 + r]);
+    }
+  }
+  float m[16];
+  matmul4(m, proj, mv);
+#pragma unroll
+  for (int k = 0; k < 16; k++) out[k] = m[k];
+}
+
+// ---------------------------------------------------------------------------------------
+// triangle set-up
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int snap(float v)
+{
+  return __float2int_rn(__fmul_rn(__fsub_rn(v, 0.5f), 256.0f));
+}
+
+// Builds the raster record of one window-space triangle.  Returns false when it covers no
+// pixel centre of the width x height frame.
+__device__ __forceinline__ bool make_record(Win v0, Win v1, Win v2, uint32_t order, int width, int height,
+                                            TriRec& r)
+{
+  int x0 = snap(v0.x), y0 = snap(v0.y);
+  int x1 = snap(v1.x), y1 = snap(v1.y);
+  const int x2 = snap(v2.x), y2 = snap(v2.y);
+  const long long area = (long long)(x0 - x1) * (y2 - y0) - (long long)(x2 - x0) * (y0 - y1);
+  if (area == 0) return false;
+  if (area < 0) {   // orient: swap vertices 0 and 1 (fixed and float)
+    int t = x0; x0 = x1; x1 = t;
+    t = y0; y0 = y1; y1 = t;
+    Win tw = v0; v0 = v1; v1 = tw;
+  }
+  const int minx = min(x0, min(x1, x2)), maxx = max(x0, max(x1, x2));
+  const int miny = min(y0, min(y1, y2)), maxy = max(y0, max(y1, y2));
+  int bx0 = (minx + 255) >> 8, bx1 = (maxx - 1) >> 8;
+  int by0 = (miny + 255) >> 8, by1 = (maxy - 1) >> 8;
+  bx0 = max(bx0, 0); by0 = max(by0, 0);
+  bx1 = min(bx1, width - 1); by1 = min(by1, height - 1);
+  if (bx1 < bx0 || by1 < by0) return false;
+
+  const int xs[3] = {x0, x1, x2}, ys[3] = {y0, y1, y2};
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int j = (i + 1) % 3;
+    const int dcdx = ys[i] - ys[j];
+    const int dcdy = xs[i] - xs[j];
+    long long c = (long long)dcdx * xs[i] - (long long)dcdy * ys[i];
+    if (dcdx < 0 || (dcdx == 0 && dcdy > 0)) c += 1;   // inclusive on low-x / low-row edges
+    // inside <=> c - dcdx*256*px + dcdy*256*py > 0  <=>  ceil(c/256) - dcdx*px + dcdy*py > 0
+    r.A[i] = -dcdx;
+    r.B[i] = dcdy;
+    r.C[i] = (int)(-((-c) >> 8));
+  }
+  // z plane from the unsnapped float vertices
+  const float x0c = __fsub_rn(v0.x, 0.5f), y0c = __fsub_rn(v0.y, 0.5f);
+  const float dx01 = __fsub_rn(v0.x, v1.x), dy01 = __fsub_rn(v0.y, v1.y);
+  const float dx20 = __fsub_rn(v2.x, v0.x), dy20 = __fsub_rn(v2.y, v0.y);
+  const float ooa = __fdiv_rn(1.0f, __fsub_rn(__fmul_rn(dx01, dy20), __fmul_rn(dy01, dx20)));
+  const float dy20o = __fmul_rn(dy20, ooa), dy01o = __fmul_rn(dy01, ooa);
+  const float dx20o = __fmul_rn(dx20, ooa), dx01o = __fmul_rn(dx01, ooa);
+  const float da01 = __fsub_rn(v0.z, v1.z), da20 = __fsub_rn(v2.z, v0.z);
+  r.dzdx = __fsub_rn(__fmul_rn(da01, dy20o), __fmul_rn(da20, dy01o));
+  r.dzdy = __fsub_rn(__fmul_rn(da20, dx01o), __fmul_rn(da01, dx20o));
+  r.a0 = __fsub_rn(v0.z, __fadd_rn(__fmul_rn(r.dzdx, x0c), __fmul_rn(r.dzdy, y0c)));
+  r.bbx = (uint32_t)bx0 | ((uint32_t)bx1 << 16);
+  r.bby = (uint32_t)by0 | ((uint32_t)by1 << 16);
+  r.order = order;
+  r.pad = 0;
+  return true;
+}
+
+
+__device__ __forceinline__ void store_record(TriRec* dst, const TriRec& r)
+{
+  const uint4* s = reinterpret_cast<const uint4*>(&r);
+  uint4* d = reinterpret_cast<uint4*>(dst);
+  d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+}
+
+// Appends the record to every tile bin its bounding box touches.
+__device__ __forceinline__ uint32_t emit_record(const SetupArgs& a, int slot, const TriRec& r)
+{
+  const int tx0 = (int)(r.bbx & 0xffff) / kTileW, tx1 = (int)(r.bbx >> 16) / kTileW;
+  const int ty0 = (int)(r.bby & 0xffff) / kTileH, ty1 = (int)(r.bby >> 16) / kTileH;
+  const int tiles = a.tiles_x * a.tiles_y;
+  uint32_t n = 0;
+  for (int ty = ty0; ty <= ty1; ty++)
+    for (int tx = tx0; tx <= tx1; tx++) {
+      const size_t bin = (size_t)slot * tiles + (size_t)ty * a.tiles_x + tx;
+      const uint32_t pos = atomicAdd(&a.bin_count[bin], 1u);
+      if (pos < a.capacity) store_record(a.bins + bin * a.capacity + pos, r);
+      n++;
+    }
+  return n;
+}
+
+__global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
+{
+  const Chunk ch = a.chunks[blockIdx.x];
+  const int slot = blockIdx.y;                       // stream slot within the group
+  const int stream = a.group_base + slot;
+  if (blockIdx.x == a.bg_chunk) {
+    if (a.bg_mode[stream]) return;                   // analytic background: nothing to rasterise
+  } else if (!((a.model_mask[stream] >> ch.model) & 1ull)) {
+    return;
+  }
+  const int tid = threadIdx.x;
+  uint32_t binned = 0, entries = 0;
+  if (tid < (int)ch.tri_count) {
+    const float* __restrict__ M = a.mvp + ((size_t)stream * (a.n_draws + 1) + ch.draw) * 16;
+    const uint32_t ti = ch.tri_begin + tid;
+    const uint4 t = a.tris[ti];
+    const float4 p0 = a.verts[t.x], p1 = a.verts[t.y], p2 = a.verts[t.z];
+    float c0[4], c1[4], c2[4];
+    vs_position(M, p0.x, p0.y, p0.z, c0);
+    vs_position(M, p1.x, p1.y, p1.z, c1);
+    vs_position(M, p2.x, p2.y, p2.z, c2);
+    const unsigned m0 = clipmask_of(c0), m1 = clipmask_of(c1), m2 = clipmask_of(c2);
+    if ((m0 & m1 & m2) == 0) {
+      if ((m0 | m1 | m2) != 0) {
+        // crosses a frustum plane: defer to clip_kernel
+        const uint32_t k = atomicAdd(&a.counters->clip_count, 1u);
+        if (k < a.clip_capacity) {
+          ClipItem it; it.slot = (uint32_t)slot; it.tri = ti; it.draw = ch.draw; it.pad = 0;
+          a.clip_list[k] = it;
+        } else {
+          atomicExch(&a.counters->clip_overflow, 1u);
+        }
+      } else {
+        const float sx = 0.5f * (float)a.width, sy = 0.5f * (float)a.height;
+        TriRec r;
+        if (make_record(viewport_vs(c0, sx, sy), viewport_vs(c1, sx, sy), viewport_vs(c2, sx, sy), t.w,
+                        a.width, a.height, r)) {
+          binned = 1;
+          entries = emit_record(a, slot, r);
+        }
+      }
+    }
+  }
+  // statistics: one atomic per wave
+  const unsigned long long bm = __ballot(binned != 0);
+  uint32_t e = entries;
+  for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off);
+  if ((tid & 63) == 0 && bm) {
+    atomicAdd(&a.counters->tris_binned, (unsigned long long)__popcll(bm));
+    atomicAdd(&a.counters->bin_entries, (unsigned long long)e);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// clip_kernel: one thread per triangle that crosses a frustum plane.  Sutherland-Hodgman in
+// clip space, planes in the order +x, -x, +y, -y, near, far; each new vertex is interpolated
+// from the end point closer to the plane; the polygon is emitted as the fan
+// (v[i-1], v[i], v[0]).
+// ---------------------------------------------------------------------------------------
+struct ClipVert { float c[4]; Win w; };
+
+__device__ __forceinline__ float clipdist(const float* c, int plane)
+{
+  // dot4(clip, plane) with planes (-1,0,0,1) (1,0,0,1) (0,-1,0,1) (0,1,0,1) (0,0,1,1) (0,0,-1,1)
+  const float px = plane == 0 ? -1.0f : (plane == 1 ? 1.0f : 0.0f);
+  const float py = plane == 2 ? -1.0f : (plane == 3 ? 1.0f : 0.0f);
+  const float pz = plane == 4 ? 1.0f : (plane == 5 ? -1.0f : 0.0f);
+  float s = __fmul_rn(c[0], px);
+  s = __fadd_rn(s, __fmul_rn(c[1], py));
+  s = __fadd_rn(s, __fmul_rn(c[2], pz));
+  s = __fadd_rn(s, c[3]);
+  return s;
+}
+
+__device__ void clip_one(const SetupArgs& a, const ClipItem it);
+
+__global__ __launch_bounds__(kBlock) void clip_kernel(SetupArgs a)
+{
+  const uint32_t n = min(a.counters->clip_count, a.clip_capacity);
+  for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n; gid += gridDim.x * blockDim.x)
+    clip_one(a, a.clip_list[gid]);
+}
+
+__device__ void clip_one(const SetupArgs& a, const ClipItem it)
+{
+  const int slot = (int)it.slot, stream = a.group_base + slot;
+  const float* __restrict__ M = a.mvp + ((size_t)stream * (a.n_draws + 1) + it.draw) * 16;
+  const uint4 t = a.tris[it.tri];
+  const float sx = 0.5f * (float)a.width, sy = 0.5f * (float)a.height;
+
+  constexpr int kMaxV = 24, kMaxP = 12;
+  ClipVert pool[kMaxV];
+  int npool = 3;
+  unsigned ormask = 0;
+  {
+    const uint32_t vi[3] = {t.x, t.y, t.z};
+    for (int i = 0; i < 3; i++) {
+      const float4 p = a.verts[vi[i]];
+      vs_position(M, p.x, p.y, p.z, pool[i].c);
+      pool[i].w = viewport_vs(pool[i].c, sx, sy);
+      ormask |= clipmask_of(pool[i].c);
+    }
+  }
+  int la[kMaxP + 1], lb[kMaxP + 1];
+  int* inl = la; int* outl = lb;
+  int nv = 3;
+  inl[0] = 0; inl[1] = 1; inl[2] = 2;
+  unsigned clipmask = ormask;
+  bool bad = false;
+  while (clipmask && nv >= 3 && !bad) {
+    const int plane = __ffs((int)clipmask) - 1;
+    clipmask &= ~(1u << plane);
+    if (nv >= kMaxP) { bad = true; break; }
+    int prev = inl[0];
+    float dp_prev = clipdist(pool[prev].c, plane);
+    int outc = 0;
+    inl[nv] = inl[0];
+    for (int i = 1; i <= nv; i++) {
+      const int cur = inl[i];
+      const float dp = clipdist(pool[cur].c, plane);
+      bool diff;
+      if (dp_prev >= 0.0f) {
+        if (outc >= kMaxP) { bad = true; break; }
+        outl[outc++] = prev;
+        diff = dp < 0.0f;
+      } else {
+        diff = !(dp < 0.0f);
+      }
+      if (diff) {
+        if (npool >= kMaxV || outc >= kMaxP) { bad = true; break; }
+        const float denom = __fsub_rn(dp, dp_prev);
+        bool from_cur;
+        if (dp < 0.0f) from_cur = dp_prev > -dp;        // going out
+        else from_cur = !(dp > -dp_prev);               // coming in
+        const float tt = from_cur ? __fdiv_rn(dp, denom) : __fdiv_rn(-dp_prev, denom);
+        const float* o = from_cur ? pool[cur].c : pool[prev].c;
+        const float* in = from_cur ? pool[prev].c : pool[cur].c;
+        ClipVert& nvx = pool[npool];
+#pragma unroll
+        for (int k = 0; k < 4; k++) nvx.c[k] = __fadd_rn(__fmul_rn(__fsub_rn(in[k], o[k]), tt), o[k]);
+        nvx.w = viewport_clip(nvx.c, sx, sy);
+        outl[outc++] = npool++;
+      }
+      prev = cur;
+      dp_prev = dp;
+    }
+    int* sw = inl; inl = outl; outl = sw;
+    nv = outc;
+  }
+  if (bad || nv < 3) return;
+  uint32_t binned = 0, entries = 0;
+  for (int i = 2; i < nv; i++) {
+    TriRec r;
+    if (make_record(pool[inl[i - 1]].w, pool[inl[i]].w, pool[inl[0]].w, t.w, a.width, a.height, r)) {
+      binned++;
+      entries += emit_record(a, slot, r);
+    }
+  }
+  if (binned) {
+    atomicAdd(&a.counters->tris_binned, (unsigned long long)binned);
+    atomicAdd(&a.counters->bin_entries, (unsigned long long)entries);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// tile_kernel
+// ---------------------------------------------------------------------------------------
+
+constexpr unsigned long long kNoFragment = 0x00ffffff00000000ull;   // cleared depth 1.0, order 0
+constexpr unsigned long long kResolvedBit = 1ull << 63;
+
+__device__ __forceinline__ uint32_t z24_of(float z)
+{
+  const float zc = fminf(fmaxf(z, 0.0f), 1.0f);
+  return (uint32_t)__float2int_rn(__fmul_rn(zc, 16777215.0f));
+}
+
+// MODE 0: depth test (atomicMin of {z24, order});  MODE 1: write the exact float z of the
+// fragment that won (needed only for window z <= 0.5, where float z is finer than 24 bits).
+template <int MODE>
+__device__ __forceinline__ void fragment(unsigned long long* keys, const TriRec& r, int px, int py, int lidx)
+{
+  const float z = __fmaf_rn(r.dzdy, (float)py, __fmaf_rn(r.dzdx, (float)px, r.a0));
+  const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | r.order;
+  if (MODE == 0) {
+    atomicMin(&keys[lidx], key);
+  } else {
+    if (keys[lidx] == key) keys[lidx] = kResolvedBit | (unsigned long long)__float_as_uint(z);
+  }
+}
+
+__device__ __forceinline__ bool inside(const TriRec& r, int px, int py)
+{
+  const int e0 = r.A[0] * px + r.B[0] * py + r.C[0];
+  const int e1 = r.A[1] * px + r.B[1] * py + r.C[1];
+  const int e2 = r.A[2] * px + r.B[2] * py + r.C[2];
+  return (e0 > 0) & (e1 > 0) & (e2 > 0);
+}
+
+constexpr int kSmallArea = 32;
+
+template <int MODE>
+__device__ __forceinline__ void raster_bin(unsigned long long* keys, uint32_t* s_large, int* s_nlarge,
+                                           const TriRec* recs, uint32_t n, int x_base, int y_base, int tid)
+{
+  for (uint32_t base = 0; base < n; base += kBlock) {
+    const uint32_t i = base + tid;
+    const bool have = i < n;
+    TriRec r;
+    int lx0 = 0, lx1 = -1, ly0 = 0, ly1 = -1;
+    if (have) {
+      const uint4* src = reinterpret_cast<const uint4*>(recs + i);
+      uint4* dst = reinterpret_cast<uint4*>(&r);
+      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+      lx0 = max((int)(r.bbx & 0xffff) - x_base, 0);
+      lx1 = min((int)(r.bbx >> 16) - x_base, kTileW - 1);
+      ly0 = max((int)(r.bby & 0xffff) - y_base, 0);
+      ly1 = min((int)(r.bby >> 16) - y_base, kTileH - 1);
+    }
+    const int w = lx1 - lx0 + 1, h = ly1 - ly0 + 1;
+    const bool large = have && (w * h > kSmallArea);
+    if (have && !large) {
+      for (int ly = ly0; ly <= ly1; ly++)
+        for (int lx = lx0; lx <= lx1; lx++) {
+          const int px = x_base + lx, py = y_base + ly;
+          if (inside(r, px, py)) fragment<MODE>(keys, r, px, py, ly * kTileW + lx);
+        }
+    }
+    // large triangles: the whole workgroup rasterises them one at a time in 16x16 stamps
+    if (tid == 0) *s_nlarge = 0;
+    __syncthreads();
+    if (large) s_large[atomicAdd(s_nlarge, 1)] = i;
+    __syncthreads();
+    const int nl = *s_nlarge;
+    for (int k = 0; k < nl; k++) {
+      const TriRec* rp = recs + s_large[k];
+      TriRec q;
+      {
+        const uint4* src = reinterpret_cast<const uint4*>(rp);
+        uint4* dst = reinterpret_cast<uint4*>(&q);
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+      }
+      const int qx0 = max((int)(q.bbx & 0xffff) - x_base, 0), qx1 = min((int)(q.bbx >> 16) - x_base, kTileW - 1);
+      const int qy0 = max((int)(q.bby & 0xffff) - y_base, 0), qy1 = min((int)(q.bby >> 16) - y_base, kTileH - 1);
+      const int tx = tid & 15, ty = tid >> 4;
+      for (int sy = qy0 & ~15; sy <= qy1; sy += 16)
+        for (int sx = qx0 & ~15; sx <= qx1; sx += 16) {
+          const int lx = sx + tx, ly = sy + ty;
+          if (lx >= qx0 && lx <= qx1 && ly >= qy0 && ly <= qy1) {
+            const int px = x_base + lx, py = y_base + ly;
+            if (inside(q, px, py)) fragment<MODE>(keys, q, px, py, ly * kTileW + lx);
+          }
+        }
+    }
+    __syncthreads();
+  }
+}
+
+// urdf_filter.frag:14-35
+__device__ __forceinline__ float shade(float sensor, float z, float z_near, float z_far, float max_diff,
+                                       float replace_value, bool& filt)
+{
+  const float num = __fdiv_rn(__fmul_rn(z_near, z_far), __fsub_rn(z_near, z_far));
+  const float off = __fdiv_rn(z_far, __fsub_rn(z_far, z_near));
+  const float virt = __fdiv_rn(num, __fsub_rn(z, off));
+  filt = sensor > __fsub_rn(virt, max_diff);
+  return filt ? replace_value : sensor;
+}
+
+template <bool TWO_KERNEL>
+__global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
+{
+  __shared__ unsigned long long keys[kTileW * kTileH];
+  __shared__ uint32_t s_large[kBlock];
+  __shared__ int s_nlarge;
+
+  const int tid = threadIdx.x;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int bin = blockIdx.x;
+  const int slot = bin / tiles, tile = bin - slot * tiles;
+  const int stream = a.group_base + slot;
+  const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+  const int x_base = txi * kTileW, y_base = tyi * kTileH;
+
+  const bool analytic_bg = a.bg_mode[stream] != 0;
+  const float bgz = a.bg_z[stream];
+  const unsigned long long bgkey = analytic_bg ? (((unsigned long long)z24_of(bgz) << 32)) : kNoFragment;
+  for (int i = tid; i < kTileW * kTileH; i += kBlock) keys[i] = bgkey;
+
+  const uint32_t count = a.bin_count[bin];
+  const uint32_t n = min(count, a.capacity);
+  const TriRec* recs = a.bins + (size_t)bin * a.capacity;
+  __syncthreads();
+  if (tid == 0) {
+    a.bin_count[bin] = 0;                 // ready for the next batch
+    if (count) atomicMax(&a.counters->max_bin_fill, count);
+  }
+  raster_bin<0>(keys, s_large, &s_nlarge, recs, n, x_base, y_base, tid);
+
+  // Does any pixel need the exact float z of its winner?  Only when the winning depth is in the
+  // lower half of the depth range (z24 <= 2^23): above it, float z == (z24 + 1) * 2^-24 exactly.
+  bool need = false;
+  for (int i = tid; i < kTileW * kTileH; i += kBlock) {
+    const unsigned long long k = keys[i];
+    if (k != bgkey && (uint32_t)(k >> 32) <= 8388608u) need = true;
+  }
+  if (__syncthreads_or(need)) {
+    raster_bin<1>(keys, s_large, &s_nlarge, recs, n, x_base, y_base, tid);
+  }
+
+  // resolve: 16 lanes x 4 pixels per tile row, 16 rows per pass
+  const bool vec = (a.width & 3) == 0;
+  for (int pass = 0; pass < kTileH / 16; pass++) {
+    const int ly = pass * 16 + (tid >> 4), lx = (tid & 15) * 4;
+    const int px = x_base + lx, py = y_base + ly;
+    if (py >= a.height || px >= a.width) continue;
+    float z[4];
+    bool frag[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const unsigned long long k = keys[ly * kTileW + lx + j];
+      frag[j] = true;
+      if (k & kResolvedBit) z[j] = __uint_as_float((uint32_t)k);
+      else if (k == bgkey) { z[j] = bgz; frag[j] = analytic_bg; }
+      else z[j] = __fmul_rn((float)((uint32_t)(k >> 32) + 1u), 5.9604644775390625e-08f);
+    }
+    const size_t gofs = ((size_t)stream * a.height + py) * a.width + px;
+    const int nvalid = min(4, a.width - px);
+    if (TWO_KERNEL) {
+      const size_t zofs = ((size_t)slot * a.height + py) * a.width + px;
+      // "no fragment" (only without background quad) is encoded as NaN
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (!frag[j]) z[j] = __uint_as_float(0x7fc00000u);
+      if (vec) *reinterpret_cast<float4*>(a.zsurface + zofs) = make_float4(z[0], z[1], z[2], z[3]);
+      else for (int j = 0; j < nvalid; j++) a.zsurface[zofs + j] = z[j];
+    } else {
+      float s[4];
+      if (vec) {
+        const float4 v = *reinterpret_cast<const float4*>(a.depth + gofs);
+        s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
+      } else {
+        for (int j = 0; j < 4; j++) s[j] = j < nvalid ? a.depth[gofs + j] : 0.0f;
+      }
+      float o[4];
+      uint32_t mbits = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        bool f;
+        o[j] = shade(s[j], z[j], a.z_near, a.z_far, a.max_diff, a.replace_value, f);
+        if (!frag[j]) { o[j] = 0.0f; f = false; }     // GL clear colour
+        if (f) mbits |= 0xffu << (8 * j);
+      }
+      if (vec) {
+        *reinterpret_cast<float4*>(a.masked + gofs) = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.mask) *reinterpret_cast<uint32_t*>(a.mask + gofs) = mbits;
+      } else {
+        for (int j = 0; j < nvalid; j++) {
+          a.masked[gofs + j] = o[j];
+          if (a.mask) a.mask[gofs + j] = (uint8_t)(mbits >> (8 * j));
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// compare_kernel (two-kernel mode): streaming, 13 B/pixel (4 sensor + 4 z + 4 masked + 1 mask)
+// ---------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kBlock) void compare_kernel(CompareArgs a)
+{
+  const size_t n4 = a.n_pixels >> 2;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 s = reinterpret_cast<const float4*>(a.depth)[i];
+    const float4 z = reinterpret_cast<const float4*>(a.zsurface)[i];
+    const float sv[4] = {s.x, s.y, s.z, s.w}, zv[4] = {z.x, z.y, z.z, z.w};
+    float o[4];
+    uint32_t mbits = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      bool f;
+      o[j] = shade(sv[j], zv[j], a.z_near, a.z_far, a.max_diff, a.replace_value, f);
+      if (zv[j] != zv[j]) { o[j] = 0.0f; f = false; }
+      if (f) mbits |= 0xffu << (8 * j);
+    }
+    reinterpret_cast<float4*>(a.masked)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (a.mask) reinterpret_cast<uint32_t*>(a.mask)[i] = mbits;
+  }
+  // tail
+  if (blockIdx.x == 0 && threadIdx.x < (a.n_pixels & 3)) {
+    const size_t i = (n4 << 2) + threadIdx.x;
+    bool f;
+    float o = shade(a.depth[i], a.zsurface[i], a.z_near, a.z_far, a.max_diff, a.replace_value, f);
+    if (a.zsurface[i] != a.zsurface[i]) { o = 0.0f; f = false; }
+    a.masked[i] = o;
+    if (a.mask) a.mask[i] = f ? 255 : 0;
+  }
+}
+
+// host-callable launchers ---------------------------------------------------------------
+void launch_pose(const PoseArgs& a, hipStream_t st)
+{
+  const int total = a.n_streams * (a.n_draws + 1);
+  hipLaunchKernelGGL(pose_kernel, dim3((total + 127) / 128), dim3(128), 0, st, a);
+}
+void launch_setup(const SetupArgs& a, int n_chunks, hipStream_t st)
+{
+  hipLaunchKernelGGL(setup_kernel, dim3(n_chunks, a.group_size), dim3(kBlock), 0, st, a);
+}
+void launch_clip(const SetupArgs& a, hipStream_t st)
+{
+  // the item count lives on the device: fixed grid, grid-stride loop
+  hipLaunchKernelGGL(clip_kernel, dim3(512), dim3(kBlock), 0, st, a);
+}
+void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st)
+{
+  const int blocks = a.group_size * a.tiles_x * a.tiles_y;
+  if (two_kernel) hipLaunchKernelGGL(tile_kernel<true>, dim3(blocks), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL(tile_kernel<false>, dim3(blocks), dim3(kBlock), 0, st, a);
+}
+void launch_compare(const CompareArgs& a, hipStream_t st)
+{
+  size_t n4 = a.n_pixels >> 2;
+  size_t blocks = (n4 + kBlock - 1) / kBlock;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(compare_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+}
+
+}  // namespace rtuf
