@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- filtered depth frames/s of the hot path (BASELINE.json metric) on N MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic input: `--streams` concurrent
+640x480 camera streams of the synthetic PR2-like robot (config C3 of SURVEY.md section 8d:
+"640x480, PR2 URDF, batch=256 concurrent camera streams on 1 MI355X", the configuration the
+BASELINE target ">=30 frames/s per stream at >=256 streams" is quoted on).  Every step stages a
+fresh joint state + camera pose for every stream, then runs pose -> set-up/binning -> clip ->
+tile raster + per-pixel compare on depth frames that are already resident in HBM.  Inputs rotate
+through `--variants` distinct pre-generated batches so no step can reuse the previous result.
+
+Multi-GPU (`--gpus N`, launched by torch.distributed.run): streams are independent, so every rank
+runs the same per-GPU batch on its own streams (weak scaling, no data-path collective); RCCL is
+used only for the barrier and the max-over-ranks time reduction.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=256, help="concurrent camera streams per GPU")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--triangles", type=int, default=250000, help="triangle budget of the PR2-like model")
+    ap.add_argument("--variants", type=int, default=2, help="distinct input batches rotated through the steps")
+    ap.add_argument("--two-kernel", action="store_true", help="rasteriser + separate compare kernel")
+    ap.add_argument("--no-mask", action="store_true", help="need_mask_ == false: no mask output")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
+    ap.add_argument("--check-frames", type=int, default=4, help="frames of the last step verified against the oracle")
+    args = ap.parse_args()
+
+    import torch
+    import realtime_urdf_filter_amd as R
+    from realtime_urdf_filter_amd import workloads as WL
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    n, W, H = args.streams, args.width, args.height
+    # --- workload: every rank owns `n` different streams (seeds offset by rank) --------------
+    variants = []
+    for v in range(args.variants):
+        wl = WL.pr2_workload(n, W, H, args.triangles, first_state_seed=1000 + 100000 * v + 1000003 * rank)
+        variants.append(wl)
+    wl0 = variants[0]
+    p = R.default_params()
+    p.filter_replace_value = wl0.replace_value
+    p.depth_distance_threshold = wl0.max_diff
+    if args.two_kernel:
+        p.flags |= R.FLAG_TWO_KERNEL
+    ctx = R.Context(W, H, n, local_rank, p)
+    ids = wl0.load_into(ctx)
+    ctx.enable_timing(True)
+
+    d_depth = []
+    for v, wl in enumerate(variants):
+        host = np.stack([wl.depth(s + 7 * v + 1000 * rank) for s in range(n)])
+        d_depth.append(torch.from_numpy(host).to(dev))
+    d_masked = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+    d_mask = None if args.no_mask else torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def step(k):
+        v = k % len(variants)
+        variants[v].stage(ctx, ids)
+        ctx.filter_batch_device(n, d_depth[v].data_ptr(), d_masked.data_ptr(), d_mask.data_ptr() if d_mask is not None else 0)
+        ctx.sync()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    barrier()
+    acc = {"ms_pose": 0.0, "ms_setup": 0.0, "ms_raster": 0.0, "ms_compare": 0.0, "ms_total": 0.0}
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+        st = ctx.stats()
+        for key in acc:
+            acc[key] += st[key]
+    ctx.sync()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = ctx.stats()
+
+    if rank == 0:
+        K = max(args.steps, 1)
+        frames = n * world * args.steps
+        value = frames / elapsed
+        per = {k: v / K for k, v in acc.items()}
+        px = W * H
+        two = args.two_kernel
+        # dominant kernel and its algorithmic bytes per launch:
+        #   fused tile kernel : 9 B/pixel = 4 sensor read + 4 masked write + 1 mask write (8 without mask)
+        #   two-kernel mode   : tile kernel writes the 4 B/pixel z-surface; compare moves 13 B/pixel
+        groups = 1
+        if two:
+            cands = {"tile_kernel<two_kernel>": (per["ms_raster"], 4 * px * n), "compare_kernel": (per["ms_compare"], (13 if d_mask is not None else 12) * px * n)}
+        else:
+            cands = {"tile_kernel<fused>": (per["ms_raster"], (9 if d_mask is not None else 8) * px * n)}
+        cands["setup_kernel+clip_kernel"] = (per["ms_setup"], 12 * wl0.n_vertices() + 16 * wl0.n_triangles())
+        dom = max((k for k in cands if not k.startswith("setup")), key=lambda k: cands[k][0])
+        dur_ms, alg_bytes = cands[dom]
+        achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+        peak = 8000.0
+        out = {
+            "metric": "filtered depth frames/sec (640x480, PR2 URDF)",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: %dx%d depth, synthetic PR2-like URDF (%d links with meshes, %d triangles), batch=%d concurrent streams per GPU, new joint state + camera pose every step"
+                                   % (W, H, wl0.meta["links_with_geometry"], wl0.meta["triangles"], n),
+                       "streams_per_gpu": n, "mode": "two-kernel" if two else "fused", "mask_output": d_mask is not None,
+                       "parallelism": "stream-sharded x%d" % world},
+            "per_stream_fps": value / (n * world),
+            "kernel_ms_per_step": per,
+            "rasteriser": {"triangles_per_s": wl0.n_triangles() * n / (per["ms_setup"] * 1e-3) if per["ms_setup"] > 0 else None,
+                           "binned_triangles_per_s": st["triangles_binned"] / (per["ms_raster"] * 1e-3) if per["ms_raster"] > 0 else None,
+                           "triangles_submitted": st["triangles_submitted"], "triangles_binned": st["triangles_binned"],
+                           "triangles_clipped": st["triangles_clipped"], "bin_entries": st["bin_entries"],
+                           "max_bin_fill": st["max_bin_fill"], "bin_capacity": st["bin_capacity"], "regrowths": st["regrowths"]},
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
+                         "frac": achieved / peak, "traffic": None, "launches_per_step": groups,
+                         "avg_launch_ms": dur_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        # ---- parity spot check + CPU baseline (oracle = checker / reported baseline only) ------
+        if world == 1:
+            from oracle import bindings as O
+            v_last = (args.warmup + args.steps - 1) % len(variants)
+            wl = variants[v_last]
+            hm = d_masked.cpu().numpy()
+            hk = d_mask.cpu().numpy() if d_mask is not None else None
+            hd = d_depth[v_last].cpu().numpy()
+            bad_mask = bad_depth = 0
+            t_cpu = 0.0
+            n_cpu = 0
+            budget = args.cpu_seconds
+            s = 0
+            while s < n and (s < args.check_frames or (budget > 0 and t_cpu < budget)):
+                c0 = time.perf_counter()
+                om, ok = O.filter_frame(hd[s], wl.projection[s], wl.oracle_draws(s), wl.offset_inv[s], wl.cam_tf[s],
+                                        max_diff=wl.max_diff, replace_value=wl.replace_value)
+                t_cpu += time.perf_counter() - c0
+                n_cpu += 1
+                if hk is not None:
+                    bad_mask += int((ok != hk[s]).sum())
+                bad_depth += int((om.view(np.uint32) != hm[s].view(np.uint32)).sum())
+                s += 1
+            out["parity"] = {"frames_checked": n_cpu, "mask_mismatch_pixels": bad_mask, "depth_mismatch_pixels": bad_depth}
+            if n_cpu:
+                out["cpu_baseline"] = {"value": n_cpu / t_cpu, "unit": "frames/s", "cores": 1, "kind": "port",
+                                       "sample": "%d frames of the same batch through oracle/rtuf_oracle.c (single thread, %.1f s)" % (n_cpu, t_cpu)}
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -125,6 +125,15 @@ void rtuf_projection_from_intrinsics(double fx, double fy, double cx, double cy,
  * (src/urdf_renderer.cpp:173-190). */
 int rtuf_set_link_poses(rtuf_context *ctx, int stream, int model, const double *link_tf, int n_links);
 
+/* Batched forms of the two setters above (one FFI crossing per frame for N streams):
+ * matrices are [n_streams][16] resp. [n_streams][n_links][16], for streams
+ * first_stream .. first_stream + n_streams - 1.  Any of the three camera arrays may be NULL
+ * (that matrix keeps its previous value for all n streams). */
+int rtuf_set_cameras(rtuf_context *ctx, int first_stream, int n_streams, const double *projection,
+                     const double *camera_offset_inv, const double *camera_tf);
+int rtuf_set_link_poses_batch(rtuf_context *ctx, int first_stream, int n_streams, int model,
+                              const double *link_tf, int n_links);
+
 /* ---- the hot path ------------------------------------------------------------------ */
 /* filter() for n streams at once (stream ids 0..n-1), host buffers:
  * depth_in[s]: width*height float32 metres, row 0 first (src/urdf_filter.cpp:233-234);

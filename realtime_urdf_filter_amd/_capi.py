@@ -23,7 +23,7 @@ SYMBOLS = [
     "rtuf_default_params", "rtuf_abi_version", "rtuf_create", "rtuf_destroy", "rtuf_last_error",
     "rtuf_set_params", "rtuf_add_model", "rtuf_add_link", "rtuf_add_draw", "rtuf_finalize_models",
     "rtuf_num_links", "rtuf_num_triangles", "rtuf_set_stream_models", "rtuf_set_camera",
-    "rtuf_projection_from_intrinsics", "rtuf_set_link_poses", "rtuf_filter_batch",
+    "rtuf_projection_from_intrinsics", "rtuf_set_link_poses", "rtuf_set_cameras", "rtuf_set_link_poses_batch", "rtuf_filter_batch",
     "rtuf_filter_batch_device", "rtuf_filter", "rtuf_get_masked_depth", "rtuf_get_mask", "rtuf_sync",
     "rtuf_stream", "rtuf_get_stats", "rtuf_enable_timing", "rtuf_debug_read_zsurface",
 ]
@@ -89,6 +89,8 @@ def load_library(path=None):
     lib.rtuf_projection_from_intrinsics.argtypes = [cd, cd, cd, cd, cd, cd, ci, ci, cd, cd, vp, vp, vp]
     lib.rtuf_projection_from_intrinsics.restype = None
     lib.rtuf_set_link_poses.argtypes = [vp, ci, ci, vp, ci]
+    lib.rtuf_set_cameras.argtypes = [vp, ci, ci, vp, vp, vp]
+    lib.rtuf_set_link_poses_batch.argtypes = [vp, ci, ci, ci, vp, ci]
     lib.rtuf_filter_batch.argtypes = [vp, ci, vp, vp, vp]
     lib.rtuf_filter_batch_device.argtypes = [vp, ci, vp, vp, vp]
     lib.rtuf_filter.argtypes = [vp, vp, vp, ci, ci]
@@ -191,6 +193,17 @@ class Context:
     def set_link_poses(self, stream, model, link_tf):
         a = np.ascontiguousarray(link_tf, np.float64).reshape(-1, 16)
         self._check(self._lib.rtuf_set_link_poses(self._h, stream, model, _ptr(a), len(a)))
+
+    def set_cameras(self, first_stream, projections=None, camera_offset_inv=None, camera_tf=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, np.float64).reshape(-1, 16)
+                for a in (projections, camera_offset_inv, camera_tf)]
+        n = max(len(a) for a in arrs if a is not None)
+        self._check(self._lib.rtuf_set_cameras(self._h, first_stream, n, *[_ptr(a) for a in arrs]))
+
+    def set_link_poses_batch(self, first_stream, model, link_tf):
+        a = np.ascontiguousarray(link_tf, np.float64)
+        n, nl = a.shape[0], a.shape[1]
+        self._check(self._lib.rtuf_set_link_poses_batch(self._h, first_stream, n, model, _ptr(a), nl))
 
     # hot path
     def filter_batch(self, depth, want_mask=True):

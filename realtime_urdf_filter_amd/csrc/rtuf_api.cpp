@@ -423,6 +423,35 @@ int rtuf_set_link_poses(rtuf_context* c, int stream, int model, const double* li
   return RTUF_OK;
 }
 
+int rtuf_set_cameras(rtuf_context* c, int first, int n, const double* projection, const double* offset_inv,
+                     const double* cam_tf)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (first < 0 || n < 0 || first + n > c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream range %d+%d", first, n);
+  for (int s = 0; s < n; s++) {
+    Camera& cam = c->h_cams[first + s];
+    if (projection) memcpy(cam.projection, projection + 16 * (size_t)s, sizeof cam.projection);
+    if (offset_inv) memcpy(cam.offset_inv, offset_inv + 16 * (size_t)s, sizeof cam.offset_inv);
+    if (cam_tf) memcpy(cam.cam_tf, cam_tf + 16 * (size_t)s, sizeof cam.cam_tf);
+  }
+  return RTUF_OK;
+}
+
+int rtuf_set_link_poses_batch(rtuf_context* c, int first, int n, int model, const double* link_tf, int n_links)
+{
+  if (!c || !link_tf) return RTUF_ERR_INVALID;
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (first < 0 || n < 0 || first + n > c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream range %d+%d", first, n);
+  if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
+  const HostModel& m = c->models[model];
+  if (n_links != (int)m.links.size()) return c->fail(RTUF_ERR_INVALID, "model %d has %d links, got %d", model, (int)m.links.size(), n_links);
+  for (int s = 0; s < n; s++)
+    memcpy(c->h_link_tf + ((size_t)(first + s) * c->n_links + m.link_base) * 16, link_tf + (size_t)s * n_links * 16,
+           sizeof(double) * 16 * (size_t)n_links);
+  return RTUF_OK;
+}
+
 // ---- the hot path ---------------------------------------------------------------------
 static hipEvent_t get_event(rtuf_context* c, size_t i)
 {
