@@ -50,7 +50,7 @@ struct rtuf_context {
   uint32_t bg_chunk = 0;
 
   // static geometry (device)
-  float4* d_verts = nullptr; uint4* d_tris = nullptr; Chunk* d_chunks = nullptr; Draw* d_draws = nullptr;
+  float4* d_cverts = nullptr; uint32_t* d_ctris = nullptr; Chunk* d_chunks = nullptr; Draw* d_draws = nullptr;
 
   // per-frame pose staging
   Camera* h_cams = nullptr;            // pinned [max_streams]
@@ -168,7 +168,7 @@ void rtuf_destroy(rtuf_context* c)
   if (c->stream) hipStreamSynchronize(c->stream);
   free_frame_buffers(c);
   auto dfree = [](auto*& p) { if (p) { hipFree(p); p = nullptr; } };
-  dfree(c->d_verts); dfree(c->d_tris); dfree(c->d_chunks); dfree(c->d_draws);
+  dfree(c->d_cverts); dfree(c->d_ctris); dfree(c->d_chunks); dfree(c->d_draws);
   for (hipEvent_t ev : c->events) hipEventDestroy(ev);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -275,11 +275,11 @@ static int alloc_frame_buffers(rtuf_context* c)
   while (G > 1 && (size_t)G * tiles * cap * sizeof(TriRec) > budget) G = (G + 1) / 2;
   c->group = G;
   c->capacity = cap;
-  c->clip_capacity = (uint32_t)std::min<size_t>((size_t)G * 8192, (size_t)1 << 24);
+  c->clip_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 8192 / kCounterShards, 1024), (size_t)1 << 22);   // per shard
   HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(TriRec)));
   HIP_TRY(c, hipMalloc(&c->d_bin_count, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(c->d_bin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
-  HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * sizeof(ClipItem)));
+  HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
   if (c->params.flags & RTUF_FLAG_TWO_KERNEL)
     HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)G * c->width * c->height * sizeof(float)));
   return RTUF_OK;
@@ -290,10 +290,70 @@ int rtuf_finalize_models(rtuf_context* c)
   if (!c) return RTUF_ERR_INVALID;
   if (c->finalized) return c->fail(RTUF_ERR_STATE, "models already finalised");
   hipSetDevice(c->device);
-  std::vector<float4> verts;
-  std::vector<uint4> tris;
+  std::vector<float4> cverts;
+  std::vector<uint32_t> ctris;
   std::vector<Chunk> chunks;
   std::vector<Draw> draws;
+  int64_t tri_seq = 0;
+  // Splits one draw's triangle list into chunks of <= kBlock triangles / <= kMaxChunkVerts vertices.
+  auto add_chunks = [&](const std::vector<float>& v, const std::vector<uint32_t>& t, uint32_t draw_id, uint32_t model) {
+    const uint32_t nt = (uint32_t)(t.size() / 3);
+    std::vector<int32_t> local(v.size() / 3, -1);
+    std::vector<uint32_t> touched;
+    uint32_t done = 0;
+    while (done < nt) {
+      Chunk ch{};
+      ch.tri_begin = (uint32_t)ctris.size();
+      ch.vert_begin = (uint32_t)cverts.size();
+      ch.draw = draw_id; ch.model = model;
+      ch.order_base = (uint32_t)(tri_seq + 1);
+      touched.clear();
+      uint32_t nv = 0, n = 0;
+      while (done + n < nt && n < (uint32_t)kBlock) {
+        const uint32_t* ix = &t[3 * (size_t)(done + n)];
+        uint32_t fresh = 0;
+        for (int k = 0; k < 3; k++) {
+          bool seen = local[ix[k]] >= 0;
+          for (int q = 0; q < k && !seen; q++) seen = ix[q] == ix[k];
+          if (!seen) fresh++;
+        }
+        if (nv + fresh > (uint32_t)kMaxChunkVerts) break;
+        uint32_t li[3];
+        for (int k = 0; k < 3; k++) {
+          if (local[ix[k]] < 0) {
+            local[ix[k]] = (int32_t)nv++;
+            touched.push_back(ix[k]);
+            cverts.push_back(make_float4(v[3 * (size_t)ix[k]], v[3 * (size_t)ix[k] + 1], v[3 * (size_t)ix[k] + 2], 1.0f));
+          }
+          li[k] = (uint32_t)local[ix[k]];
+        }
+        ctris.push_back(li[0] | (li[1] << 10) | (li[2] << 20));
+        n++;
+      }
+      ch.tri_count = n; ch.vert_count = nv;
+      {
+        // bounding sphere (centre of the box, radius padded): used for whole-chunk frustum culling
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+        for (uint32_t q = 0; q < nv; q++) {
+          const float4& p = cverts[ch.vert_begin + q];
+          const float pp[3] = {p.x, p.y, p.z};
+          for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], pp[k]); hi[k] = std::max(hi[k], pp[k]); }
+        }
+        double r2 = 0;
+        for (int k = 0; k < 3; k++) ch.center[k] = 0.5f * (lo[k] + hi[k]);
+        for (uint32_t q = 0; q < nv; q++) {
+          const float4& p = cverts[ch.vert_begin + q];
+          const double dx = (double)p.x - ch.center[0], dy = (double)p.y - ch.center[1], dz = (double)p.z - ch.center[2];
+          r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+        }
+        ch.radius = (float)(std::sqrt(r2) * 1.0001 + 1e-6);
+      }
+      chunks.push_back(ch);
+      for (uint32_t id : touched) local[id] = -1;
+      done += n;
+      tri_seq += n;
+    }
+  };
   int link_base = 0;
   for (size_t mi = 0; mi < c->models.size(); mi++) {
     HostModel& m = c->models[mi];
@@ -307,53 +367,31 @@ int rtuf_finalize_models(rtuf_context* c)
         d.model = (uint32_t)mi;
         const uint32_t draw_id = (uint32_t)draws.size();
         draws.push_back(d);
-        const uint32_t vbase = (uint32_t)verts.size();
-        for (size_t v = 0; v + 2 < hd.verts.size(); v += 3)
-          verts.push_back(make_float4(hd.verts[v], hd.verts[v + 1], hd.verts[v + 2], 1.0f));
-        const uint32_t nt = (uint32_t)(hd.tris.size() / 3);
-        for (uint32_t t = 0; t < nt; t += kBlock) {
-          Chunk ch{};
-          ch.tri_begin = (uint32_t)tris.size() + t;
-          ch.tri_count = std::min<uint32_t>(kBlock, nt - t);
-          ch.draw = draw_id;
-          ch.model = (uint32_t)mi;
-          chunks.push_back(ch);
-        }
-        for (uint32_t t = 0; t < nt; t++) {
-          const uint32_t order = (uint32_t)tris.size() + 1;   // draw-order sequence, background is 0
-          tris.push_back(make_uint4(vbase + hd.tris[3 * t], vbase + hd.tris[3 * t + 1], vbase + hd.tris[3 * t + 2], order));
-        }
+        add_chunks(hd.verts, hd.tris, draw_id, (uint32_t)mi);
       }
     }
     link_base += (int)m.links.size();
   }
   c->n_links = link_base;
   c->n_draws = (int)draws.size();
-  c->n_tris = (int64_t)tris.size();
+  c->n_tris = tri_seq;
   // background quad as the hidden last draw (used only when a stream's projection does not make
-  // it a constant full-screen plane): GL_QUADS -> (0,1,3), (1,2,3); both with order 0
+  // it a constant full-screen plane): GL_QUADS -> (0,1,3), (1,2,3); both get order 0
   {
     const float zq = (float)((double)c->params.far_plane * 0.99);
-    const uint32_t vbase = (uint32_t)verts.size();
-    verts.push_back(make_float4(-100.0f, -100.0f, zq, 1.0f));
-    verts.push_back(make_float4(100.0f, -100.0f, zq, 1.0f));
-    verts.push_back(make_float4(100.0f, 100.0f, zq, 1.0f));
-    verts.push_back(make_float4(-100.0f, 100.0f, zq, 1.0f));
-    Chunk ch{};
-    ch.tri_begin = (uint32_t)tris.size(); ch.tri_count = 2; ch.draw = (uint32_t)c->n_draws; ch.model = 0;
+    const std::vector<float> bv = {-100.0f, -100.0f, zq, 100.0f, -100.0f, zq, 100.0f, 100.0f, zq, -100.0f, 100.0f, zq};
+    const std::vector<uint32_t> bt = {0, 1, 3, 1, 2, 3};
     c->bg_chunk = (uint32_t)chunks.size();
-    chunks.push_back(ch);
-    tris.push_back(make_uint4(vbase + 0, vbase + 1, vbase + 3, 0));
-    tris.push_back(make_uint4(vbase + 1, vbase + 2, vbase + 3, 0));
+    add_chunks(bv, bt, (uint32_t)c->n_draws, 0);
   }
   c->n_chunks = (int)chunks.size();
   if (draws.empty()) draws.push_back(Draw{});
-  HIP_TRY(c, hipMalloc(&c->d_verts, verts.size() * sizeof(float4)));
-  HIP_TRY(c, hipMalloc(&c->d_tris, tris.size() * sizeof(uint4)));
+  HIP_TRY(c, hipMalloc(&c->d_cverts, cverts.size() * sizeof(float4)));
+  HIP_TRY(c, hipMalloc(&c->d_ctris, ctris.size() * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&c->d_chunks, chunks.size() * sizeof(Chunk)));
   HIP_TRY(c, hipMalloc(&c->d_draws, draws.size() * sizeof(Draw)));
-  HIP_TRY(c, hipMemcpy(c->d_verts, verts.data(), verts.size() * sizeof(float4), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(c->d_tris, tris.data(), tris.size() * sizeof(uint4), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_cverts, cverts.data(), cverts.size() * sizeof(float4), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_ctris, ctris.data(), ctris.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_draws, draws.data(), draws.size() * sizeof(Draw), hipMemcpyHostToDevice));
   const int rc = alloc_frame_buffers(c);
@@ -500,9 +538,9 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
   for (int base = 0; base < n; base += c->group) {
     const int gs = std::min(c->group, n - base);
     // clip list is per group
-    HIP_TRY(c, hipMemsetAsync(&c->d_counters->clip_count, 0, sizeof(unsigned int), st));
+    if (base > 0) launch_reset_clip(c->d_counters, st);
     SetupArgs sa{};
-    sa.verts = c->d_verts; sa.tris = c->d_tris; sa.chunks = c->d_chunks; sa.mvp = c->d_mvp;
+    sa.cverts = c->d_cverts; sa.ctris = c->d_ctris; sa.chunks = c->d_chunks; sa.mvp = c->d_mvp;
     sa.model_mask = c->d_model_mask; sa.bg_mode = c->d_bg_mode; sa.bins = c->d_bins; sa.bin_count = c->d_bin_count;
     sa.clip_list = c->d_clip_list; sa.counters = c->d_counters; sa.group_base = base; sa.group_size = gs;
     sa.n_draws = c->n_draws; sa.width = c->width; sa.height = c->height; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
@@ -556,7 +594,12 @@ int rtuf_sync(rtuf_context* c)
   for (int attempt = 0; attempt < 8; attempt++) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (!c->pending) return RTUF_OK;
-    const Counters& k = *c->h_counters;
+    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0; unsigned max_bin_fill = 0, clip_overflow = 0; } k;
+    for (int i = 0; i < kCounterShards; i++) {
+      const CounterShard& sh = c->h_counters->shard[i];
+      k.tris_binned += sh.tris_binned; k.bin_entries += sh.bin_entries; k.clip_count += sh.clip_count;
+      k.max_bin_fill = std::max(k.max_bin_fill, sh.max_bin_fill); k.clip_overflow |= sh.clip_overflow;
+    }
     c->stats.triangles_submitted = (uint64_t)c->n_tris * (uint64_t)c->last_n;
     c->stats.triangles_binned = k.tris_binned;
     c->stats.bin_entries = k.bin_entries;
@@ -588,7 +631,7 @@ int rtuf_sync(rtuf_context* c)
     if (clip_over) {
       hipFree(c->d_clip_list); c->d_clip_list = nullptr;
       c->clip_capacity *= 4;
-      HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * sizeof(ClipItem)));
+      HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
       c->stats.regrowths++;
     }
     if (c->d_zsurface && (c->params.flags & RTUF_FLAG_TWO_KERNEL)) {

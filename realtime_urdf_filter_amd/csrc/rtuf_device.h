@@ -2,10 +2,11 @@
 //
 // HBM layout (all arrays owned by one rtuf_context, one GPU):
 //   static geometry, uploaded once by rtuf_finalize_models()
-//     verts  float4[V]   object-space positions (w unused)            16 B / vertex
-//     tris   uint4[T]    absolute vertex ids i0,i1,i2 + draw-order     16 B / triangle
-//                        sequence number (>= 1; 0 is the background)
-//     chunks Chunk[C]    <= 256 consecutive triangles of ONE draw call
+//     chunks Chunk[C]    <= 256 consecutive triangles of ONE draw call + the list of the
+//                        <= 384 distinct vertices they use                32 B / chunk
+//     cverts float4[Vc]  object-space positions, grouped per chunk        16 B / vertex
+//     ctris  u32[T]      3 x 10-bit chunk-local vertex ids                 4 B / triangle
+//                        (draw-order sequence number = chunk.order_base + index; 0 = background)
 //     draws  Draw[D]     link id + the glScalef/glTranslatef of the draw
 //   per frame, per stream s (slot within the batch)
 //     cams   Camera[N]   projection / camera_offset_inv / camera_tf as f64
@@ -24,6 +25,8 @@ namespace rtuf {
 constexpr int kTileW = 64;
 constexpr int kTileH = 64;
 constexpr int kBlock = 256;
+constexpr int kMaxChunkVerts = 384;     // unique vertices per set-up chunk (LDS: 16 B each)
+constexpr int kStreamsPerBlock = 4;     // streams a set-up workgroup loops over per chunk
 
 struct alignas(16) TriRec {     // 64 B: one rasterisable triangle inside one tile bin
   int32_t A[3];                 // edge i is inside  <=>  A[i]*px + B[i]*py + C[i] > 0
@@ -37,11 +40,17 @@ struct alignas(16) TriRec {     // 64 B: one rasterisable triangle inside one ti
 };
 static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
 
-struct Chunk {
-  uint32_t tri_begin;
+struct Chunk {                  // <= 256 consecutive triangles of one draw + their vertex list
+  uint32_t tri_begin;           // into ctris
   uint32_t tri_count;
+  uint32_t vert_begin;          // into cverts
+  uint32_t vert_count;          // <= kMaxChunkVerts
   uint32_t draw;
   uint32_t model;
+  uint32_t order_base;          // draw-order sequence number of the chunk's first triangle (>= 1)
+  uint32_t pad;
+  float center[3];              // object-space bounding sphere of the chunk's vertices
+  float radius;
 };
 
 struct Draw {
@@ -60,19 +69,25 @@ struct Camera {
 
 struct ClipItem {
   uint32_t slot;                // stream slot within the in-flight group
-  uint32_t tri;                 // global triangle index
-  uint32_t draw;
+  uint32_t chunk;
+  uint32_t tri;                 // triangle index within the chunk
   uint32_t pad;
 };
 
-struct Counters {               // device-side statistics / overflow detection
+// Device-side statistics / overflow detection.  One hot word would serialise every workgroup at
+// a single L2 atomic unit (~12 ns per atomic), so everything is sharded over kCounterShards
+// cache-line-sized slots that the host sums after the batch.
+constexpr int kCounterShards = 64;
+struct alignas(128) CounterShard {
   unsigned long long tris_binned;
   unsigned long long bin_entries;
-  unsigned int clip_count;      // entries in clip_list
+  unsigned int clip_count;      // entries in this shard's segment of clip_list
   unsigned int max_bin_fill;
   unsigned int clip_overflow;
-  unsigned int pad;
+  unsigned int pad[25];
 };
+static_assert(sizeof(CounterShard) == 128, "CounterShard must be one 128-byte line");
+struct Counters { CounterShard shard[kCounterShards]; };
 
 struct FrameConsts {
   int width, height;
@@ -99,8 +114,8 @@ struct PoseArgs {
 };
 
 struct SetupArgs {
-  const float4* verts;
-  const uint4* tris;
+  const float4* cverts;          // chunk-local vertex lists (object space)
+  const uint32_t* ctris;         // 3 x 10-bit chunk-local vertex ids per triangle
   const Chunk* chunks;
   const float* mvp;              // [n_streams][n_draws + 1][16]
   const uint64_t* model_mask;    // [n_streams] bit m set: stream renders model m
@@ -114,7 +129,7 @@ struct SetupArgs {
   int n_draws;
   int width, height, tiles_x, tiles_y;
   uint32_t capacity;
-  uint32_t clip_capacity;
+  uint32_t clip_capacity;        // per shard segment
   uint32_t bg_chunk;             // index of the background-quad chunk
 };
 
@@ -148,6 +163,7 @@ struct CompareArgs {
 void launch_pose(const PoseArgs& a, hipStream_t st);
 void launch_setup(const SetupArgs& a, int n_chunks, hipStream_t st);
 void launch_clip(const SetupArgs& a, hipStream_t st);
+void launch_reset_clip(Counters* c, hipStream_t st);
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st);
 void launch_compare(const CompareArgs& a, hipStream_t st);
 

@@ -212,13 +212,7 @@ __device__ __forceinline__ bool make_record(Win v0, Win v1, Win v2, uint32_t ord
   int x0 = snap(v0.x), y0 = snap(v0.y);
   int x1 = snap(v1.x), y1 = snap(v1.y);
   const int x2 = snap(v2.x), y2 = snap(v2.y);
-  const long long area = (long long)(x0 - x1) * (y2 - y0) - (long long)(x2 - x0) * (y0 - y1);
-  if (area == 0) return false;
-  if (area < 0) {   // orient: swap vertices 0 and 1 (fixed and float)
-    int t = x0; x0 = x1; x1 = t;
-    t = y0; y0 = y1; y1 = t;
-    Win tw = v0; v0 = v1; v1 = tw;
-  }
+  // bounding box of covered pixel centres first: most mesh triangles are sub-pixel and end here
   const int minx = min(x0, min(x1, x2)), maxx = max(x0, max(x1, x2));
   const int miny = min(y0, min(y1, y2)), maxy = max(y0, max(y1, y2));
   int bx0 = (minx + 255) >> 8, bx1 = (maxx - 1) >> 8;
@@ -226,6 +220,13 @@ __device__ __forceinline__ bool make_record(Win v0, Win v1, Win v2, uint32_t ord
   bx0 = max(bx0, 0); by0 = max(by0, 0);
   bx1 = min(bx1, width - 1); by1 = min(by1, height - 1);
   if (bx1 < bx0 || by1 < by0) return false;
+  const long long area = (long long)(x0 - x1) * (y2 - y0) - (long long)(x2 - x0) * (y0 - y1);
+  if (area == 0) return false;
+  if (area < 0) {   // orient: swap vertices 0 and 1 (fixed and float)
+    int t = x0; x0 = x1; x1 = t;
+    t = y0; y0 = y1; y1 = t;
+    Win tw = v0; v0 = v1; v1 = tw;
+  }
 
   const int xs[3] = {x0, x1, x2}, ys[3] = {y0, y1, y2};
 #pragma unroll
@@ -266,7 +267,8 @@ __device__ __forceinline__ void store_record(TriRec* dst, const TriRec& r)
   d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
 }
 
-// Appends the record to every tile bin its bounding box touches.
+// Appends the record to every tile bin its bounding box touches (one lane, plain atomics):
+// used by the rare clip path.
 __device__ __forceinline__ uint32_t emit_record(const SetupArgs& a, int slot, const TriRec& r)
 {
   const int tx0 = (int)(r.bbx & 0xffff) / kTileW, tx1 = (int)(r.bbx >> 16) / kTileW;
@@ -283,56 +285,190 @@ __device__ __forceinline__ uint32_t emit_record(const SetupArgs& a, int slot, co
   return n;
 }
 
+// Wave-cooperative form: all 64 lanes call it; lanes with `have` own a record.  Lanes that
+// target the same bin are grouped with ballots (ALU only), then every group leader issues its
+// atomicAdd in the SAME instruction, so a wave pays one atomic round trip per tile index
+// instead of one per distinct bin; group members get consecutive slots, which makes the
+// 64-byte record stores of neighbouring mesh triangles contiguous.
+__device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slot, bool have, const TriRec& r)
+{
+  const int lane = threadIdx.x & 63;
+  int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+  if (have) {
+    tx0 = (int)(r.bbx & 0xffff) / kTileW; tx1 = (int)(r.bbx >> 16) / kTileW;
+    ty0 = (int)(r.bby & 0xffff) / kTileH; ty1 = (int)(r.bby >> 16) / kTileH;
+  }
+  const int tw = tx1 - tx0 + 1;
+  const int ntile = have ? tw * (ty1 - ty0 + 1) : 0;
+  const int tiles = a.tiles_x * a.tiles_y;
+  uint32_t n = 0;
+  for (int k = 0;; k++) {
+    const bool act = k < ntile;
+    unsigned long long pending = __ballot(act);
+    if (!pending) break;
+    int bin = -1;
+    if (act) {
+      const int ty = ty0 + k / tw, tx = tx0 + k % tw;
+      bin = slot * tiles + ty * a.tiles_x + tx;
+    }
+    unsigned long long mymask = 0;
+    int myleader = lane;
+    while (pending) {
+      const int leader = __ffsll((long long)pending) - 1;
+      const int lbin = __shfl(bin, leader);
+      const unsigned long long m = __ballot(act && bin == lbin);
+      if (act && bin == lbin) { mymask = m; myleader = leader; }
+      pending &= ~m;
+    }
+    uint32_t base = 0;
+    if (act && lane == myleader) base = atomicAdd(&a.bin_count[bin], (uint32_t)__popcll(mymask));
+    base = __shfl(base, myleader);
+    if (act) {
+      const uint32_t pos = base + (uint32_t)__popcll(mymask & ((1ull << lane) - 1ull));
+      if (pos < a.capacity) store_record(a.bins + (size_t)bin * a.capacity + pos, r);
+      n++;
+    }
+  }
+  return n;
+}
+
+// setup_kernel: one workgroup per (chunk, group of kStreamsPerBlock streams).  A chunk is <= 256
+// consecutive triangles of one draw call with its own <= kMaxChunkVerts vertex list, so each
+// vertex is transformed once per stream (into LDS) instead of once per incident triangle, and
+// the chunk's geometry is loaded once for all streams of the group.
+// True when the chunk's bounding sphere lies completely outside one frustum plane: then all its
+// vertices carry that plane's clip bit and every triangle would be rejected by the per-triangle
+// test anyway (same result, decided once per chunk).  Margins keep the test conservative.
+__device__ __forceinline__ bool chunk_outside(const float* __restrict__ M, const Chunk& ch)
+{
+  const float cx = ch.center[0], cy = ch.center[1], cz = ch.center[2], rad = ch.radius;
+  float c[4], n2[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    c[r] = M[r] * cx + M[4 + r] * cy + M[8 + r] * cz + M[12 + r];
+  }
+  // plane i: w -/+ coordinate >= 0; normal = row3 -/+ rowk (xyz part of the object-space plane)
+  bool out = false;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+#pragma unroll
+    for (int sgn = 0; sgn < 2; sgn++) {
+      const float sg = sgn ? 1.0f : -1.0f;
+      const float nx = M[3] + sg * M[k], ny = M[7] + sg * M[4 + k], nz = M[11] + sg * M[8 + k];
+      const float d = c[3] + sg * c[k];
+      const float nn = sqrtf(nx * nx + ny * ny + nz * nz);
+      const float slack = rad * nn * 1.001f + 1e-5f * (fabsf(c[3]) + fabsf(c[k])) + 1e-30f;
+      if (d < -slack) out = true;
+    }
+  }
+  (void)n2;
+  return out;
+}
+
 __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
 {
-  const Chunk ch = a.chunks[blockIdx.x];
-  const int slot = blockIdx.y;                       // stream slot within the group
-  const int stream = a.group_base + slot;
-  if (blockIdx.x == a.bg_chunk) {
-    if (a.bg_mode[stream]) return;                   // analytic background: nothing to rasterise
-  } else if (!((a.model_mask[stream] >> ch.model) & 1ull)) {
-    return;
-  }
+  __shared__ float4 s_win[2][kMaxChunkVerts];   // window x, y, z + clip mask bits (double-buffered)
+  __shared__ uint32_t s_stat[2];
+  if (threadIdx.x < 2) s_stat[threadIdx.x] = 0;
+  const int chunk_id = blockIdx.y;
+  const int shard_id = (int)((blockIdx.x + blockIdx.y) % kCounterShards);
+  CounterShard& shard = a.counters->shard[shard_id];
+  const Chunk ch = a.chunks[chunk_id];
   const int tid = threadIdx.x;
+  const bool is_bg = (uint32_t)chunk_id == a.bg_chunk;
+
+  float4 pv0 = make_float4(0, 0, 0, 1), pv1 = pv0;
+  if (tid < (int)ch.vert_count) pv0 = a.cverts[ch.vert_begin + tid];
+  if (tid + kBlock < (int)ch.vert_count) pv1 = a.cverts[ch.vert_begin + tid + kBlock];
+  const bool have_tri = tid < (int)ch.tri_count;
+  const uint32_t packed = have_tri ? a.ctris[ch.tri_begin + tid] : 0u;
+  const uint32_t i0 = packed & 1023u, i1 = (packed >> 10) & 1023u, i2 = (packed >> 20) & 1023u;
+  const uint32_t order = is_bg ? 0u : ch.order_base + (uint32_t)tid;
+  const float sx = 0.5f * (float)a.width, sy = 0.5f * (float)a.height;
+
   uint32_t binned = 0, entries = 0;
-  if (tid < (int)ch.tri_count) {
+  int buf = 0;
+  for (int k = 0; k < kStreamsPerBlock; k++) {
+    const int slot = blockIdx.x * kStreamsPerBlock + k;
+    if (slot >= a.group_size) break;
+    const int stream = a.group_base + slot;
+    if (is_bg) {
+      if (a.bg_mode[stream]) continue;                   // analytic background: nothing to rasterise
+    } else if (!((a.model_mask[stream] >> ch.model) & 1ull)) {
+      continue;
+    }
     const float* __restrict__ M = a.mvp + ((size_t)stream * (a.n_draws + 1) + ch.draw) * 16;
-    const uint32_t ti = ch.tri_begin + tid;
-    const uint4 t = a.tris[ti];
-    const float4 p0 = a.verts[t.x], p1 = a.verts[t.y], p2 = a.verts[t.z];
-    float c0[4], c1[4], c2[4];
-    vs_position(M, p0.x, p0.y, p0.z, c0);
-    vs_position(M, p1.x, p1.y, p1.z, c1);
-    vs_position(M, p2.x, p2.y, p2.z, c2);
-    const unsigned m0 = clipmask_of(c0), m1 = clipmask_of(c1), m2 = clipmask_of(c2);
-    if ((m0 & m1 & m2) == 0) {
-      if ((m0 | m1 | m2) != 0) {
-        // crosses a frustum plane: defer to clip_kernel
-        const uint32_t k = atomicAdd(&a.counters->clip_count, 1u);
-        if (k < a.clip_capacity) {
-          ClipItem it; it.slot = (uint32_t)slot; it.tri = ti; it.draw = ch.draw; it.pad = 0;
-          a.clip_list[k] = it;
+    if (chunk_outside(M, ch)) continue;                  // uniform per workgroup
+    float4* win = s_win[buf];
+    buf ^= 1;
+    // phase 1: vertex shader + clip test + viewport, once per chunk vertex
+    if (tid < (int)ch.vert_count) {
+      float c[4];
+      vs_position(M, pv0.x, pv0.y, pv0.z, c);
+      const Win w = viewport_vs(c, sx, sy);
+      win[tid] = make_float4(w.x, w.y, w.z, __uint_as_float(clipmask_of(c)));
+    }
+    if (tid + kBlock < (int)ch.vert_count) {
+      float c[4];
+      vs_position(M, pv1.x, pv1.y, pv1.z, c);
+      const Win w = viewport_vs(c, sx, sy);
+      win[tid + kBlock] = make_float4(w.x, w.y, w.z, __uint_as_float(clipmask_of(c)));
+    }
+    // one barrier per stream: the buffer written two iterations ago was last read before the
+    // previous iteration's barrier
+    __syncthreads();
+    // phase 2: one lane per triangle
+    bool have = false, needs_clip = false;
+    TriRec r;
+    if (have_tri) {
+      const float4 w0 = win[i0], w1 = win[i1], w2 = win[i2];
+      const unsigned m0 = __float_as_uint(w0.w), m1 = __float_as_uint(w1.w), m2 = __float_as_uint(w2.w);
+      if ((m0 & m1 & m2) == 0) {
+        if ((m0 | m1 | m2) != 0) {
+          needs_clip = true;
         } else {
-          atomicExch(&a.counters->clip_overflow, 1u);
-        }
-      } else {
-        const float sx = 0.5f * (float)a.width, sy = 0.5f * (float)a.height;
-        TriRec r;
-        if (make_record(viewport_vs(c0, sx, sy), viewport_vs(c1, sx, sy), viewport_vs(c2, sx, sy), t.w,
-                        a.width, a.height, r)) {
-          binned = 1;
-          entries = emit_record(a, slot, r);
+          Win v0, v1, v2;
+          v0.x = w0.x; v0.y = w0.y; v0.z = w0.z;
+          v1.x = w1.x; v1.y = w1.y; v1.z = w1.z;
+          v2.x = w2.x; v2.y = w2.y; v2.z = w2.z;
+          have = make_record(v0, v1, v2, order, a.width, a.height, r);
         }
       }
     }
+    // triangles that cross a frustum plane go to clip_kernel: one list append per wave
+    const unsigned long long cm = __ballot(needs_clip);
+    if (cm) {
+      const int lane = tid & 63;
+      const int leader = __ffsll((long long)cm) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&shard.clip_count, (uint32_t)__popcll(cm));
+      base = __shfl(base, leader);
+      if (needs_clip) {
+        const uint32_t kk = base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+        if (kk < a.clip_capacity) {
+          ClipItem it; it.slot = (uint32_t)slot; it.chunk = (uint32_t)chunk_id; it.tri = (uint32_t)tid; it.pad = 0;
+          a.clip_list[(size_t)shard_id * a.clip_capacity + kk] = it;
+        } else {
+          shard.clip_overflow = 1u;
+        }
+      }
+    }
+    if (__ballot(have)) {
+      entries += emit_record_wave(a, slot, have, r);
+      binned += have ? 1u : 0u;
+    }
   }
-  // statistics: one atomic per wave
-  const unsigned long long bm = __ballot(binned != 0);
-  uint32_t e = entries;
-  for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off);
-  if ((tid & 63) == 0 && bm) {
-    atomicAdd(&a.counters->tris_binned, (unsigned long long)__popcll(bm));
-    atomicAdd(&a.counters->bin_entries, (unsigned long long)e);
+  // statistics: one (sharded) atomic pair per workgroup
+  uint32_t b = binned, e = entries;
+  for (int off = 32; off > 0; off >>= 1) { b += __shfl_down(b, off); e += __shfl_down(e, off); }
+  if ((tid & 63) == 0 && b) {
+    atomicAdd(&s_stat[0], b);
+    atomicAdd(&s_stat[1], e);
+  }
+  __syncthreads();
+  if (tid == 0 && s_stat[0]) {
+    atomicAdd(&shard.tris_binned, (unsigned long long)s_stat[0]);
+    atomicAdd(&shard.bin_entries, (unsigned long long)s_stat[1]);
   }
 }
 
@@ -357,20 +493,26 @@ __device__ __forceinline__ float clipdist(const float* c, int plane)
   return s;
 }
 
-__device__ void clip_one(const SetupArgs& a, const ClipItem it);
+__device__ void clip_one(const SetupArgs& a, const ClipItem it, int shard_id);
 
 __global__ __launch_bounds__(kBlock) void clip_kernel(SetupArgs a)
 {
-  const uint32_t n = min(a.counters->clip_count, a.clip_capacity);
-  for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n; gid += gridDim.x * blockDim.x)
-    clip_one(a, a.clip_list[gid]);
+  // workgroups b, b + kCounterShards, ... serve shard b % kCounterShards
+  const int shard_id = blockIdx.x % kCounterShards;
+  const uint32_t n = min(a.counters->shard[shard_id].clip_count, a.clip_capacity);
+  const uint32_t per = gridDim.x / kCounterShards;
+  const ClipItem* list = a.clip_list + (size_t)shard_id * a.clip_capacity;
+  for (uint32_t i = (blockIdx.x / kCounterShards) * blockDim.x + threadIdx.x; i < n; i += per * blockDim.x)
+    clip_one(a, list[i], shard_id);
 }
 
-__device__ void clip_one(const SetupArgs& a, const ClipItem it)
+__device__ void clip_one(const SetupArgs& a, const ClipItem it, int shard_id)
 {
   const int slot = (int)it.slot, stream = a.group_base + slot;
-  const float* __restrict__ M = a.mvp + ((size_t)stream * (a.n_draws + 1) + it.draw) * 16;
-  const uint4 t = a.tris[it.tri];
+  const Chunk ch = a.chunks[it.chunk];
+  const float* __restrict__ M = a.mvp + ((size_t)stream * (a.n_draws + 1) + ch.draw) * 16;
+  const uint32_t packed = a.ctris[ch.tri_begin + it.tri];
+  const uint32_t order = it.chunk == a.bg_chunk ? 0u : ch.order_base + it.tri;
   const float sx = 0.5f * (float)a.width, sy = 0.5f * (float)a.height;
 
   constexpr int kMaxV = 24, kMaxP = 12;
@@ -378,9 +520,9 @@ __device__ void clip_one(const SetupArgs& a, const ClipItem it)
   int npool = 3;
   unsigned ormask = 0;
   {
-    const uint32_t vi[3] = {t.x, t.y, t.z};
+    const uint32_t vi[3] = {packed & 1023u, (packed >> 10) & 1023u, (packed >> 20) & 1023u};
     for (int i = 0; i < 3; i++) {
-      const float4 p = a.verts[vi[i]];
+      const float4 p = a.cverts[ch.vert_begin + vi[i]];
       vs_position(M, p.x, p.y, p.z, pool[i].c);
       pool[i].w = viewport_vs(pool[i].c, sx, sy);
       ormask |= clipmask_of(pool[i].c);
@@ -436,14 +578,14 @@ __device__ void clip_one(const SetupArgs& a, const ClipItem it)
   uint32_t binned = 0, entries = 0;
   for (int i = 2; i < nv; i++) {
     TriRec r;
-    if (make_record(pool[inl[i - 1]].w, pool[inl[i]].w, pool[inl[0]].w, t.w, a.width, a.height, r)) {
+    if (make_record(pool[inl[i - 1]].w, pool[inl[i]].w, pool[inl[0]].w, order, a.width, a.height, r)) {
       binned++;
       entries += emit_record(a, slot, r);
     }
   }
   if (binned) {
-    atomicAdd(&a.counters->tris_binned, (unsigned long long)binned);
-    atomicAdd(&a.counters->bin_entries, (unsigned long long)entries);
+    atomicAdd(&a.counters->shard[shard_id].tris_binned, (unsigned long long)binned);
+    atomicAdd(&a.counters->shard[shard_id].bin_entries, (unsigned long long)entries);
   }
 }
 
@@ -541,15 +683,25 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, uint32_t* s
   }
 }
 
-// urdf_filter.frag:14-35
-__device__ __forceinline__ float shade(float sensor, float z, float z_near, float z_far, float max_diff,
-                                       float replace_value, bool& filt)
+// urdf_filter.frag:14-35.  num = z_near*z_far/(z_near-z_far) and off = z_far/(z_far-z_near)
+// depend on uniforms only and are evaluated once per thread (same float operations).
+struct ShadeConsts { float num, off, max_diff, replace_value; };
+
+__device__ __forceinline__ ShadeConsts shade_consts(float z_near, float z_far, float max_diff, float replace_value)
 {
-  const float num = __fdiv_rn(__fmul_rn(z_near, z_far), __fsub_rn(z_near, z_far));
-  const float off = __fdiv_rn(z_far, __fsub_rn(z_far, z_near));
-  const float virt = __fdiv_rn(num, __fsub_rn(z, off));
-  filt = sensor > __fsub_rn(virt, max_diff);
-  return filt ? replace_value : sensor;
+  ShadeConsts k;
+  k.num = __fdiv_rn(__fmul_rn(z_near, z_far), __fsub_rn(z_near, z_far));
+  k.off = __fdiv_rn(z_far, __fsub_rn(z_far, z_near));
+  k.max_diff = max_diff;
+  k.replace_value = replace_value;
+  return k;
+}
+
+__device__ __forceinline__ float shade(float sensor, float z, const ShadeConsts& k, bool& filt)
+{
+  const float virt = __fdiv_rn(k.num, __fsub_rn(z, k.off));
+  filt = sensor > __fsub_rn(virt, k.max_diff);
+  return filt ? k.replace_value : sensor;
 }
 
 template <bool TWO_KERNEL>
@@ -570,27 +722,31 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
   const bool analytic_bg = a.bg_mode[stream] != 0;
   const float bgz = a.bg_z[stream];
   const unsigned long long bgkey = analytic_bg ? (((unsigned long long)z24_of(bgz) << 32)) : kNoFragment;
-  for (int i = tid; i < kTileW * kTileH; i += kBlock) keys[i] = bgkey;
+  const ShadeConsts sc = shade_consts(a.z_near, a.z_far, a.max_diff, a.replace_value);
 
   const uint32_t count = a.bin_count[bin];
   const uint32_t n = min(count, a.capacity);
   const TriRec* recs = a.bins + (size_t)bin * a.capacity;
-  __syncthreads();
-  if (tid == 0) {
-    a.bin_count[bin] = 0;                 // ready for the next batch
-    if (count) atomicMax(&a.counters->max_bin_fill, count);
-  }
-  raster_bin<0>(keys, s_large, &s_nlarge, recs, n, x_base, y_base, tid);
+  const bool empty = n == 0;                // no geometry in this tile: pure streaming compare
+  if (!empty) {
+    for (int i = tid; i < kTileW * kTileH; i += kBlock) keys[i] = bgkey;
+    __syncthreads();
+    if (tid == 0) {
+      a.bin_count[bin] = 0;                 // ready for the next batch
+      atomicMax(&a.counters->shard[bin % kCounterShards].max_bin_fill, count);
+    }
+    raster_bin<0>(keys, s_large, &s_nlarge, recs, n, x_base, y_base, tid);
 
-  // Does any pixel need the exact float z of its winner?  Only when the winning depth is in the
-  // lower half of the depth range (z24 <= 2^23): above it, float z == (z24 + 1) * 2^-24 exactly.
-  bool need = false;
-  for (int i = tid; i < kTileW * kTileH; i += kBlock) {
-    const unsigned long long k = keys[i];
-    if (k != bgkey && (uint32_t)(k >> 32) <= 8388608u) need = true;
-  }
-  if (__syncthreads_or(need)) {
-    raster_bin<1>(keys, s_large, &s_nlarge, recs, n, x_base, y_base, tid);
+    // Does any pixel need the exact float z of its winner?  Only when the winning depth is in the
+    // lower half of the depth range (z24 <= 2^23): above it, float z == (z24 + 1) * 2^-24 exactly.
+    bool need = false;
+    for (int i = tid; i < kTileW * kTileH; i += kBlock) {
+      const unsigned long long k = keys[i];
+      if (k != bgkey && (uint32_t)(k >> 32) <= 8388608u) need = true;
+    }
+    if (__syncthreads_or(need)) {
+      raster_bin<1>(keys, s_large, &s_nlarge, recs, n, x_base, y_base, tid);
+    }
   }
 
   // resolve: 16 lanes x 4 pixels per tile row, 16 rows per pass
@@ -603,7 +759,7 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
     bool frag[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const unsigned long long k = keys[ly * kTileW + lx + j];
+      const unsigned long long k = empty ? bgkey : keys[ly * kTileW + lx + j];
       frag[j] = true;
       if (k & kResolvedBit) z[j] = __uint_as_float((uint32_t)k);
       else if (k == bgkey) { z[j] = bgz; frag[j] = analytic_bg; }
@@ -631,7 +787,7 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         bool f;
-        o[j] = shade(s[j], z[j], a.z_near, a.z_far, a.max_diff, a.replace_value, f);
+        o[j] = shade(s[j], z[j], sc, f);
         if (!frag[j]) { o[j] = 0.0f; f = false; }     // GL clear colour
         if (f) mbits |= 0xffu << (8 * j);
       }
@@ -654,6 +810,7 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
 
 __global__ __launch_bounds__(kBlock) void compare_kernel(CompareArgs a)
 {
+  const ShadeConsts sc = shade_consts(a.z_near, a.z_far, a.max_diff, a.replace_value);
   const size_t n4 = a.n_pixels >> 2;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -665,7 +822,7 @@ __global__ __launch_bounds__(kBlock) void compare_kernel(CompareArgs a)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       bool f;
-      o[j] = shade(sv[j], zv[j], a.z_near, a.z_far, a.max_diff, a.replace_value, f);
+      o[j] = shade(sv[j], zv[j], sc, f);
       if (zv[j] != zv[j]) { o[j] = 0.0f; f = false; }
       if (f) mbits |= 0xffu << (8 * j);
     }
@@ -676,14 +833,26 @@ __global__ __launch_bounds__(kBlock) void compare_kernel(CompareArgs a)
   if (blockIdx.x == 0 && threadIdx.x < (a.n_pixels & 3)) {
     const size_t i = (n4 << 2) + threadIdx.x;
     bool f;
-    float o = shade(a.depth[i], a.zsurface[i], a.z_near, a.z_far, a.max_diff, a.replace_value, f);
+    float o = shade(a.depth[i], a.zsurface[i], sc, f);
     if (a.zsurface[i] != a.zsurface[i]) { o = 0.0f; f = false; }
     a.masked[i] = o;
     if (a.mask) a.mask[i] = f ? 255 : 0;
   }
 }
 
+// clip-list counters are per in-flight group: reset between groups of one batch (clip_count of
+// earlier groups stays in the statistics through clip_total)
+__global__ void reset_clip_kernel(Counters* c)
+{
+  const int i = threadIdx.x;
+  if (i < kCounterShards) c->shard[i].clip_count = 0;
+}
+
 // host-callable launchers ---------------------------------------------------------------
+void launch_reset_clip(Counters* c, hipStream_t st)
+{
+  hipLaunchKernelGGL(reset_clip_kernel, dim3(1), dim3(kCounterShards), 0, st, c);
+}
 void launch_pose(const PoseArgs& a, hipStream_t st)
 {
   const int total = a.n_streams * (a.n_draws + 1);
@@ -691,12 +860,13 @@ void launch_pose(const PoseArgs& a, hipStream_t st)
 }
 void launch_setup(const SetupArgs& a, int n_chunks, hipStream_t st)
 {
-  hipLaunchKernelGGL(setup_kernel, dim3(n_chunks, a.group_size), dim3(kBlock), 0, st, a);
+  // x = stream group (fastest: consecutive workgroups share the chunk's geometry in L2), y = chunk
+  hipLaunchKernelGGL(setup_kernel, dim3((a.group_size + kStreamsPerBlock - 1) / kStreamsPerBlock, n_chunks), dim3(kBlock), 0, st, a);
 }
 void launch_clip(const SetupArgs& a, hipStream_t st)
 {
   // the item count lives on the device: fixed grid, grid-stride loop
-  hipLaunchKernelGGL(clip_kernel, dim3(512), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * 8), dim3(kBlock), 0, st, a);
 }
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st)
 {
