@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--two-kernel", action="store_true", help="rasteriser + separate compare kernel")
     ap.add_argument("--no-mask", action="store_true", help="need_mask_ == false: no mask output")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
+    ap.add_argument("--debug-flags", type=lambda x: int(x, 0), default=0, help="timing experiments only (results are wrong)")
     ap.add_argument("--check-frames", type=int, default=4, help="frames of the last step verified against the oracle")
     args = ap.parse_args()
 
@@ -72,6 +73,7 @@ def main():
     p.depth_distance_threshold = wl0.max_diff
     if args.two_kernel:
         p.flags |= R.FLAG_TWO_KERNEL
+    p.flags |= args.debug_flags
     ctx = R.Context(W, H, n, local_rank, p)
     ids = wl0.load_into(ctx)
     ctx.enable_timing(True)

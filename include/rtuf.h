@@ -167,7 +167,8 @@ typedef struct {
   uint32_t max_bin_fill;            /* largest bin of the last batch                   */
   uint32_t bin_capacity;
   uint32_t regrowths;               /* times the bins were enlarged and a batch re-run */
-  uint32_t reserved;
+  uint32_t max_fbin_fill;           /* largest fragment bin of the last batch          */
+  uint64_t fragments_binned;        /* covered pixels of tiny (<= 2x2 px) triangles binned as fragments */
   float ms_pose, ms_setup, ms_raster, ms_compare, ms_total;   /* last timed batch       */
 } rtuf_stats;
 int rtuf_get_stats(rtuf_context *ctx, rtuf_stats *out);

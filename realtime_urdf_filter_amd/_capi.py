@@ -40,7 +40,7 @@ class Stats(ctypes.Structure):
     _fields_ = [("triangles_submitted", ctypes.c_uint64), ("triangles_binned", ctypes.c_uint64),
                 ("bin_entries", ctypes.c_uint64), ("triangles_clipped", ctypes.c_uint64),
                 ("max_bin_fill", ctypes.c_uint32), ("bin_capacity", ctypes.c_uint32),
-                ("regrowths", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("regrowths", ctypes.c_uint32), ("max_fbin_fill", ctypes.c_uint32), ("fragments_binned", ctypes.c_uint64),
                 ("ms_pose", ctypes.c_float), ("ms_setup", ctypes.c_float), ("ms_raster", ctypes.c_float),
                 ("ms_compare", ctypes.c_float), ("ms_total", ctypes.c_float)]
 

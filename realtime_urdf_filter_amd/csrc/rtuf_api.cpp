@@ -61,8 +61,9 @@ struct rtuf_context {
 
   // rasteriser working set
   int group = 0;                       // in-flight streams per launch group
-  uint32_t capacity = 0, clip_capacity = 0;
+  uint32_t capacity = 0, fcapacity = 0, clip_capacity = 0;
   TriRec* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr;
+  Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
   Counters* d_counters = nullptr; Counters* h_counters = nullptr;
   float* d_zsurface = nullptr;
 
@@ -155,7 +156,7 @@ static void free_frame_buffers(rtuf_context* c)
   auto dfree = [](auto*& p) { if (p) { hipFree(p); p = nullptr; } };
   auto hfree = [](auto*& p) { if (p) { hipHostFree(p); p = nullptr; } };
   dfree(c->d_cams); dfree(c->d_link_tf); dfree(c->d_model_mask); dfree(c->d_mvp); dfree(c->d_bg_z); dfree(c->d_bg_mode);
-  dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_clip_list); dfree(c->d_counters); dfree(c->d_zsurface);
+  dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_counters); dfree(c->d_zsurface);
   dfree(c->d_depth); dfree(c->d_masked); dfree(c->d_mask);
   hfree(c->h_cams); hfree(c->h_link_tf); hfree(c->h_model_mask); hfree(c->h_counters);
   c->staged_streams = 0;
@@ -276,9 +277,13 @@ static int alloc_frame_buffers(rtuf_context* c)
   c->group = G;
   c->capacity = cap;
   c->clip_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 8192 / kCounterShards, 1024), (size_t)1 << 22);   // per shard
+  c->fcapacity = std::max<uint32_t>(cap, 1024);
   HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(TriRec)));
   HIP_TRY(c, hipMalloc(&c->d_bin_count, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(c->d_bin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc(&c->d_fbins, (size_t)G * tiles * c->fcapacity * sizeof(Frag)));
+  HIP_TRY(c, hipMalloc(&c->d_fbin_count, (size_t)G * tiles * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemset(c->d_fbin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
   if (c->params.flags & RTUF_FLAG_TWO_KERNEL)
     HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)G * c->width * c->height * sizeof(float)));
@@ -499,19 +504,24 @@ static hipEvent_t get_event(rtuf_context* c, size_t i)
   return c->events[i];
 }
 
-static int grow_bins(rtuf_context* c, uint32_t needed)
+static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
 {
   const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
-  uint32_t cap = c->capacity;
+  uint32_t cap = c->capacity, fcap = c->fcapacity;
   while (cap < needed) cap *= 2;
+  while (fcap < fneeded) fcap *= 2;
   hipFree(c->d_bins); c->d_bins = nullptr;
+  hipFree(c->d_fbins); c->d_fbins = nullptr;
   int G = c->group;
   const size_t budget = (size_t)48 << 30;
-  while (G > 1 && (size_t)G * tiles * cap * sizeof(TriRec) > budget) G = (G + 1) / 2;
-  if ((size_t)G * tiles * cap * sizeof(TriRec) > ((size_t)160 << 30)) return c->fail(RTUF_ERR_CAPACITY, "bin capacity %u too large", cap);
+  auto bytes = [&](int g) { return (size_t)g * tiles * ((size_t)cap * sizeof(TriRec) + (size_t)fcap * sizeof(Frag)); };
+  while (G > 1 && bytes(G) > budget) G = (G + 1) / 2;
+  if (bytes(G) > ((size_t)160 << 30)) return c->fail(RTUF_ERR_CAPACITY, "bin capacity %u/%u too large", cap, fcap);
   c->group = G;
   c->capacity = cap;
+  c->fcapacity = fcap;
   HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(TriRec)));
+  HIP_TRY(c, hipMalloc(&c->d_fbins, (size_t)G * tiles * fcap * sizeof(Frag)));
   c->stats.regrowths++;
   return RTUF_OK;
 }
@@ -542,6 +552,7 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
     SetupArgs sa{};
     sa.cverts = c->d_cverts; sa.ctris = c->d_ctris; sa.chunks = c->d_chunks; sa.mvp = c->d_mvp;
     sa.model_mask = c->d_model_mask; sa.bg_mode = c->d_bg_mode; sa.bins = c->d_bins; sa.bin_count = c->d_bin_count;
+    sa.fbins = c->d_fbins; sa.fbin_count = c->d_fbin_count; sa.fcapacity = c->fcapacity;
     sa.clip_list = c->d_clip_list; sa.counters = c->d_counters; sa.group_base = base; sa.group_size = gs;
     sa.n_draws = c->n_draws; sa.width = c->width; sa.height = c->height; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
     sa.capacity = c->capacity; sa.clip_capacity = c->clip_capacity; sa.bg_chunk = c->bg_chunk;
@@ -549,7 +560,8 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
     launch_clip(sa, st);
     if (c->timing) hipEventRecord(get_event(c, ev++), st);
     TileArgs ta{};
-    ta.bins = c->d_bins; ta.bin_count = c->d_bin_count; ta.depth = d_depth; ta.masked = d_masked; ta.mask = d_mask;
+    ta.bins = c->d_bins; ta.bin_count = c->d_bin_count;
+    ta.fbins = c->d_fbins; ta.fbin_count = c->d_fbin_count; ta.fcapacity = c->fcapacity; ta.depth = d_depth; ta.masked = d_masked; ta.mask = d_mask;
     ta.zsurface = c->d_zsurface; ta.bg_z = c->d_bg_z; ta.bg_mode = c->d_bg_mode; ta.counters = c->d_counters;
     ta.group_base = base; ta.group_size = gs; ta.width = c->width; ta.height = c->height;
     ta.tiles_x = c->tiles_x; ta.tiles_y = c->tiles_y; ta.capacity = c->capacity; ta.flags = c->params.flags;
@@ -594,11 +606,12 @@ int rtuf_sync(rtuf_context* c)
   for (int attempt = 0; attempt < 8; attempt++) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (!c->pending) return RTUF_OK;
-    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0; unsigned max_bin_fill = 0, clip_overflow = 0; } k;
+    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0; unsigned max_bin_fill = 0, max_fbin_fill = 0, clip_overflow = 0; } k;
     for (int i = 0; i < kCounterShards; i++) {
       const CounterShard& sh = c->h_counters->shard[i];
       k.tris_binned += sh.tris_binned; k.bin_entries += sh.bin_entries; k.clip_count += sh.clip_count;
       k.max_bin_fill = std::max(k.max_bin_fill, sh.max_bin_fill); k.clip_overflow |= sh.clip_overflow;
+      k.max_fbin_fill = std::max(k.max_fbin_fill, sh.max_fbin_fill); k.frags += sh.frags;
     }
     c->stats.triangles_submitted = (uint64_t)c->n_tris * (uint64_t)c->last_n;
     c->stats.triangles_binned = k.tris_binned;
@@ -606,7 +619,9 @@ int rtuf_sync(rtuf_context* c)
     c->stats.triangles_clipped = k.clip_count;
     c->stats.max_bin_fill = k.max_bin_fill;
     c->stats.bin_capacity = c->capacity;
-    const bool bin_over = k.max_bin_fill > c->capacity;
+    c->stats.fragments_binned = k.frags;
+    c->stats.max_fbin_fill = k.max_fbin_fill;
+    const bool bin_over = k.max_bin_fill > c->capacity || k.max_fbin_fill > c->fcapacity;
     const bool clip_over = k.clip_overflow != 0;
     if (!bin_over && !clip_over) {
       c->pending = false;
@@ -627,7 +642,7 @@ int rtuf_sync(rtuf_context* c)
       return RTUF_OK;
     }
     // overflow: enlarge and run the batch again (inputs are still resident)
-    if (bin_over) { const int rc = grow_bins(c, k.max_bin_fill); if (rc != RTUF_OK) { c->pending = false; return rc; } }
+    if (bin_over) { const int rc = grow_bins(c, k.max_bin_fill, k.max_fbin_fill); if (rc != RTUF_OK) { c->pending = false; return rc; } }
     if (clip_over) {
       hipFree(c->d_clip_list); c->d_clip_list = nullptr;
       c->clip_capacity *= 4;
@@ -639,6 +654,7 @@ int rtuf_sync(rtuf_context* c)
     }
     const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
     HIP_TRY(c, hipMemsetAsync(c->d_bin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_fbin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->stream));
     const int rc = enqueue_batch(c, c->last_n, c->last_depth, c->last_masked, c->last_mask);
     if (rc != RTUF_OK) { c->pending = false; return rc; }
   }

@@ -14,7 +14,8 @@
 //     mvp    f32[N][D][16]  written by pose_kernel
 //     depth  f32[N][H][W] in, masked f32[N][H][W] + mask u8[N][H][W] out
 //   rasteriser working set, per in-flight stream g and screen tile
-//     bin_count u32[G][tiles], bins TriRec[G][tiles][capacity]
+//     bin_count u32[G][tiles], bins TriRec[G][tiles][capacity]     (triangles, 64 B records)
+//     fbin_count u32[G][tiles], fbins Frag[G][tiles][fcapacity]    (pixels of tiny triangles, 16 B)
 //     clip_list ClipItem[], zsurface f32[G][H][W] (two-kernel mode only)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -22,8 +23,14 @@
 
 namespace rtuf {
 
-constexpr int kTileW = 64;
-constexpr int kTileH = 64;
+#ifndef RTUF_TILE_W
+#define RTUF_TILE_W 32
+#endif
+#ifndef RTUF_TILE_H
+#define RTUF_TILE_H 32
+#endif
+constexpr int kTileW = RTUF_TILE_W;      // screen tile of one raster workgroup (LDS: 8 B per pixel)
+constexpr int kTileH = RTUF_TILE_H;
 constexpr int kBlock = 256;
 constexpr int kMaxChunkVerts = 384;     // unique vertices per set-up chunk (LDS: 16 B each)
 constexpr int kStreamsPerBlock = 4;     // streams a set-up workgroup loops over per chunk
@@ -39,6 +46,14 @@ struct alignas(16) TriRec {     // 64 B: one rasterisable triangle inside one ti
   uint32_t pad;
 };
 static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
+
+struct alignas(16) Frag {       // 16 B: one covered pixel of a tiny (<= 2x2 px bounding box) triangle
+  uint32_t xy;                  // x | y << 16
+  uint32_t z24;                 // 24-bit depth-test value
+  uint32_t order;               // draw-order sequence number
+  uint32_t zbits;               // float window z (what the fragment shader sees)
+};
+static_assert(sizeof(Frag) == 16, "Frag must be 16 bytes");
 
 struct Chunk {                  // <= 256 consecutive triangles of one draw + their vertex list
   uint32_t tri_begin;           // into ctris
@@ -84,7 +99,9 @@ struct alignas(128) CounterShard {
   unsigned int clip_count;      // entries in this shard's segment of clip_list
   unsigned int max_bin_fill;
   unsigned int clip_overflow;
-  unsigned int pad[25];
+  unsigned int max_fbin_fill;
+  unsigned long long frags;
+  unsigned int pad[22];
 };
 static_assert(sizeof(CounterShard) == 128, "CounterShard must be one 128-byte line");
 struct Counters { CounterShard shard[kCounterShards]; };
@@ -120,8 +137,11 @@ struct SetupArgs {
   const float* mvp;              // [n_streams][n_draws + 1][16]
   const uint64_t* model_mask;    // [n_streams] bit m set: stream renders model m
   const uint32_t* bg_mode;       // [n_streams]
-  TriRec* bins;                  // [G][tiles][capacity]
+  TriRec* bins;                  // [G][tiles][capacity]   triangles with a bounding box > 2x2 px
   uint32_t* bin_count;           // [G][tiles]
+  Frag* fbins;                   // [G][tiles][fcapacity]  covered pixels of the tiny triangles
+  uint32_t* fbin_count;          // [G][tiles]
+  uint32_t fcapacity;
   ClipItem* clip_list;
   Counters* counters;
   int group_base;                // first stream slot of this in-flight group
@@ -136,6 +156,9 @@ struct SetupArgs {
 struct TileArgs {
   const TriRec* bins;
   uint32_t* bin_count;           // reset to 0 by this kernel after use
+  const Frag* fbins;
+  uint32_t* fbin_count;          // reset to 0 by this kernel after use
+  uint32_t fcapacity;
   const float* depth;            // [n][H][W]
   float* masked;                 // [n][H][W]
   uint8_t* mask;                 // [n][H][W] or nullptr

@@ -336,6 +336,65 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slo
 // consecutive triangles of one draw call with its own <= kMaxChunkVerts vertex list, so each
 // vertex is transformed once per stream (into LDS) instead of once per incident triangle, and
 // the chunk's geometry is loaded once for all streams of the group.
+__device__ __forceinline__ uint32_t z24_of(float z)
+{
+  const float zc = fminf(fmaxf(z, 0.0f), 1.0f);
+  return (uint32_t)__float2int_rn(__fmul_rn(zc, 16777215.0f));
+}
+
+__device__ __forceinline__ bool inside(const TriRec& r, int px, int py)
+{
+  const int e0 = r.A[0] * px + r.B[0] * py + r.C[0];
+  const int e1 = r.A[1] * px + r.B[1] * py + r.C[1];
+  const int e2 = r.A[2] * px + r.B[2] * py + r.C[2];
+  return (e0 > 0) & (e1 > 0) & (e2 > 0);
+}
+
+// Wave-cooperative emission of the covered pixels of tiny triangles (bounding box <= 2x2): four
+// rounds (one per bounding-box corner), each with the same ballot grouping / single atomic
+// round trip as emit_record_wave.  A tiny triangle that covers no pixel centre emits nothing.
+__device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int slot, bool tiny, const TriRec& r,
+                                                        int bx0, int bx1, int by0, int by1)
+{
+  const int lane = threadIdx.x & 63;
+  const int tiles = a.tiles_x * a.tiles_y;
+  uint32_t n = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int px = bx0 + (k & 1), py = by0 + (k >> 1);
+    const bool act = tiny && px <= bx1 && py <= by1 && inside(r, px, py);
+    unsigned long long pending = __ballot(act);
+    if (!pending) continue;
+    const int bin = act ? slot * tiles + (py / kTileH) * a.tiles_x + (px / kTileW) : -1;
+    unsigned long long mymask = 0;
+    int myleader = lane;
+    while (pending) {
+      const int leader = __ffsll((long long)pending) - 1;
+      const int lbin = __shfl(bin, leader);
+      const unsigned long long m = __ballot(act && bin == lbin);
+      if (act && bin == lbin) { mymask = m; myleader = leader; }
+      pending &= ~m;
+    }
+    uint32_t base = 0;
+    if (act && lane == myleader) base = atomicAdd(&a.fbin_count[bin], (uint32_t)__popcll(mymask));
+    base = __shfl(base, myleader);
+    if (act) {
+      const uint32_t pos = base + (uint32_t)__popcll(mymask & ((1ull << lane) - 1ull));
+      if (pos < a.fcapacity) {
+        const float z = __fmaf_rn(r.dzdy, (float)py, __fmaf_rn(r.dzdx, (float)px, r.a0));
+        uint4 f;
+        f.x = (uint32_t)px | ((uint32_t)py << 16);
+        f.y = z24_of(z);
+        f.z = r.order;
+        f.w = __float_as_uint(z);
+        reinterpret_cast<uint4*>(a.fbins)[(size_t)bin * a.fcapacity + pos] = f;
+      }
+      n++;
+    }
+  }
+  return n;
+}
+
 // True when the chunk's bounding sphere lies completely outside one frustum plane: then all its
 // vertices carry that plane's clip bit and every triangle would be rejected by the per-triangle
 // test anyway (same result, decided once per chunk).  Margins keep the test conservative.
@@ -368,8 +427,8 @@ __device__ __forceinline__ bool chunk_outside(const float* __restrict__ M, const
 __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
 {
   __shared__ float4 s_win[2][kMaxChunkVerts];   // window x, y, z + clip mask bits (double-buffered)
-  __shared__ uint32_t s_stat[2];
-  if (threadIdx.x < 2) s_stat[threadIdx.x] = 0;
+  __shared__ uint32_t s_stat[3];
+  if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
   const int chunk_id = blockIdx.y;
   const int shard_id = (int)((blockIdx.x + blockIdx.y) % kCounterShards);
   CounterShard& shard = a.counters->shard[shard_id];
@@ -386,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
   const uint32_t order = is_bg ? 0u : ch.order_base + (uint32_t)tid;
   const float sx = 0.5f * (float)a.width, sy = 0.5f * (float)a.height;
 
-  uint32_t binned = 0, entries = 0;
+  uint32_t binned = 0, entries = 0, nfrag = 0;
   int buf = 0;
   for (int k = 0; k < kStreamsPerBlock; k++) {
     const int slot = blockIdx.x * kStreamsPerBlock + k;
@@ -454,21 +513,30 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
       }
     }
     if (__ballot(have)) {
-      entries += emit_record_wave(a, slot, have, r);
+      // Tiny triangles (bounding box <= 2x2 pixel centres, the bulk of a dense mesh) are resolved
+      // to their covered pixels right here and binned as 16-byte fragments; everything else is
+      // binned as a 64-byte triangle record.
+      const int bx0 = (int)(r.bbx & 0xffff), bx1 = (int)(r.bbx >> 16);
+      const int by0 = (int)(r.bby & 0xffff), by1 = (int)(r.bby >> 16);
+      const bool tiny = have && (bx1 - bx0) <= 1 && (by1 - by0) <= 1;
+      nfrag += emit_fragments_wave(a, slot, tiny, r, bx0, bx1, by0, by1);
+      entries += emit_record_wave(a, slot, have && !tiny, r);
       binned += have ? 1u : 0u;
     }
   }
   // statistics: one (sharded) atomic pair per workgroup
-  uint32_t b = binned, e = entries;
-  for (int off = 32; off > 0; off >>= 1) { b += __shfl_down(b, off); e += __shfl_down(e, off); }
+  uint32_t b = binned, e = entries, f = nfrag;
+  for (int off = 32; off > 0; off >>= 1) { b += __shfl_down(b, off); e += __shfl_down(e, off); f += __shfl_down(f, off); }
   if ((tid & 63) == 0 && b) {
     atomicAdd(&s_stat[0], b);
     atomicAdd(&s_stat[1], e);
+    atomicAdd(&s_stat[2], f);
   }
   __syncthreads();
   if (tid == 0 && s_stat[0]) {
     atomicAdd(&shard.tris_binned, (unsigned long long)s_stat[0]);
     atomicAdd(&shard.bin_entries, (unsigned long long)s_stat[1]);
+    atomicAdd(&shard.frags, (unsigned long long)s_stat[2]);
   }
 }
 
@@ -596,11 +664,6 @@ __device__ void clip_one(const SetupArgs& a, const ClipItem it, int shard_id)
 constexpr unsigned long long kNoFragment = 0x00ffffff00000000ull;   // cleared depth 1.0, order 0
 constexpr unsigned long long kResolvedBit = 1ull << 63;
 
-__device__ __forceinline__ uint32_t z24_of(float z)
-{
-  const float zc = fminf(fmaxf(z, 0.0f), 1.0f);
-  return (uint32_t)__float2int_rn(__fmul_rn(zc, 16777215.0f));
-}
 
 // MODE 0: depth test (atomicMin of {z24, order});  MODE 1: write the exact float z of the
 // fragment that won (needed only for window z <= 0.5, where float z is finer than 24 bits).
@@ -616,20 +679,29 @@ __device__ __forceinline__ void fragment(unsigned long long* keys, const TriRec&
   }
 }
 
-__device__ __forceinline__ bool inside(const TriRec& r, int px, int py)
+
+constexpr int kSmallArea = 12;     // bounding boxes up to this many pixels are walked by their own lane
+
+// Broadcast of one lane's record to the whole wave through scalar registers (v_readlane): the
+// cooperative path then runs with the triangle's 16 words as SGPR operands.
+__device__ __forceinline__ TriRec broadcast_record(const TriRec& r, int src_lane)
 {
-  const int e0 = r.A[0] * px + r.B[0] * py + r.C[0];
-  const int e1 = r.A[1] * px + r.B[1] * py + r.C[1];
-  const int e2 = r.A[2] * px + r.B[2] * py + r.C[2];
-  return (e0 > 0) & (e1 > 0) & (e2 > 0);
+  TriRec q;
+  const int* s = reinterpret_cast<const int*>(&r);
+  int* d = reinterpret_cast<int*>(&q);
+#pragma unroll
+  for (int k = 0; k < 16; k++) d[k] = __builtin_amdgcn_readlane(s[k], src_lane);
+  return q;
 }
 
-constexpr int kSmallArea = 32;
-
+// Rasterises the bin's records into the LDS key tile.  Every wave works on its own records
+// (no workgroup barrier inside): lane-per-triangle for tiny bounding boxes, the whole wave in
+// 8x8 stamps for anything larger.
 template <int MODE>
-__device__ __forceinline__ void raster_bin(unsigned long long* keys, uint32_t* s_large, int* s_nlarge,
-                                           const TriRec* recs, uint32_t n, int x_base, int y_base, int tid)
+__device__ __forceinline__ void raster_bin(unsigned long long* keys, const TriRec* recs, uint32_t n,
+                                           int x_base, int y_base, int tid, bool dbg_load_only)
 {
+  const int lane = tid & 63;
   for (uint32_t base = 0; base < n; base += kBlock) {
     const uint32_t i = base + tid;
     const bool have = i < n;
@@ -643,43 +715,76 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, uint32_t* s
       lx1 = min((int)(r.bbx >> 16) - x_base, kTileW - 1);
       ly0 = max((int)(r.bby & 0xffff) - y_base, 0);
       ly1 = min((int)(r.bby >> 16) - y_base, kTileH - 1);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; k++) reinterpret_cast<int*>(&r)[k] = 0;
     }
     const int w = lx1 - lx0 + 1, h = ly1 - ly0 + 1;
-    const bool large = have && (w * h > kSmallArea);
-    if (have && !large) {
-      for (int ly = ly0; ly <= ly1; ly++)
-        for (int lx = lx0; lx <= lx1; lx++) {
+    int area = (have && w > 0 && h > 0) ? w * h : 0;
+    if (dbg_load_only) { if (r.order == 0xdeadbeefu) keys[0] = 0; area = 0; }
+    const bool small = area > 0 && area <= kSmallArea;
+    // lane-per-triangle: walk the bounding box as one run of `area` candidates
+    {
+      int lx = lx0, ly = ly0;
+      int todo = small ? area : 0;
+      while (__ballot(todo > 0)) {
+        if (todo > 0) {
           const int px = x_base + lx, py = y_base + ly;
           if (inside(r, px, py)) fragment<MODE>(keys, r, px, py, ly * kTileW + lx);
+          if (++lx > lx1) { lx = lx0; ly++; }
+          todo--;
         }
+      }
     }
-    // large triangles: the whole workgroup rasterises them one at a time in 16x16 stamps
-    if (tid == 0) *s_nlarge = 0;
-    __syncthreads();
-    if (large) s_large[atomicAdd(s_nlarge, 1)] = i;
-    __syncthreads();
-    const int nl = *s_nlarge;
-    for (int k = 0; k < nl; k++) {
-      const TriRec* rp = recs + s_large[k];
+    // quarter-wave cooperative: four triangles at a time, 16 lanes each, one candidate pixel per
+    // lane and step (the bounding box is walked as a linear run, so slivers waste nothing)
+    unsigned long long big = __ballot(area > kSmallArea);
+    const int grp = lane >> 4, sub = lane & 15;
+    while (big) {
+      int src = -1;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int sl = big ? __ffsll((long long)big) - 1 : -1;
+        if (big) big &= big - 1;
+        if (g == grp) src = sl;
+      }
+      const int srcl = src < 0 ? lane : src;
       TriRec q;
       {
-        const uint4* src = reinterpret_cast<const uint4*>(rp);
-        uint4* dst = reinterpret_cast<uint4*>(&q);
-        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+        const int* sp = reinterpret_cast<const int*>(&r);
+        int* dp = reinterpret_cast<int*>(&q);
+#pragma unroll
+        for (int k = 0; k < 15; k++) dp[k] = __shfl(sp[k], srcl);
       }
       const int qx0 = max((int)(q.bbx & 0xffff) - x_base, 0), qx1 = min((int)(q.bbx >> 16) - x_base, kTileW - 1);
       const int qy0 = max((int)(q.bby & 0xffff) - y_base, 0), qy1 = min((int)(q.bby >> 16) - y_base, kTileH - 1);
-      const int tx = tid & 15, ty = tid >> 4;
-      for (int sy = qy0 & ~15; sy <= qy1; sy += 16)
-        for (int sx = qx0 & ~15; sx <= qx1; sx += 16) {
-          const int lx = sx + tx, ly = sy + ty;
-          if (lx >= qx0 && lx <= qx1 && ly >= qy0 && ly <= qy1) {
-            const int px = x_base + lx, py = y_base + ly;
-            if (inside(q, px, py)) fragment<MODE>(keys, q, px, py, ly * kTileW + lx);
-          }
+      const int qw = qx1 - qx0 + 1;
+      const int qarea = src < 0 ? 0 : qw * (qy1 - qy0 + 1);
+      // idx / qw for idx < 4096, qw <= 64 via an exact reciprocal multiply
+      const uint32_t inv = (uint32_t)ceilf(__fdiv_rn(65536.0f, (float)max(qw, 1)));
+      for (int idx = sub; __ballot(idx < qarea); idx += 16) {
+        if (idx < qarea) {
+          const int yy = (int)(((uint32_t)idx * inv) >> 16);
+          const int lx = qx0 + idx - yy * qw, ly = qy0 + yy;
+          const int px = x_base + lx, py = y_base + ly;
+          if (inside(q, px, py)) fragment<MODE>(keys, q, px, py, ly * kTileW + lx);
         }
+      }
     }
-    __syncthreads();
+  }
+}
+
+// Fragments of the tiny triangles: 16-byte records, perfectly coalesced, one LDS atomic each.
+template <int MODE>
+__device__ __forceinline__ void raster_frags(unsigned long long* keys, const uint4* frags, uint32_t nf,
+                                             int x_base, int y_base, int tid)
+{
+  for (uint32_t i = tid; i < nf; i += kBlock) {
+    const uint4 f = frags[i];
+    const int lidx = ((int)(f.x >> 16) - y_base) * kTileW + ((int)(f.x & 0xffff) - x_base);
+    const unsigned long long key = ((unsigned long long)f.y << 32) | f.z;
+    if (MODE == 0) atomicMin(&keys[lidx], key);
+    else if (keys[lidx] == key) keys[lidx] = kResolvedBit | (unsigned long long)f.w;
   }
 }
 
@@ -708,8 +813,6 @@ template <bool TWO_KERNEL>
 __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
 {
   __shared__ unsigned long long keys[kTileW * kTileH];
-  __shared__ uint32_t s_large[kBlock];
-  __shared__ int s_nlarge;
 
   const int tid = threadIdx.x;
   const int tiles = a.tiles_x * a.tiles_y;
@@ -724,18 +827,25 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
   const unsigned long long bgkey = analytic_bg ? (((unsigned long long)z24_of(bgz) << 32)) : kNoFragment;
   const ShadeConsts sc = shade_consts(a.z_near, a.z_far, a.max_diff, a.replace_value);
 
-  const uint32_t count = a.bin_count[bin];
-  const uint32_t n = min(count, a.capacity);
+  const uint32_t count = a.bin_count[bin], fcount = a.fbin_count[bin];
+  const uint32_t n = min(count, a.capacity), nf = min(fcount, a.fcapacity);
   const TriRec* recs = a.bins + (size_t)bin * a.capacity;
-  const bool empty = n == 0;                // no geometry in this tile: pure streaming compare
+  const uint4* frags = reinterpret_cast<const uint4*>(a.fbins) + (size_t)bin * a.fcapacity;
+  // flags bits 8.. are timing experiments only (wrong results): 0x100 skip rasterisation, 0x200 skip pixel loops
+  const bool empty = (n == 0 && nf == 0) || (a.flags & 0x100u);   // no geometry in this tile: pure streaming compare
   if (!empty) {
     for (int i = tid; i < kTileW * kTileH; i += kBlock) keys[i] = bgkey;
     __syncthreads();
     if (tid == 0) {
       a.bin_count[bin] = 0;                 // ready for the next batch
-      atomicMax(&a.counters->shard[bin % kCounterShards].max_bin_fill, count);
+      a.fbin_count[bin] = 0;
+      CounterShard& sh = a.counters->shard[bin % kCounterShards];
+      if (count) atomicMax(&sh.max_bin_fill, count);
+      if (fcount) atomicMax(&sh.max_fbin_fill, fcount);
     }
-    raster_bin<0>(keys, s_large, &s_nlarge, recs, n, x_base, y_base, tid);
+    raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0);
+    raster_frags<0>(keys, frags, nf, x_base, y_base, tid);
+    __syncthreads();
 
     // Does any pixel need the exact float z of its winner?  Only when the winning depth is in the
     // lower half of the depth range (z24 <= 2^23): above it, float z == (z24 + 1) * 2^-24 exactly.
@@ -745,14 +855,18 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
       if (k != bgkey && (uint32_t)(k >> 32) <= 8388608u) need = true;
     }
     if (__syncthreads_or(need)) {
-      raster_bin<1>(keys, s_large, &s_nlarge, recs, n, x_base, y_base, tid);
+      raster_bin<1>(keys, recs, n, x_base, y_base, tid, false);
+      raster_frags<1>(keys, frags, nf, x_base, y_base, tid);
+      __syncthreads();
     }
   }
 
   // resolve: 16 lanes x 4 pixels per tile row, 16 rows per pass
   const bool vec = (a.width & 3) == 0;
-  for (int pass = 0; pass < kTileH / 16; pass++) {
-    const int ly = pass * 16 + (tid >> 4), lx = (tid & 15) * 4;
+  constexpr int kLanesPerRow = kTileW / 4, kRowsPerPass = kBlock / kLanesPerRow;
+  for (int pass = 0; pass < (kTileH + kRowsPerPass - 1) / kRowsPerPass; pass++) {
+    const int ly = pass * kRowsPerPass + tid / kLanesPerRow, lx = (tid % kLanesPerRow) * 4;
+    if (ly >= kTileH) continue;
     const int px = x_base + lx, py = y_base + ly;
     if (py >= a.height || px >= a.width) continue;
     float z[4];
