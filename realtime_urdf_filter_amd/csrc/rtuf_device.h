@@ -3,7 +3,7 @@
 // HBM layout (all arrays owned by one rtuf_context, one GPU):
 //   static geometry, uploaded once by rtuf_finalize_models()
 //     chunks Chunk[C]    <= 256 consecutive triangles of ONE draw call + the list of the
-//                        <= 384 distinct vertices they use                32 B / chunk
+//                        <= 256 distinct vertices they use                32 B / chunk
 //     cverts float4[Vc]  object-space positions, grouped per chunk        16 B / vertex
 //     ctris  u32[T]      3 x 10-bit chunk-local vertex ids                 4 B / triangle
 //                        (draw-order sequence number = chunk.order_base + index; 0 = background)
@@ -32,7 +32,7 @@ namespace rtuf {
 constexpr int kTileW = RTUF_TILE_W;      // screen tile of one raster workgroup (LDS: 8 B per pixel)
 constexpr int kTileH = RTUF_TILE_H;
 constexpr int kBlock = 256;
-constexpr int kMaxChunkVerts = 384;     // unique vertices per set-up chunk (LDS: 16 B each)
+constexpr int kMaxChunkVerts = 256;     // unique vertices per set-up chunk (one per lane; LDS: 24 B each per stream)
 constexpr int kStreamsPerBlock = 4;     // streams a set-up workgroup loops over per chunk
 
 struct alignas(16) TriRec {     // 64 B: one rasterisable triangle inside one tile bin

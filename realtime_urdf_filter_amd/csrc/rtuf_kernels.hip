@@ -395,115 +395,133 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
   return n;
 }
 
-// True when the chunk's bounding sphere lies completely outside one frustum plane: then all its
-// vertices carry that plane's clip bit and every triangle would be rejected by the per-triangle
-// test anyway (same result, decided once per chunk).  Margins keep the test conservative.
-__device__ __forceinline__ bool chunk_outside(const float* __restrict__ M, const Chunk& ch)
+// True when the chunk's bounding sphere lies completely outside frustum plane `plane` (0..5 =
+// +x,-x,+y,-y,near,far): then all its vertices carry that plane's clip bit and every triangle
+// would be rejected by the per-triangle test anyway (same result, decided once per chunk).
+// Margins keep the test conservative.
+__device__ __forceinline__ bool chunk_outside_plane(const float* M, const Chunk& ch, int plane)
 {
-  const float cx = ch.center[0], cy = ch.center[1], cz = ch.center[2], rad = ch.radius;
-  float c[4], n2[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    c[r] = M[r] * cx + M[4 + r] * cy + M[8 + r] * cz + M[12 + r];
-  }
-  // plane i: w -/+ coordinate >= 0; normal = row3 -/+ rowk (xyz part of the object-space plane)
-  bool out = false;
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-#pragma unroll
-    for (int sgn = 0; sgn < 2; sgn++) {
-      const float sg = sgn ? 1.0f : -1.0f;
-      const float nx = M[3] + sg * M[k], ny = M[7] + sg * M[4 + k], nz = M[11] + sg * M[8 + k];
-      const float d = c[3] + sg * c[k];
-      const float nn = sqrtf(nx * nx + ny * ny + nz * nz);
-      const float slack = rad * nn * 1.001f + 1e-5f * (fabsf(c[3]) + fabsf(c[k])) + 1e-30f;
-      if (d < -slack) out = true;
-    }
-  }
-  (void)n2;
-  return out;
+  const int k = plane >> 1;
+  const float sg = (plane & 1) ? 1.0f : -1.0f;          // plane: w + sg * coord >= 0
+  const float cx = ch.center[0], cy = ch.center[1], cz = ch.center[2];
+  const float cw = M[3] * cx + M[7] * cy + M[11] * cz + M[15];
+  const float ck = M[k] * cx + M[4 + k] * cy + M[8 + k] * cz + M[12 + k];
+  const float nx = M[3] + sg * M[k], ny = M[7] + sg * M[4 + k], nz = M[11] + sg * M[8 + k];
+  const float d = cw + sg * ck;
+  const float nn = sqrtf(nx * nx + ny * ny + nz * nz);
+  const float slack = ch.radius * nn * 1.001f + 1e-5f * (fabsf(cw) + fabsf(ck)) + 1e-30f;
+  return d < -slack;
 }
 
+// setup_kernel: one workgroup per (chunk, group of kStreamsPerBlock streams).
+//   once:        the group's matrices are fetched into LDS; one lane per (stream, frustum plane)
+//                decides whether the whole chunk is outside for that stream
+//   per stream:  phase 1  every chunk vertex once: vertex shader, clip test, viewport, 1/256-px
+//                         snap -> LDS
+//                phase 2  one lane per triangle on the snapped integers: trivial reject,
+//                         frustum-crossers to the clip list, sub-pixel cull; survivors
+//                         (typically < 20 %) are appended to an LDS work list
+//   once:        phase 3  the work list of all streams is processed by DENSE waves: full
+//                         set-up (edge functions, z plane) and binning
 __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
 {
-  __shared__ float4 s_win[2][kMaxChunkVerts];   // window x, y, z + clip mask bits (double-buffered)
+  __shared__ float4 s_win[kStreamsPerBlock][kMaxChunkVerts];   // window x, y, z + clip mask bits
+  __shared__ int2 s_snap[kStreamsPerBlock][kMaxChunkVerts];    // snapped x; snapped y << 8 | clip mask
+  __shared__ uint32_t s_packed[kBlock];                         // the chunk's triangles
+  __shared__ uint16_t s_list[kStreamsPerBlock * kBlock];        // survivors: stream k << 8 | triangle
+  __shared__ uint32_t s_nlist;
   __shared__ uint32_t s_stat[3];
-  if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
+  __shared__ float s_mvp[kStreamsPerBlock][16];
+  __shared__ uint32_t s_on[kStreamsPerBlock];
+  const int tid = threadIdx.x;
+  if (tid < 3) s_stat[tid] = 0;
+  if (tid == 3) s_nlist = 0;
   const int chunk_id = blockIdx.y;
   const int shard_id = (int)((blockIdx.x + blockIdx.y) % kCounterShards);
   CounterShard& shard = a.counters->shard[shard_id];
   const Chunk ch = a.chunks[chunk_id];
-  const int tid = threadIdx.x;
   const bool is_bg = (uint32_t)chunk_id == a.bg_chunk;
 
-  float4 pv0 = make_float4(0, 0, 0, 1), pv1 = pv0;
-  if (tid < (int)ch.vert_count) pv0 = a.cverts[ch.vert_begin + tid];
-  if (tid + kBlock < (int)ch.vert_count) pv1 = a.cverts[ch.vert_begin + tid + kBlock];
+  float4 pv = make_float4(0, 0, 0, 1);
+  const bool have_vert = tid < (int)ch.vert_count;
+  if (have_vert) pv = a.cverts[ch.vert_begin + tid];
   const bool have_tri = tid < (int)ch.tri_count;
   const uint32_t packed = have_tri ? a.ctris[ch.tri_begin + tid] : 0u;
+  s_packed[tid] = packed;
   const uint32_t i0 = packed & 1023u, i1 = (packed >> 10) & 1023u, i2 = (packed >> 20) & 1023u;
-  const uint32_t order = is_bg ? 0u : ch.order_base + (uint32_t)tid;
   const float sx = 0.5f * (float)a.width, sy = 0.5f * (float)a.height;
+  const int lane = tid & 63;
+  // all matrices of the stream group are fetched up front (one global round trip per workgroup
+  // instead of one per stream) and kept in LDS
+  if (tid < kStreamsPerBlock * 16) {
+    const int k = tid >> 4, slot = blockIdx.x * kStreamsPerBlock + k;
+    float v = 0.0f;
+    if (slot < a.group_size)
+      v = a.mvp[((size_t)(a.group_base + slot) * (a.n_draws + 1) + ch.draw) * 16 + (tid & 15)];
+    s_mvp[k][tid & 15] = v;
+  }
+  if (tid >= 64 && tid < 64 + kStreamsPerBlock) {
+    const int k = tid - 64, slot = blockIdx.x * kStreamsPerBlock + k;
+    uint32_t on = 0;
+    if (slot < a.group_size) {
+      const int stream = a.group_base + slot;
+      on = is_bg ? (a.bg_mode[stream] ? 0u : 1u) : (uint32_t)((a.model_mask[stream] >> ch.model) & 1ull);
+    }
+    s_on[k] = on;
+  }
+  __syncthreads();
+  if (tid < kStreamsPerBlock * 6) {
+    const int k = tid / 6;
+    if (s_on[k] && chunk_outside_plane(s_mvp[k], ch, tid % 6)) s_on[k] = 0;   // benign race: all writers store 0
+  }
+  __syncthreads();
 
-  uint32_t binned = 0, entries = 0, nfrag = 0;
-  int buf = 0;
   for (int k = 0; k < kStreamsPerBlock; k++) {
     const int slot = blockIdx.x * kStreamsPerBlock + k;
-    if (slot >= a.group_size) break;
-    const int stream = a.group_base + slot;
-    if (is_bg) {
-      if (a.bg_mode[stream]) continue;                   // analytic background: nothing to rasterise
-    } else if (!((a.model_mask[stream] >> ch.model) & 1ull)) {
-      continue;
-    }
-    const float* __restrict__ M = a.mvp + ((size_t)stream * (a.n_draws + 1) + ch.draw) * 16;
-    if (chunk_outside(M, ch)) continue;                  // uniform per workgroup
-    float4* win = s_win[buf];
-    buf ^= 1;
-    // phase 1: vertex shader + clip test + viewport, once per chunk vertex
-    if (tid < (int)ch.vert_count) {
+    if (!s_on[k]) continue;                              // uniform per workgroup
+    // phase 1
+    if (have_vert) {
+      float M[16];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float4 col = reinterpret_cast<const float4*>(s_mvp[k])[q];
+        M[4 * q] = col.x; M[4 * q + 1] = col.y; M[4 * q + 2] = col.z; M[4 * q + 3] = col.w;
+      }
       float c[4];
-      vs_position(M, pv0.x, pv0.y, pv0.z, c);
+      vs_position(M, pv.x, pv.y, pv.z, c);
       const Win w = viewport_vs(c, sx, sy);
-      win[tid] = make_float4(w.x, w.y, w.z, __uint_as_float(clipmask_of(c)));
+      const unsigned cm = clipmask_of(c);
+      s_win[k][tid] = make_float4(w.x, w.y, w.z, __uint_as_float(cm));
+      s_snap[k][tid] = make_int2(snap(w.x), (int)(((unsigned)snap(w.y) << 8) | cm));
     }
-    if (tid + kBlock < (int)ch.vert_count) {
-      float c[4];
-      vs_position(M, pv1.x, pv1.y, pv1.z, c);
-      const Win w = viewport_vs(c, sx, sy);
-      win[tid + kBlock] = make_float4(w.x, w.y, w.z, __uint_as_float(clipmask_of(c)));
-    }
-    // one barrier per stream: the buffer written two iterations ago was last read before the
-    // previous iteration's barrier
     __syncthreads();
-    // phase 2: one lane per triangle
-    bool have = false, needs_clip = false;
-    TriRec r;
+    // phase 2
+    bool survive = false, needs_clip = false;
     if (have_tri) {
-      const float4 w0 = win[i0], w1 = win[i1], w2 = win[i2];
-      const unsigned m0 = __float_as_uint(w0.w), m1 = __float_as_uint(w1.w), m2 = __float_as_uint(w2.w);
+      const int2 p0 = s_snap[k][i0], p1 = s_snap[k][i1], p2 = s_snap[k][i2];
+      const unsigned m0 = (unsigned)p0.y & 63u, m1 = (unsigned)p1.y & 63u, m2 = (unsigned)p2.y & 63u;
       if ((m0 & m1 & m2) == 0) {
         if ((m0 | m1 | m2) != 0) {
           needs_clip = true;
         } else {
-          Win v0, v1, v2;
-          v0.x = w0.x; v0.y = w0.y; v0.z = w0.z;
-          v1.x = w1.x; v1.y = w1.y; v1.z = w1.z;
-          v2.x = w2.x; v2.y = w2.y; v2.z = w2.z;
-          have = make_record(v0, v1, v2, order, a.width, a.height, r);
+          const int y0 = p0.y >> 8, y1 = p1.y >> 8, y2 = p2.y >> 8;
+          const int minx = min(p0.x, min(p1.x, p2.x)), maxx = max(p0.x, max(p1.x, p2.x));
+          const int miny = min(y0, min(y1, y2)), maxy = max(y0, max(y1, y2));
+          const int bx0 = max((minx + 255) >> 8, 0), bx1 = min((maxx - 1) >> 8, a.width - 1);
+          const int by0 = max((miny + 255) >> 8, 0), by1 = min((maxy - 1) >> 8, a.height - 1);
+          survive = bx1 >= bx0 && by1 >= by0;
         }
       }
     }
     // triangles that cross a frustum plane go to clip_kernel: one list append per wave
-    const unsigned long long cm = __ballot(needs_clip);
-    if (cm) {
-      const int lane = tid & 63;
-      const int leader = __ffsll((long long)cm) - 1;
+    const unsigned long long cmk = __ballot(needs_clip);
+    if (cmk) {
+      const int leader = __ffsll((long long)cmk) - 1;
       uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(&shard.clip_count, (uint32_t)__popcll(cm));
+      if (lane == leader) base = atomicAdd(&shard.clip_count, (uint32_t)__popcll(cmk));
       base = __shfl(base, leader);
       if (needs_clip) {
-        const uint32_t kk = base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+        const uint32_t kk = base + (uint32_t)__popcll(cmk & ((1ull << lane) - 1ull));
         if (kk < a.clip_capacity) {
           ClipItem it; it.slot = (uint32_t)slot; it.chunk = (uint32_t)chunk_id; it.tri = (uint32_t)tid; it.pad = 0;
           a.clip_list[(size_t)shard_id * a.clip_capacity + kk] = it;
@@ -512,10 +530,39 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
         }
       }
     }
+    const unsigned long long sm = __ballot(survive);
+    if (sm) {
+      const int leader = __ffsll((long long)sm) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&s_nlist, (uint32_t)__popcll(sm));
+      base = __shfl(base, leader);
+      if (survive) s_list[base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = (uint16_t)((k << 8) | tid);
+    }
+  }
+  __syncthreads();
+  // phase 3: dense set-up + binning of the survivors of all streams
+  const uint32_t nlist = s_nlist;
+  uint32_t binned = 0, entries = 0, nfrag = 0;
+  for (uint32_t base = 0; base < nlist; base += kBlock) {
+    const uint32_t j = base + tid;
+    bool have = false;
+    TriRec r;
+    int slot = 0;
+    if (j < nlist) {
+      const uint32_t e = s_list[j];
+      const int k = (int)(e >> 8), t = (int)(e & 255u);
+      slot = blockIdx.x * kStreamsPerBlock + k;
+      const uint32_t p = s_packed[t];
+      const float4 w0 = s_win[k][p & 1023u], w1 = s_win[k][(p >> 10) & 1023u], w2 = s_win[k][(p >> 20) & 1023u];
+      Win v0, v1, v2;
+      v0.x = w0.x; v0.y = w0.y; v0.z = w0.z;
+      v1.x = w1.x; v1.y = w1.y; v1.z = w1.z;
+      v2.x = w2.x; v2.y = w2.y; v2.z = w2.z;
+      have = make_record(v0, v1, v2, is_bg ? 0u : ch.order_base + (uint32_t)t, a.width, a.height, r);
+    }
     if (__ballot(have)) {
-      // Tiny triangles (bounding box <= 2x2 pixel centres, the bulk of a dense mesh) are resolved
-      // to their covered pixels right here and binned as 16-byte fragments; everything else is
-      // binned as a 64-byte triangle record.
+      // Tiny triangles (bounding box <= 2x2 pixel centres) are resolved to their covered pixels
+      // right here and binned as 16-byte fragments; everything else as a 64-byte triangle record.
       const int bx0 = (int)(r.bbx & 0xffff), bx1 = (int)(r.bbx >> 16);
       const int by0 = (int)(r.bby & 0xffff), by1 = (int)(r.bby >> 16);
       const bool tiny = have && (bx1 - bx0) <= 1 && (by1 - by0) <= 1;
@@ -524,10 +571,10 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
       binned += have ? 1u : 0u;
     }
   }
-  // statistics: one (sharded) atomic pair per workgroup
+  // statistics: one (sharded) atomic triple per workgroup
   uint32_t b = binned, e = entries, f = nfrag;
   for (int off = 32; off > 0; off >>= 1) { b += __shfl_down(b, off); e += __shfl_down(e, off); f += __shfl_down(f, off); }
-  if ((tid & 63) == 0 && b) {
+  if (lane == 0 && b) {
     atomicAdd(&s_stat[0], b);
     atomicAdd(&s_stat[1], e);
     atomicAdd(&s_stat[2], f);
