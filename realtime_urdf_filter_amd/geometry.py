@@ -67,8 +67,18 @@ def box_draws(dimx, dimy, dimz):
         [-X, Y, Z], [-X, Y, -Z], [-X, -Y, -Z], [-X, -Y, Z],      # left
         [X, Y, -Z], [X, Y, Z], [X, -Y, Z], [X, -Y, -Z]], np.float32)
     first = DrawCall(v, quads_to_tris(6))
-    # glutSolidCube(dimx): size = dSize * 0.5 in double, glVertex3d -> float
-    s = float(dx) * 0.5
+    second = prims_to_draw(cube_prims(dx), OP_SCALE, (dx, dy, dz))
+    return [first, second]
+
+
+def box_vbo_vertices(dimx, dimy, dimz):
+    """The 24 float32 vertices of RenderableBox::createBoxVBO (drawn as GL_QUADS)."""
+    return box_draws(dimx, dimy, dimz)[0].verts
+
+
+def cube_prims(size):
+    """glutSolidCube(size), freeglut 2.8 [recall]: size = dSize * 0.5 in double, one GL_QUADS block."""
+    s = float(np.float32(size)) * 0.5
     P, N = s, -s
     c = np.array([
         [P, N, P], [P, N, N], [P, P, N], [P, P, P],
@@ -76,9 +86,8 @@ def box_draws(dimx, dimy, dimz):
         [P, P, P], [N, P, P], [N, N, P], [P, N, P],
         [N, N, P], [N, P, P], [N, P, N], [N, N, N],
         [N, N, P], [N, N, N], [P, N, N], [P, N, P],
-        [N, N, N], [N, P, N], [P, P, N], [P, N, N]], np.float64).astype(np.float32)
-    second = DrawCall(c, quads_to_tris(6), OP_SCALE, (dx, dy, dz))
-    return [first, second]
+        [N, N, N], [N, P, N], [P, P, N], [P, N, N]], np.float64)
+    return [(GL_QUADS, c)]
 
 
 def _circle_table(n):
@@ -95,67 +104,96 @@ def _circle_table(n):
     return sint, cost
 
 
-def sphere_draws(radius, slices=10, stacks=10):
-    """glutSolidSphere(radius, slices, stacks), freeglut 2.8 [recall]."""
+GL_TRIANGLE_FAN, GL_QUADS, GL_QUAD_STRIP = 6, 7, 8
+
+
+def prims_to_draw(prims, pre_op=OP_NONE, op=(0.0, 0.0, 0.0)):
+    """[(gl_mode, verts f64 [N,3]), ...] (glBegin/glVertex3d/glEnd blocks) -> one DrawCall with the
+    triangles in the order the GL driver assembles them; glVertex3d rounds to float32."""
+    verts, tris = [], []
+    for mode, v in prims:
+        base = len(verts)
+        verts += [tuple(x) for x in np.asarray(v, np.float64)]
+        n = len(v)
+        if mode == GL_TRIANGLE_FAN:
+            tris += fan_to_tris(n, base)
+        elif mode == GL_QUAD_STRIP:
+            tris += quad_strip_to_tris(n, base)
+        elif mode == GL_QUADS:
+            tris += quads_to_tris(n // 4, base)
+        else:
+            raise ValueError("unsupported GL mode %r" % mode)
+    return DrawCall(np.asarray(verts, np.float64).astype(np.float32), tris, pre_op, op)
+
+
+def sphere_prims(radius, slices=10, stacks=10):
+    """glutSolidSphere(radius, slices, stacks), freeglut 2.8 [recall]: the glBegin/glEnd blocks."""
     radius = float(np.float32(radius))
     sint1, cost1 = _circle_table(-slices)
     sint2, cost2 = _circle_table(stacks * 2)
-    verts, tris = [], []
+    prims = []
     z1, r1 = cost2[1 if stacks > 0 else 0], sint2[1 if stacks > 0 else 0]
-    base = len(verts)
-    verts.append((0.0, 0.0, radius))
+    v = [(0.0, 0.0, radius)]
     for j in range(slices, -1, -1):
-        verts.append((cost1[j] * r1 * radius, sint1[j] * r1 * radius, z1 * radius))
-    tris += fan_to_tris(len(verts) - base, base)
+        v.append((cost1[j] * r1 * radius, sint1[j] * r1 * radius, z1 * radius))
+    prims.append((GL_TRIANGLE_FAN, np.asarray(v, np.float64)))
     z0, r0 = z1, r1
     for i in range(1, stacks - 1):
         z0, z1 = z1, cost2[i + 1]
         r0, r1 = r1, sint2[i + 1]
-        base = len(verts)
+        v = []
         for j in range(slices + 1):
-            verts.append((cost1[j] * r1 * radius, sint1[j] * r1 * radius, z1 * radius))
-            verts.append((cost1[j] * r0 * radius, sint1[j] * r0 * radius, z0 * radius))
-        tris += quad_strip_to_tris(len(verts) - base, base)
+            v.append((cost1[j] * r1 * radius, sint1[j] * r1 * radius, z1 * radius))
+            v.append((cost1[j] * r0 * radius, sint1[j] * r0 * radius, z0 * radius))
+        prims.append((GL_QUAD_STRIP, np.asarray(v, np.float64)))
     z0, r0 = z1, r1
-    base = len(verts)
-    verts.append((0.0, 0.0, -radius))
+    v = [(0.0, 0.0, -radius)]
     for j in range(slices + 1):
-        verts.append((cost1[j] * r0 * radius, sint1[j] * r0 * radius, z0 * radius))
-    tris += fan_to_tris(len(verts) - base, base)
-    return [DrawCall(np.asarray(verts, np.float64).astype(np.float32), tris)]
+        v.append((cost1[j] * r0 * radius, sint1[j] * r0 * radius, z0 * radius))
+    prims.append((GL_TRIANGLE_FAN, np.asarray(v, np.float64)))
+    return prims
 
 
-def cylinder_draws(radius, length, slices=10, stacks=10):
-    """glTranslatef(0,0,-length/2); glutSolidCylinder(radius, length, slices, stacks) [recall]."""
+def sphere_draws(radius, slices=10, stacks=10):
+    return [prims_to_draw(sphere_prims(radius, slices, stacks))]
+
+
+def cylinder_prims(radius, length, slices=10, stacks=10):
+    """glutSolidCylinder(radius, length, slices, stacks), freeglut 2.8 [recall]."""
     radius = float(np.float32(radius))
-    length32 = np.float32(length)
-    height = float(length32)
+    height = float(np.float32(length))
     sint, cost = _circle_table(-slices)
     zstep = height / (stacks if stacks > 0 else 1)
-    verts, tris = [], []
-    base = len(verts)
-    verts.append((0.0, 0.0, 0.0))
+    prims = []
+    v = [(0.0, 0.0, 0.0)]
     for j in range(slices + 1):
-        verts.append((cost[j] * radius, sint[j] * radius, 0.0))
-    tris += fan_to_tris(len(verts) - base, base)
-    base = len(verts)
-    verts.append((0.0, 0.0, height))
+        v.append((cost[j] * radius, sint[j] * radius, 0.0))
+    prims.append((GL_TRIANGLE_FAN, np.asarray(v, np.float64)))
+    v = [(0.0, 0.0, height)]
     for j in range(slices, -1, -1):
-        verts.append((cost[j] * radius, sint[j] * radius, height))
-    tris += fan_to_tris(len(verts) - base, base)
+        v.append((cost[j] * radius, sint[j] * radius, height))
+    prims.append((GL_TRIANGLE_FAN, np.asarray(v, np.float64)))
     z0, z1 = 0.0, zstep
     for i in range(1, stacks + 1):
         if i == stacks:
             z1 = height
-        base = len(verts)
+        v = []
         for j in range(slices + 1):
-            verts.append((cost[j] * radius, sint[j] * radius, z0))
-            verts.append((cost[j] * radius, sint[j] * radius, z1))
-        tris += quad_strip_to_tris(len(verts) - base, base)
+            v.append((cost[j] * radius, sint[j] * radius, z0))
+            v.append((cost[j] * radius, sint[j] * radius, z1))
+        prims.append((GL_QUAD_STRIP, np.asarray(v, np.float64)))
         z0 = z1
         z1 += zstep
-    tz = -length32 / np.float32(2)     # `-length/2` evaluated in float like the reference
-    return [DrawCall(np.asarray(verts, np.float64).astype(np.float32), tris, OP_TRANSLATE, (0.0, 0.0, tz))]
+    return prims
+
+
+def cylinder_translate(length):
+    """The glTranslatef(0, 0, -length/2) of RenderableCylinder::render, evaluated in float."""
+    return (0.0, 0.0, float(-np.float32(length) / np.float32(2)))
+
+
+def cylinder_draws(radius, length, slices=10, stacks=10):
+    return [prims_to_draw(cylinder_prims(radius, length, slices, stacks), OP_TRANSLATE, cylinder_translate(length))]
 
 
 def mesh_draws(verts, tris, sx=1.0, sy=1.0, sz=1.0):

@@ -1,0 +1,72 @@
+"""CPU: the C-ABI library loads and exports every symbol include/rtuf.h declares; without a GPU
+it refuses to create a context (there is no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import realtime_urdf_filter_amd as R
+from realtime_urdf_filter_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rtuf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtuf_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = R.load_library()
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), "librtuf.so does not export %s" % s
+    assert set(_capi.SYMBOLS) == set(syms), "python binding list out of date: %r" % (set(_capi.SYMBOLS) ^ set(syms))
+
+
+def test_abi_version_and_struct_sizes():
+    lib = R.load_library()
+    assert lib.rtuf_abi_version() == 1
+    assert ctypes.sizeof(_capi.Params) == 48
+    p = R.default_params()
+    assert abs(p.near_plane - 0.1) < 1e-7 and p.far_plane == 8.0 and abs(p.depth_distance_threshold - 0.05) < 1e-7
+    assert p.filter_replace_value == 0.0 and p.flags == R.FLAG_BACKGROUND_QUAD
+
+
+def test_projection_from_intrinsics_matches_reference_formula():
+    P, tx, ty = R.projection_from_intrinsics(525.0, 526.0, 319.5, 239.5, 640, 480, 0.1, 8.0, Tx=-39.4, Ty=0.0)
+    assert P[0] == -2.0 * 525.0 / 640 and P[5] == 2.0 * 526.0 / 480
+    assert P[8] == 2.0 * (0.5 - 319.5 / 640) and P[9] == 2.0 * (239.5 / 480 - 0.5)
+    assert P[10] == -(8.0 + 0.1) / (8.0 - 0.1) and P[14] == -2.0 * 8.0 * 0.1 / (8.0 - 0.1) and P[11] == -1
+    assert tx == -1 * (-39.4 / 525.0) and ty == 0.0
+    assert all(P[i] == 0 for i in (1, 2, 3, 4, 6, 7, 12, 13, 15))
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful on a machine without a GPU")
+def test_no_cpu_fallback():
+    with pytest.raises(R.RtufError) as e:
+        R.Context(64, 48)
+    assert e.value.code == _capi.RTUF_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under realtime_urdf_filter_amd/ may import it."""
+    pkg = os.path.join(ROOT, "realtime_urdf_filter_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", ".sh")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "oracle" not in txt.replace("the oracle", "").replace("oracle/", "").lower() or "import oracle" not in txt, f
+                assert "from oracle" not in txt and "import oracle" not in txt and "librtuf_oracle" not in txt, f

@@ -1,0 +1,152 @@
+"""CPU: host-side logic above the C ABI -- URDF reader, tf-style algebra, forward kinematics,
+primitive tessellation, STL reader, 16UC1 conversions, synthetic workloads, sharding."""
+import math
+
+import numpy as np
+import pytest
+
+from realtime_urdf_filter_amd import geometry as G
+from realtime_urdf_filter_amd import sharding, synthetic, urdf, workloads
+from realtime_urdf_filter_amd.filter import (URDFRenderer, depth_f32_to_u16, depth_u16_to_f32, RenderableBox)
+
+
+def test_example_urdf_links_and_q1_boxes():
+    m = urdf.Model.from_string(workloads.EXAMPLE_URDF)
+    assert [l.name for l in m.get_links()] == ["wall1", "wall2", "world"]      # std::map order
+    assert m.root_link() == "world"
+    fk = urdf.forward_kinematics(m)
+    assert np.allclose(fk["wall1"].origin, [0, 5, 0])
+    c, s = math.cos(0.785398163), math.sin(0.785398163)
+    assert np.allclose(fk["wall1"].basis, [[c, -s, 0], [s, c, 0], [0, 0, 1]], atol=1e-12)
+    rd = URDFRenderer(workloads.EXAMPLE_URDF, "/EXAMPLE", "cam", "/world", urdf.StaticTransformProvider(), "visual", 1.0, [])
+    assert len(rd.renderables_) == 2 and all(isinstance(r, RenderableBox) for r in rd.renderables_)
+    assert rd.renderables_[0].name == "/EXAMPLE/wall1"
+    d = rd.renderables_[0].draws
+    assert len(d) == 2 and d[0].pre_op == 0 and d[1].pre_op == 1 and d[1].op == (4.0, 0.5, 2.0)
+    # second box (quirk Q1): glutSolidCube(dimx) scaled by the dims -> extents dimx^2, dimx*dimy, dimx*dimz
+    ext = np.abs(d[1].verts).max(0) * 2 * np.array(d[1].op)
+    assert np.allclose(ext, [16.0, 2.0, 8.0])
+    assert np.allclose(np.abs(d[0].verts).max(0) * 2, [4.0, 0.5, 2.0])
+
+
+def test_geometry_type_scale_and_ignore():
+    xml = workloads.EXAMPLE_URDF
+    tf = urdf.StaticTransformProvider()
+    assert len(URDFRenderer(xml, "", "c", "w", tf, "collision", 1.0, []).renderables_) == 2
+    assert len(URDFRenderer(xml, "", "c", "w", tf, "visual", 1.0, ["wall1"]).renderables_) == 1
+    r = URDFRenderer(xml, "", "c", "w", tf, "visual", 0.5, []).renderables_[0]
+    assert (r.dimx, r.dimy, r.dimz) == (2.0, 0.25, 1.0)
+    assert len(URDFRenderer(xml, "", "c", "w", tf, "bogus", 1.0, []).renderables_) == 0
+
+
+def test_primitive_triangle_counts():
+    assert [len(d.tris) for d in G.box_draws(1, 2, 3)] == [12, 12]
+    assert len(G.sphere_draws(0.5)[0].tris) == 180
+    assert len(G.cylinder_draws(0.5, 1.0)[0].tris) == 220
+    cyl = G.cylinder_draws(0.5, 1.0)[0]
+    assert cyl.pre_op == 2 and cyl.op == (0.0, 0.0, -0.5)
+    v = G.sphere_draws(0.5)[0].verts
+    assert np.allclose(np.linalg.norm(v, axis=1), 0.5, atol=1e-6)
+
+
+def test_quad_and_strip_decomposition_order():
+    assert G.quads_to_tris(1) == [(0, 1, 3), (1, 2, 3)]
+    assert G.fan_to_tris(5) == [(0, 1, 2), (0, 2, 3), (0, 3, 4)]
+    assert G.quad_strip_to_tris(6) == [(0, 1, 3), (2, 0, 3), (2, 3, 5), (4, 2, 5)]
+
+
+def test_transform_algebra_matches_matrix_form():
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        q = rng.normal(size=4)
+        a = urdf.Transform.from_quaternion(q, rng.normal(size=3))
+        b = urdf.Transform.from_quaternion(rng.normal(size=4), rng.normal(size=3))
+        assert np.allclose(a.basis @ a.basis.T, np.eye(3), atol=1e-12)
+        ab = a * b
+        p = rng.normal(size=3)
+        assert np.allclose(ab * p, a * (b * p))
+        ident = a * a.inverse()
+        assert np.allclose(ident.basis, np.eye(3), atol=1e-12) and np.allclose(ident.origin, 0, atol=1e-12)
+        q2 = a.get_rotation()
+        a2 = urdf.Transform.from_quaternion(q2)
+        assert np.allclose(a2.basis, a.basis, atol=1e-12)
+        m = a.opengl_matrix().reshape(4, 4).T
+        assert np.allclose(m[:3, :3], a.basis) and np.allclose(m[:3, 3], a.origin) and np.allclose(m[3], [0, 0, 0, 1])
+
+
+def test_rpy_convention():
+    t = urdf.pose_to_transform((1, 2, 3), (0, 0, math.pi / 2))
+    assert np.allclose(t * np.array([1.0, 0, 0]), [1, 3, 3])
+    t = urdf.pose_to_transform((0, 0, 0), (math.pi / 2, 0, 0))
+    assert np.allclose(t * np.array([0.0, 1, 0]), [0, 0, 1])
+
+
+def test_forward_kinematics_joint_types():
+    xml = """<robot name="r"><link name="a"/><link name="b"/><link name="c"/><link name="d"/>
+      <joint name="j1" type="revolute"><origin xyz="1 0 0"/><parent link="a"/><child link="b"/><axis xyz="0 0 1"/><limit lower="-1" upper="1"/></joint>
+      <joint name="j2" type="prismatic"><origin xyz="0 1 0"/><parent link="b"/><child link="c"/><axis xyz="1 0 0"/><limit lower="0" upper="1"/></joint>
+      <joint name="j3" type="fixed"><origin xyz="0 0 1" rpy="0 0 1.5707963267948966"/><parent link="c"/><child link="d"/></joint></robot>"""
+    m = urdf.Model.from_string(xml)
+    fk = urdf.forward_kinematics(m, {"j1": math.pi / 2, "j2": 0.5})
+    assert np.allclose(fk["b"].origin, [1, 0, 0])
+    assert np.allclose(fk["c"].origin, [0, 0.5, 0])
+    assert np.allclose(fk["d"].origin, [0.0, 0.5, 1.0])
+    tf = urdf.StaticTransformProvider(fk)
+    assert np.allclose(tf.lookup_transform("a", "d").origin, fk["d"].origin)
+    with pytest.raises(KeyError):
+        tf.lookup_transform("a", "nope")
+
+
+def test_update_link_transforms_reuses_stale_transform_on_failure():
+    """Quirk Q7 (src/urdf_renderer.cpp:173-190)."""
+    tf = urdf.StaticTransformProvider({"/world": urdf.Transform(), "/P/wall1": urdf.Transform(None, (1, 2, 3))})
+    rd = URDFRenderer(workloads.EXAMPLE_URDF, "/P", "cam", "/world", tf, "visual", 1.0, [])
+    rd.update_link_transforms()
+    assert np.allclose(rd.renderables_[0].link_to_fixed.origin, [1, 2, 3])
+    assert np.allclose(rd.renderables_[1].link_to_fixed.origin, [1, 2, 3])      # wall2 lookup failed
+
+
+def test_depth_conversions_16uc1():
+    u = np.array([[0, 1, 999, 1000, 4500, 65535]], np.uint16)
+    f = depth_u16_to_f32(u)
+    assert f.dtype == np.float32 and f[0, 3] == np.float32(1000) * np.float32(0.001)
+    back = depth_f32_to_u16(np.array([[0.0005, 0.0015, 0.0025, 5.0, np.nan, np.inf, -1.0, 70.0]], np.float32))
+    assert list(back[0]) == [0, 2, 2, 5000, 0, 65535, 0, 65535]         # half-to-even, saturate, NaN -> 0
+
+
+def test_stl_roundtrip_and_solid_header_quirk():
+    v, t = synthetic.lumpy_ellipsoid(100, (0.1, 0.2, 0.3), 3)
+    data = G.write_binary_stl(v, t, header=b"solid looks like ascii but is binary")
+    v2, t2 = G.load_stl(data)
+    assert len(t2) == len(t) and np.array_equal(v2[t2.reshape(-1)], v[t.reshape(-1)])
+    ascii_stl = b"solid x\nfacet normal 0 0 1\nouter loop\nvertex 0 0 0\nvertex 1 0 0\nvertex 0 1 0\nendloop\nendfacet\nendsolid x\n"
+    v3, t3 = G.load_stl(ascii_stl)
+    assert v3.shape == (3, 3) and t3.tolist() == [[0, 1, 2]]
+    with pytest.raises(ValueError):
+        G.load_stl(b"garbage")
+
+
+def test_synthetic_is_deterministic():
+    a = synthetic.SplitMix64(42)
+    b = synthetic.SplitMix64(42)
+    assert [a.next_u64() for _ in range(4)] == [b.next_u64() for _ in range(4)]
+    assert synthetic.SplitMix64(0).next_u64() == 0xE220A8397B1DCDAF            # published splitmix64 vector
+    d0, d1 = synthetic.sensor_depth(64, 48, 3), synthetic.sensor_depth(64, 48, 3)
+    assert np.array_equal(d0.view(np.uint32), d1.view(np.uint32))
+    assert np.isnan(synthetic.sensor_depth(640, 480, 0)).sum() > 1000
+    w1 = workloads.pr2_workload(2, 160, 120, total_triangles=3000)
+    w2 = workloads.pr2_workload(2, 160, 120, total_triangles=3000)
+    assert np.array_equal(w1.link_tf[0], w2.link_tf[0]) and np.array_equal(w1.cam_tf, w2.cam_tf)
+    assert w1.meta["links_with_geometry"] == 51 and 2500 < w1.n_triangles() < 3600
+
+
+def test_sharding_partitions_streams():
+    for n, w in ((256, 8), (513, 8), (7, 3), (2, 4)):
+        seen = []
+        for r in range(w):
+            first, cnt = sharding.shard_range(n, w, r)
+            seen += list(range(first, first + cnt))
+        assert seen == list(range(n))
+    assert sharding.models_for_rank(64, 8, 3) == [3, 11, 19, 27, 35, 43, 51, 59]
+    with pytest.raises(ValueError):
+        sharding.shard_range(4, 2, 2)

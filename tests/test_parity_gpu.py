@@ -1,0 +1,291 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against (1) the committed golden fixtures
+(outputs of the reference's GLSL on llvmpipe) and (2) the CPU oracle on seeded inputs.
+Bar: bit-exact masks and bit-exact float depth (north_star tolerance for depth is 1e-4; the
+implementation is exact, so the tests demand equality)."""
+import numpy as np
+import pytest
+
+import golden_io
+import scenes as S
+import realtime_urdf_filter_amd as R
+from realtime_urdf_filter_amd import workloads as WL
+from realtime_urdf_filter_amd import _capi, urdf
+from realtime_urdf_filter_amd.filter import CameraInfo, FilterParameters, RealtimeURDFFilter, depth_f32_to_u16, depth_u16_to_f32
+from oracle import bindings as O
+
+pytestmark = pytest.mark.gpu
+
+
+def params(replace=5.0, max_diff=0.05, two_kernel=False, **kw):
+    p = R.default_params()
+    p.filter_replace_value = replace
+    p.depth_distance_threshold = max_diff
+    if two_kernel:
+        p.flags |= R.FLAG_TWO_KERNEL
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a, np.float32).view(np.uint32), np.ascontiguousarray(b, np.float32).view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("two_kernel", [False, True])
+@pytest.mark.parametrize("name", golden_io.fixture_names())
+def test_golden_fixture(name, two_kernel):
+    fx = golden_io.Fixture(name)
+    ctx = R.Context(fx.width, fx.height, 1, 0, params(fx.replace_value, fx.max_diff, two_kernel))
+    m, tfs = fx.load_into(ctx)
+    ctx.set_camera(0, fx.projection, fx.offset_inv, fx.cam_tf)
+    if len(tfs):
+        ctx.set_link_poses(0, m, tfs)
+    masked, mask = ctx.filter_batch(fx.depth[None])
+    fx.check(masked[0], mask[0])
+    ctx.close()
+
+
+def run_soups(W, H, n_streams, seed, two_kernel=False, **pkw):
+    rng = np.random.default_rng(seed)
+    P = S.projection(525.0 * W / 640, 525.0 * W / 640, (W - 1) / 2, (H - 1) / 2, W, H)
+    geo = S.soup_geometry(rng, n_links=7, tris_per_link=50)
+    ctx = R.Context(W, H, n_streams, 0, params(5.0, 0.05, two_kernel, **pkw))
+    m = ctx.add_model()
+    for pre, op, v, t in geo:
+        l = ctx.add_link(m)
+        ctx.add_draw(m, l, v, t, pre, op)
+    ctx.finalize_models()
+    depth = np.stack([S.sensor_depth(W, H, 0.3 * s + seed) for s in range(n_streams)])
+    per = []
+    for s in range(n_streams):
+        tfs = S.random_link_poses(rng, len(geo), near=(s % 3 == 1), far=(s % 3 == 2))
+        offinv, camtf = S.random_camera(rng, small=bool(s & 1))
+        ctx.set_camera(s, P, offinv, camtf)
+        ctx.set_link_poses(s, m, np.stack(tfs))
+        per.append((tfs, offinv, camtf))
+    return ctx, P, geo, depth, per
+
+
+def check_vs_oracle(masked, mask, P, geo, depth, per, want_mask=True):
+    for s, (tfs, offinv, camtf) in enumerate(per):
+        draws = [(tfs[i],) + geo[i] for i in range(len(geo))]
+        om, ok = O.filter_frame(depth[s], P, draws, offinv, camtf, replace_value=5.0)
+        if want_mask:
+            assert (ok != mask[s]).sum() == 0, "stream %d mask differs" % s
+        assert bits_equal(om, masked[s]), "stream %d depth differs" % s
+
+
+@pytest.mark.parametrize("two_kernel", [False, True])
+@pytest.mark.parametrize("size", [(640, 480), (150, 100), (1280, 720)])
+def test_random_scenes_batch(size, two_kernel):
+    ctx, P, geo, depth, per = run_soups(size[0], size[1], 4, seed=size[0] + int(two_kernel), two_kernel=two_kernel)
+    masked, mask = ctx.filter_batch(depth)
+    check_vs_oracle(masked, mask, P, geo, depth, per)
+    st = ctx.stats()
+    assert st["triangles_submitted"] == 4 * 350 and st["triangles_clipped"] > 0
+    ctx.close()
+
+
+def test_need_mask_false():
+    ctx, P, geo, depth, per = run_soups(320, 240, 2, seed=5)
+    masked, mask = ctx.filter_batch(depth, want_mask=False)
+    assert mask is None
+    check_vs_oracle(masked, None, P, geo, depth, per, want_mask=False)
+    ctx.close()
+
+
+def test_bin_regrowth_and_inflight_groups():
+    """Tiny bins + 2 streams per in-flight group: the batch overflows, is re-run with larger bins and
+    still comes out exact."""
+    ctx, P, geo, depth, per = run_soups(320, 240, 5, seed=9, bin_capacity=8, max_inflight_streams=2)
+    masked, mask = ctx.filter_batch(depth)
+    check_vs_oracle(masked, mask, P, geo, depth, per)
+    st = ctx.stats()
+    assert st["regrowths"] >= 1 and st["bin_capacity"] > 8
+    masked2, mask2 = ctx.filter_batch(depth)        # second batch: no further regrowth, same answer
+    assert bits_equal(masked, masked2) and np.array_equal(mask, mask2)
+    ctx.close()
+
+
+def test_pr2_like_workload_streams():
+    wl = WL.pr2_workload(6, 640, 480, total_triangles=20000)
+    ctx = R.Context(640, 480, 6, 0, params(wl.replace_value, wl.max_diff))
+    ids = wl.load_into(ctx)
+    wl.stage(ctx, ids)
+    depth = wl.depth_batch()
+    masked, mask = ctx.filter_batch(depth)
+    for s in range(6):
+        om, ok = O.filter_frame(depth[s], wl.projection[s], wl.oracle_draws(s), wl.offset_inv[s], wl.cam_tf[s],
+                                max_diff=wl.max_diff, replace_value=wl.replace_value)
+        assert (ok != mask[s]).sum() == 0 and bits_equal(om, masked[s])
+    st = ctx.stats()
+    assert st["fragments_binned"] > 0 and st["bin_entries"] > 0
+    ctx.close()
+
+
+def test_stream_model_selection():
+    """Two models in one context; streams render different subsets (BASELINE config 5 layout)."""
+    W, H = 320, 240
+    rng = np.random.default_rng(77)
+    P = S.projection(262.5, 262.5, 159.5, 119.5, W, H)
+    geos = [S.soup_geometry(rng, 3, 40), S.soup_geometry(rng, 4, 30)]
+    ctx = R.Context(W, H, 3, 0, params())
+    mids = []
+    for geo in geos:
+        m = ctx.add_model()
+        for pre, op, v, t in geo:
+            l = ctx.add_link(m)
+            ctx.add_draw(m, l, v, t, pre, op)
+        mids.append(m)
+    ctx.finalize_models()
+    subsets = [[0], [1], [0, 1]]
+    depth = np.stack([S.sensor_depth(W, H, s) for s in range(3)])
+    tfs = [[S.random_link_poses(rng, len(g)) for g in geos] for _ in range(3)]
+    for s in range(3):
+        ctx.set_camera(s, P, None, None)
+        ctx.set_stream_models(s, [mids[k] for k in subsets[s]])
+        for k in range(2):
+            ctx.set_link_poses(s, mids[k], np.stack(tfs[s][k]))
+    masked, mask = ctx.filter_batch(depth)
+    for s in range(3):
+        draws = []
+        for k in subsets[s]:
+            draws += [(tfs[s][k][i],) + geos[k][i] for i in range(len(geos[k]))]
+        om, ok = O.filter_frame(depth[s], P, draws, replace_value=5.0)
+        assert (ok != mask[s]).sum() == 0 and bits_equal(om, masked[s])
+    ctx.close()
+
+
+def test_general_projection_draws_background_as_geometry():
+    """A projection whose background quad is not a constant full-screen plane (here: sheared z)
+    takes the geometry path for the quad; results still match the oracle."""
+    W, H = 320, 240
+    P = S.projection(262.5, 262.5, 159.5, 119.5, W, H)
+    P[2] = 0.02           # clip z picks up a little camera x: the quad's window z now varies
+    rng = np.random.default_rng(3)
+    geo = S.soup_geometry(rng, 3, 30)
+    ctx = R.Context(W, H, 1, 0, params())
+    m = ctx.add_model()
+    for pre, op, v, t in geo:
+        l = ctx.add_link(m)
+        ctx.add_draw(m, l, v, t, pre, op)
+    ctx.finalize_models()
+    tfs = S.random_link_poses(rng, 3)
+    ctx.set_camera(0, P, None, None)
+    ctx.set_link_poses(0, m, np.stack(tfs))
+    depth = S.sensor_depth(W, H, 0.5)[None]
+    masked, mask = ctx.filter_batch(depth)
+    om, ok = O.filter_frame(depth[0], P, [(tfs[i],) + geo[i] for i in range(3)], replace_value=5.0)
+    assert (ok != mask[0]).sum() == 0 and bits_equal(om, masked[0])
+    ctx.close()
+
+
+def test_single_stream_filter_api_and_errors():
+    fx = golden_io.Fixture("soup_seed11_160x120")
+    ctx = R.Context(fx.width, fx.height, 1, 0, params(fx.replace_value, fx.max_diff))
+    with pytest.raises(R.RtufError) as e:
+        ctx.set_camera(0, fx.projection, None, None)
+    assert e.value.code == -6                      # RTUF_ERR_STATE: models not finalised
+    m, tfs = fx.load_into(ctx)
+    ctx.set_camera(0, None, fx.offset_inv, fx.cam_tf)
+    ctx.set_link_poses(0, m, tfs)
+    masked, mask = ctx.filter(fx.depth, fx.projection)     # filter(buffer, glTf, w, h) + getMaskedDepth()
+    fx.check(masked, mask)
+    with pytest.raises(R.RtufError):
+        ctx.set_link_poses(0, m, tfs[:-1])
+    with pytest.raises(R.RtufError):
+        ctx.add_model()                            # already finalised
+    with pytest.raises(R.RtufError):
+        ctx.set_camera(5, fx.projection, None, None)
+    lib = R.load_library()
+    assert lib.rtuf_filter(ctx._h, fx.depth.ctypes.data, None, fx.width + 1, fx.height) == -1
+    ctx.close()
+
+
+def test_host_mirror_end_to_end_example_urdf():
+    """URDF text -> URDFRenderer -> RealtimeURDFFilter.filter() on the GPU == the reference's output for
+    urdf/example.urdf.xml (golden fixture of BASELINE config C1)."""
+    fx = golden_io.Fixture("example_urdf_640x480")
+    tf = urdf.StaticTransformProvider()
+    model = urdf.Model.from_string(WL.EXAMPLE_URDF)
+    tf.set_frames(urdf.forward_kinematics(model), "/EXAMPLE/")
+    tf.frames["/world"] = urdf.Transform()
+    tf.frames["/camera_rgb_optical_frame"] = urdf.Transform(np.array([[1.0, 0, 0], [0, 0, 1.0], [0, -1.0, 0]]), (0, 0, 0))
+    prm = FilterParameters("/world", "/camera_rgb_optical_frame",
+                           [{"model": "robot_description", "tf_prefix": "/EXAMPLE", "geometry_type": "visual", "scale": 1.0, "ignore": []}],
+                           depth_distance_threshold=0.05, filter_replace_value=5.0)
+    f = RealtimeURDFFilter(prm, tf, {"robot_description": WL.EXAMPLE_URDF})
+    info = CameraInfo(640, 480, [525.0, 0, 319.5, 0, 0, 525.0, 239.5, 0, 0, 0, 1, 0])
+    out, mask = f.filter_callback(fx.depth, "32FC1", info)
+    fx.check(out, mask)
+    assert f.getMaskedDepth() is out
+    # 16UC1 round trip (src/urdf_filter.cpp:287-288, :309-312)
+    u16 = depth_f32_to_u16(np.nan_to_num(fx.depth, nan=0.0, posinf=0.0))
+    out16, mask16 = f.filter_callback(u16, "16UC1", info)
+    d32 = depth_u16_to_f32(u16)
+    om, ok = O.filter_frame(d32, fx.projection, fx.draws, fx.offset_inv, fx.cam_tf, max_diff=0.05, replace_value=5.0)
+    assert np.array_equal(mask16, ok) and np.array_equal(out16, depth_f32_to_u16(om))
+    assert out16[ok > 0].min() == 5000 and out16[ok > 0].max() == 5000
+
+
+def test_camera_lookup_failure_keeps_previous_output():
+    """Quirk Q6: when the camera transform is unavailable the previous frame's output stays."""
+    fx = golden_io.Fixture("example_urdf_160x120")
+    tf = urdf.StaticTransformProvider()
+    tf.set_frames(urdf.forward_kinematics(urdf.Model.from_string(WL.EXAMPLE_URDF)), "/EXAMPLE/")
+    tf.frames["/world"] = urdf.Transform()
+    tf.frames["/cam"] = urdf.Transform(np.array([[1.0, 0, 0], [0, 0, 1.0], [0, -1.0, 0]]), (0, 0, 0))
+    prm = FilterParameters("/world", "/cam", [{"model": "d", "tf_prefix": "/EXAMPLE", "geometry_type": "visual"}], 0.05, filter_replace_value=5.0)
+    f = RealtimeURDFFilter(prm, tf, {"d": WL.EXAMPLE_URDF})
+    f.filter(fx.depth, fx.projection, fx.width, fx.height)
+    fx.check(f.masked_depth_, f.mask_)
+    prev = f.masked_depth_.copy()
+    del tf.frames["/cam"]
+    f.filter(np.full_like(fx.depth, 1.0), fx.projection, fx.width, fx.height)
+    assert bits_equal(prev, f.masked_depth_)
+
+
+def test_full_size_batch_properties():
+    """BASELINE config C3 scale (256 VGA streams): size-independent properties + oracle spot checks."""
+    n = 256
+    wl = WL.pr2_workload(n, 640, 480, total_triangles=60000)
+    ctx = R.Context(640, 480, n, 0, params(wl.replace_value, wl.max_diff))
+    ids = wl.load_into(ctx)
+    wl.stage(ctx, ids)
+    depth = wl.depth_batch()
+    masked, mask = ctx.filter_batch(depth)
+    # (a) output is a pure select between the sensor value and the replace value
+    recon = np.where(mask > 0, np.float32(wl.replace_value), depth)
+    assert bits_equal(recon, masked)
+    assert set(np.unique(mask)) <= {0, 255}
+    # (b) NaN and zero sensor pixels are never filtered (quirk Q9); +inf always is (quirk Q2)
+    assert (mask[np.isnan(depth)] == 0).all() and (mask[depth == 0] == 0).all() and (mask[np.isposinf(depth)] == 255).all()
+    # (c) deterministic: a second run is identical
+    masked2, mask2 = ctx.filter_batch(depth)
+    assert bits_equal(masked, masked2) and np.array_equal(mask, mask2)
+    # (d) permutation equivariance: reversing the stream order reverses the outputs
+    ctx.set_cameras(0, wl.projection[::-1], wl.offset_inv[::-1], wl.cam_tf[::-1])
+    ctx.set_link_poses_batch(0, ids[0], wl.link_tf[0][::-1])
+    masked3, mask3 = ctx.filter_batch(depth[::-1])
+    assert np.array_equal(mask3[::-1], mask) and bits_equal(masked3[::-1], masked)
+    # (e) oracle spot checks
+    for s in (0, 101, 255):
+        om, ok = O.filter_frame(depth[s], wl.projection[s], wl.oracle_draws(s), wl.offset_inv[s], wl.cam_tf[s],
+                                max_diff=wl.max_diff, replace_value=wl.replace_value)
+        assert (ok != mask[s]).sum() == 0 and bits_equal(om, masked[s])
+    ctx.close()
+
+
+def test_two_kernel_zsurface_matches_oracle_z():
+    fx = golden_io.Fixture("mesh_links_seed21_160x120")
+    ctx = R.Context(fx.width, fx.height, 1, 0, params(fx.replace_value, fx.max_diff, two_kernel=True))
+    m, tfs = fx.load_into(ctx)
+    ctx.set_camera(0, fx.projection, fx.offset_inv, fx.cam_tf)
+    ctx.set_link_poses(0, m, tfs)
+    ctx.filter_batch(fx.depth[None])
+    z = ctx.read_zsurface(1)[0]
+    _, _, zwin, prim, _ = O.filter_frame(fx.depth, fx.projection, fx.draws, fx.offset_inv, fx.cam_tf,
+                                         max_diff=fx.max_diff, replace_value=fx.replace_value, want_debug=True)
+    assert bits_equal(z, zwin)
+    ctx.close()
