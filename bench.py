@@ -137,6 +137,16 @@ def main():
         dur_ms, alg_bytes = cands[dom]
         achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         peak = 8000.0
+        # HBM bytes per launch from PMC counters are collected off-line (rocprofv3 cannot run inside the
+        # timed region): profiles/hbm_traffic.json holds the committed measurement of this same command
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            if (tj["kernel"] == dom and tj["streams"] == n and tj["width"] == W and tj["height"] == H
+                    and tj["triangles"] == wl0.meta["triangles"] and d_mask is not None):
+                traffic = tj["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "filtered depth frames/sec (640x480, PR2 URDF)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -154,7 +164,7 @@ def main():
                            "triangles_clipped": st["triangles_clipped"], "bin_entries": st["bin_entries"],
                            "max_bin_fill": st["max_bin_fill"], "bin_capacity": st["bin_capacity"], "regrowths": st["regrowths"]},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
-                         "frac": achieved / peak, "traffic": None, "launches_per_step": groups,
+                         "frac": achieved / peak, "traffic": traffic, "launches_per_step": groups,
                          "avg_launch_ms": dur_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         # ---- parity spot check + CPU baseline (oracle = checker / reported baseline only) ------
