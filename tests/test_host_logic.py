@@ -150,3 +150,27 @@ def test_sharding_partitions_streams():
     assert sharding.models_for_rank(64, 8, 3) == [3, 11, 19, 27, 35, 43, 51, 59]
     with pytest.raises(ValueError):
         sharding.shard_range(4, 2, 2)
+
+
+def test_cpp_facade_parses_reference_style_urdf(tmp_path):
+    """The C++ host layer (include/realtime_urdf_filter_amd/host.hpp): tolerant XML reader (the
+    reference's example URDF has stray '>' characters after </visual>), primitive tessellation."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "bin", "example_filter")
+    if not os.path.exists(exe):
+        subprocess.check_call([os.path.join(root, "realtime_urdf_filter_amd", "csrc", "build_facade.sh")])
+    xml = """<?xml version="1.0"?><!-- c --><robot name="x">
+      <link name="world"/>
+      <link name="a"><visual><origin xyz="0 0 1" rpy="0 0 0"/><geometry><box size="4 0.5 2" /></geometry></visual>>
+        <collision><geometry><box size="1 1 1"/></geometry></collision>></link>
+      <link name="b"><visual><geometry><sphere radius="0.5"/></geometry></visual>
+                     <visual><geometry><cylinder radius="0.2" length="1"/></geometry></visual></link>
+      <joint name="j" type="fixed"><origin xyz="0 5 0"/><parent link="world"/><child link="a"/></joint>
+      <joint name="k" type="revolute"><parent link="a"/><child link="b"/><axis xyz="0 0 1"/><limit lower="-1" upper="1" effort="1" velocity="1"/></joint>
+    </robot>"""
+    f = tmp_path / "m.urdf"
+    f.write_text(xml)
+    out = subprocess.check_output([exe, "--parse", str(f)]).decode()
+    assert out.strip() == "renderables=3 draws=4 triangles=%d first=/P/a" % (24 + 180 + 220)

@@ -289,3 +289,23 @@ def test_two_kernel_zsurface_matches_oracle_z():
                                          max_diff=fx.max_diff, replace_value=fx.replace_value, want_debug=True)
     assert bits_equal(z, zwin)
     ctx.close()
+
+
+def test_cpp_facade_example_matches_reference(tmp_path):
+    """examples/example_filter.cpp: the reference's single-camera C++ usage on the facade classes
+    (RealtimeURDFFilter::getProjectionMatrix / filter / getMaskedDepth / mask_) reproduces the
+    reference's output for urdf/example.urdf.xml."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "bin", "example_filter")
+    if not os.path.exists(exe):
+        subprocess.check_call([os.path.join(root, "realtime_urdf_filter_amd", "csrc", "build_facade.sh")])
+    fx = golden_io.Fixture("example_urdf_640x480")
+    (tmp_path / "m.urdf").write_text(WL.EXAMPLE_URDF)
+    fx.depth.tofile(tmp_path / "d.f32")
+    subprocess.check_call([exe, str(tmp_path / "m.urdf"), str(tmp_path / "d.f32"), "640", "480", "525", "525", "319.5", "239.5", "5.0",
+                           str(tmp_path / "o.f32"), str(tmp_path / "o.u8")])
+    masked = np.fromfile(tmp_path / "o.f32", np.float32).reshape(480, 640)
+    mask = np.fromfile(tmp_path / "o.u8", np.uint8).reshape(480, 640)
+    fx.check(masked, mask)
