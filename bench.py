@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--triangles", type=int, default=250000, help="triangle budget of the PR2-like model")
     ap.add_argument("--variants", type=int, default=2, help="distinct input batches rotated through the steps")
     ap.add_argument("--two-kernel", action="store_true", help="rasteriser + separate compare kernel")
+    ap.add_argument("--host-poses", action="store_true", help="stage explicit link matrices from the host instead of joint positions + on-device forward kinematics")
     ap.add_argument("--no-mask", action="store_true", help="need_mask_ == false: no mask output")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--debug-flags", type=lambda x: int(x, 0), default=0, help="timing experiments only (results are wrong)")
@@ -76,6 +77,8 @@ def main():
     p.flags |= args.debug_flags
     ctx = R.Context(W, H, n, local_rank, p)
     ids = wl0.load_into(ctx)
+    if not args.host_poses:
+        wl0.load_kinematics(ctx, ids)
     ctx.enable_timing(True)
 
     d_depth = []
@@ -88,7 +91,10 @@ def main():
 
     def step(k):
         v = k % len(variants)
-        variants[v].stage(ctx, ids)
+        if args.host_poses:
+            variants[v].stage(ctx, ids)
+        else:
+            variants[v].stage_joint_positions(ctx, ids)      # joint angles in, forward kinematics on the GPU
         ctx.filter_batch_device(n, d_depth[v].data_ptr(), d_masked.data_ptr(), d_mask.data_ptr() if d_mask is not None else 0)
         ctx.sync()
 
@@ -154,7 +160,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C3: %dx%d depth, synthetic PR2-like URDF (%d links with meshes, %d triangles), batch=%d concurrent streams per GPU, new joint state + camera pose every step"
                                    % (W, H, wl0.meta["links_with_geometry"], wl0.meta["triangles"], n),
-                       "streams_per_gpu": n, "mode": "two-kernel" if two else "fused", "mask_output": d_mask is not None,
+                       "streams_per_gpu": n, "poses": "host matrices" if args.host_poses else "joint positions, forward kinematics on the GPU", "mode": "two-kernel" if two else "fused", "mask_output": d_mask is not None,
                        "parallelism": "stream-sharded x%d" % world},
             "per_stream_fps": value / (n * world),
             "kernel_ms_per_step": per,
@@ -175,6 +181,12 @@ def main():
             hm = d_masked.cpu().numpy()
             hk = d_mask.cpu().numpy() if d_mask is not None else None
             hd = d_depth[v_last].cpu().numpy()
+            if args.host_poses:
+                link_tf_all, cam_all = wl.link_tf[0], wl.cam_tf
+            else:
+                # the oracle is fed the very matrices the GPU's forward kinematics produced
+                link_tf_all, cam_all = ctx.read_poses(n, wl.link_tf[0].shape[1])
+                out["fk"] = {"on_device": True, "max_abs_diff_vs_host_fk": float(max(np.abs(link_tf_all - wl.link_tf[0]).max(), np.abs(cam_all - wl.cam_tf).max()))}
             bad_mask = bad_depth = 0
             t_cpu = 0.0
             n_cpu = 0
@@ -182,7 +194,8 @@ def main():
             s = 0
             while s < n and (s < args.check_frames or (budget > 0 and t_cpu < budget)):
                 c0 = time.perf_counter()
-                om, ok = O.filter_frame(hd[s], wl.projection[s], wl.oracle_draws(s), wl.offset_inv[s], wl.cam_tf[s],
+                draws = [(link_tf_all[s, li], d.pre_op, d.op, d.verts, d.tris) for li, dl in enumerate(wl.models[0]) for d in dl]
+                om, ok = O.filter_frame(hd[s], wl.projection[s], draws, wl.offset_inv[s], cam_all[s],
                                         max_diff=wl.max_diff, replace_value=wl.replace_value)
                 t_cpu += time.perf_counter() - c0
                 n_cpu += 1

@@ -134,6 +134,31 @@ int rtuf_set_cameras(rtuf_context *ctx, int first_stream, int n_streams, const d
 int rtuf_set_link_poses_batch(rtuf_context *ctx, int first_stream, int n_streams, int model,
                               const double *link_tf, int n_links);
 
+/* ---- on-device forward kinematics --------------------------------------------------
+ * Replaces the per-renderable TF lookups of URDFRenderer::update_link_transforms
+ * (src/urdf_renderer.cpp:173-190) for robots whose link poses follow from joint positions: the
+ * kinematic tree of a model is uploaded once, per frame only the joint positions cross the bus and
+ * a kernel computes every  fixed<-link  transform and the matrices of rtuf_set_link_poses on the GPU
+ * (double precision, same multiplication order as the host-side forward kinematics).
+ *   n_frames frames, parent[i] < i or -1 for the root; joint_type 0 fixed, 1 revolute/continuous,
+ *   2 prismatic; joint_origin[i] = parent<-child transform at q = 0 (column-major); joint_axis[i] in
+ *   the child frame; link_frame[l] = frame the l-th link (renderable) of the model is attached to;
+ *   link_offset[l] = the URDF <origin> of its visual/collision (Renderable::link_offset). */
+enum { RTUF_JOINT_FIXED = 0, RTUF_JOINT_REVOLUTE = 1, RTUF_JOINT_PRISMATIC = 2 };
+int rtuf_set_kinematics(rtuf_context *ctx, int model, int n_frames, const int32_t *parent,
+                        const int32_t *joint_type, const double *joint_origin, const double *joint_axis,
+                        const int32_t *link_frame, const double *link_offset, int n_links);
+/* Joint positions q[n_streams][n_frames] (entries of fixed joints are ignored) and, optionally, the
+ * pose of the root frame in the fixed frame root_tf[n_streams][16] (NULL = identity).  With
+ * camera_frame >= 0 the camera transform of each stream becomes inverse(fixed<-camera_frame)
+ * (a camera mounted on the robot); with -1 it stays what rtuf_set_camera(s) set.  Overrides
+ * rtuf_set_link_poses for this model on these streams until rtuf_set_link_poses is called again. */
+int rtuf_set_joint_positions(rtuf_context *ctx, int first_stream, int n_streams, int model, const double *q,
+                             const double *root_tf, int camera_frame);
+/* Debug / test access: the link matrices ([n_streams][total links][16]) and camera transforms
+ * ([n_streams][16]) the last batch was rendered with. */
+int rtuf_debug_read_poses(rtuf_context *ctx, int n_streams, double *link_tf_out, double *cam_tf_out);
+
 /* ---- the hot path ------------------------------------------------------------------ */
 /* filter() for n streams at once (stream ids 0..n-1), host buffers:
  * depth_in[s]: width*height float32 metres, row 0 first (src/urdf_filter.cpp:233-234);

@@ -23,7 +23,7 @@ SYMBOLS = [
     "rtuf_default_params", "rtuf_abi_version", "rtuf_create", "rtuf_destroy", "rtuf_last_error",
     "rtuf_set_params", "rtuf_add_model", "rtuf_add_link", "rtuf_add_draw", "rtuf_finalize_models",
     "rtuf_num_links", "rtuf_num_triangles", "rtuf_set_stream_models", "rtuf_set_camera",
-    "rtuf_projection_from_intrinsics", "rtuf_set_link_poses", "rtuf_set_cameras", "rtuf_set_link_poses_batch", "rtuf_filter_batch",
+    "rtuf_projection_from_intrinsics", "rtuf_set_link_poses", "rtuf_set_cameras", "rtuf_set_link_poses_batch", "rtuf_set_kinematics", "rtuf_set_joint_positions", "rtuf_debug_read_poses", "rtuf_filter_batch",
     "rtuf_filter_batch_device", "rtuf_filter", "rtuf_get_masked_depth", "rtuf_get_mask", "rtuf_sync",
     "rtuf_stream", "rtuf_get_stats", "rtuf_enable_timing", "rtuf_debug_read_zsurface",
 ]
@@ -91,6 +91,9 @@ def load_library(path=None):
     lib.rtuf_set_link_poses.argtypes = [vp, ci, ci, vp, ci]
     lib.rtuf_set_cameras.argtypes = [vp, ci, ci, vp, vp, vp]
     lib.rtuf_set_link_poses_batch.argtypes = [vp, ci, ci, ci, vp, ci]
+    lib.rtuf_set_kinematics.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, ci]
+    lib.rtuf_set_joint_positions.argtypes = [vp, ci, ci, ci, vp, vp, ci]
+    lib.rtuf_debug_read_poses.argtypes = [vp, ci, vp, vp]
     lib.rtuf_filter_batch.argtypes = [vp, ci, vp, vp, vp]
     lib.rtuf_filter_batch_device.argtypes = [vp, ci, vp, vp, vp]
     lib.rtuf_filter.argtypes = [vp, vp, vp, ci, ci]
@@ -204,6 +207,27 @@ class Context:
         a = np.ascontiguousarray(link_tf, np.float64)
         n, nl = a.shape[0], a.shape[1]
         self._check(self._lib.rtuf_set_link_poses_batch(self._h, first_stream, n, model, _ptr(a), nl))
+
+    def set_kinematics(self, model, parent, joint_type, joint_origin, joint_axis, link_frame, link_offset):
+        """On-device FK tree of a model (see rtuf_set_kinematics)."""
+        pa = np.ascontiguousarray(parent, np.int32)
+        jt = np.ascontiguousarray(joint_type, np.int32)
+        jo = np.ascontiguousarray(joint_origin, np.float64).reshape(-1, 16)
+        ja = np.ascontiguousarray(joint_axis, np.float64).reshape(-1, 3)
+        lf = np.ascontiguousarray(link_frame, np.int32)
+        lo = np.ascontiguousarray(link_offset, np.float64).reshape(-1, 16)
+        self._check(self._lib.rtuf_set_kinematics(self._h, model, len(pa), _ptr(pa), _ptr(jt), _ptr(jo), _ptr(ja), _ptr(lf), _ptr(lo), len(lf)))
+
+    def set_joint_positions(self, first_stream, model, q, root_tf=None, camera_frame=-1):
+        qa = np.ascontiguousarray(q, np.float64)
+        rt = None if root_tf is None else np.ascontiguousarray(root_tf, np.float64).reshape(-1, 16)
+        self._check(self._lib.rtuf_set_joint_positions(self._h, first_stream, qa.shape[0], model, _ptr(qa), _ptr(rt), camera_frame))
+
+    def read_poses(self, n, n_links_total):
+        tf = np.empty((n, max(n_links_total, 1), 16), np.float64)
+        cam = np.empty((n, 16), np.float64)
+        self._check(self._lib.rtuf_debug_read_poses(self._h, n, _ptr(tf), _ptr(cam)))
+        return tf, cam
 
     # hot path
     def filter_batch(self, depth, want_mask=True):

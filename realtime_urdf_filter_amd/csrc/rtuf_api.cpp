@@ -29,7 +29,16 @@ struct HostDraw {
   std::vector<uint32_t> tris;     // 3 per triangle, local vertex ids
 };
 struct HostLink { std::vector<HostDraw> draws; };
-struct HostModel { std::vector<HostLink> links; int link_base = 0; };
+struct Kinematics {               // on-device forward kinematics of one model
+  int n_frames = 0, camera_frame = -1;
+  bool has_root = false, any_enabled = false;
+  int32_t* d_parent = nullptr; int32_t* d_type = nullptr; double* d_origin = nullptr; double* d_axis = nullptr;
+  int32_t* d_link_frame = nullptr; double* d_link_offset = nullptr;
+  double* h_q = nullptr; double* d_q = nullptr;             // [max_streams][n_frames]
+  double* h_root = nullptr; double* d_root = nullptr;       // [max_streams][12]
+  uint8_t* h_enabled = nullptr; uint8_t* d_enabled = nullptr;
+};
+struct HostModel { std::vector<HostLink> links; int link_base = 0; Kinematics kin; };
 
 char g_create_error[512] = "";
 
@@ -167,6 +176,14 @@ void rtuf_destroy(rtuf_context* c)
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  for (HostModel& m : c->models) {
+    Kinematics& k = m.kin;
+    hipFree(k.d_parent); hipFree(k.d_type); hipFree(k.d_origin); hipFree(k.d_axis); hipFree(k.d_link_frame); hipFree(k.d_link_offset);
+    hipFree(k.d_q); hipFree(k.d_root); hipFree(k.d_enabled);
+    if (k.h_q) hipHostFree(k.h_q);
+    if (k.h_root) hipHostFree(k.h_root);
+    if (k.h_enabled) hipHostFree(k.h_enabled);
+  }
   free_frame_buffers(c);
   auto dfree = [](auto*& p) { if (p) { hipFree(p); p = nullptr; } };
   dfree(c->d_cverts); dfree(c->d_ctris); dfree(c->d_chunks); dfree(c->d_draws);
@@ -463,6 +480,7 @@ int rtuf_set_link_poses(rtuf_context* c, int stream, int model, const double* li
   const HostModel& m = c->models[model];
   if (n_links != (int)m.links.size()) return c->fail(RTUF_ERR_INVALID, "model %d has %d links, got %d", model, (int)m.links.size(), n_links);
   memcpy(c->h_link_tf + ((size_t)stream * c->n_links + m.link_base) * 16, link_tf, sizeof(double) * 16 * (size_t)n_links);
+  if (m.kin.h_enabled) c->models[model].kin.h_enabled[stream] = 0;
   return RTUF_OK;
 }
 
@@ -489,9 +507,107 @@ int rtuf_set_link_poses_batch(rtuf_context* c, int first, int n, int model, cons
   if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
   const HostModel& m = c->models[model];
   if (n_links != (int)m.links.size()) return c->fail(RTUF_ERR_INVALID, "model %d has %d links, got %d", model, (int)m.links.size(), n_links);
-  for (int s = 0; s < n; s++)
+  for (int s = 0; s < n; s++) {
     memcpy(c->h_link_tf + ((size_t)(first + s) * c->n_links + m.link_base) * 16, link_tf + (size_t)s * n_links * 16,
            sizeof(double) * 16 * (size_t)n_links);
+    if (m.kin.h_enabled) c->models[model].kin.h_enabled[first + s] = 0;
+  }
+  return RTUF_OK;
+}
+
+
+// column-major GL matrix -> row-major 3x3 basis + origin
+static void gl_to_tf12(const double* g, double* t)
+{
+  t[0] = g[0]; t[1] = g[4]; t[2] = g[8];
+  t[3] = g[1]; t[4] = g[5]; t[5] = g[9];
+  t[6] = g[2]; t[7] = g[6]; t[8] = g[10];
+  t[9] = g[12]; t[10] = g[13]; t[11] = g[14];
+}
+
+int rtuf_set_kinematics(rtuf_context* c, int model, int n_frames, const int32_t* parent, const int32_t* joint_type,
+                        const double* joint_origin, const double* joint_axis, const int32_t* link_frame,
+                        const double* link_offset, int n_links)
+{
+  if (!c || !parent || !joint_type || !joint_origin || !joint_axis || !link_frame || !link_offset) return RTUF_ERR_INVALID;
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
+  HostModel& m = c->models[model];
+  if (n_links != (int)m.links.size()) return c->fail(RTUF_ERR_INVALID, "model %d has %d links, got %d", model, (int)m.links.size(), n_links);
+  if (n_frames <= 0 || n_frames > 4096) return c->fail(RTUF_ERR_INVALID, "bad frame count %d", n_frames);
+  for (int i = 0; i < n_frames; i++) {
+    if (parent[i] >= i || parent[i] < -1) return c->fail(RTUF_ERR_INVALID, "frame %d: parent %d must precede it", i, parent[i]);
+    if (joint_type[i] < 0 || joint_type[i] > 2) return c->fail(RTUF_ERR_INVALID, "frame %d: bad joint type %d", i, joint_type[i]);
+    int depth = 0;
+    for (int f = i; f >= 0; f = parent[f]) if (++depth > 64) return c->fail(RTUF_ERR_INVALID, "kinematic chain deeper than 64");
+  }
+  for (int l = 0; l < n_links; l++)
+    if (link_frame[l] < 0 || link_frame[l] >= n_frames) return c->fail(RTUF_ERR_INVALID, "link %d: bad frame %d", l, link_frame[l]);
+  hipSetDevice(c->device);
+  Kinematics& k = m.kin;
+  if (k.n_frames) return c->fail(RTUF_ERR_STATE, "kinematics of model %d already set", model);
+  std::vector<double> org(12 * (size_t)n_frames), off(12 * (size_t)std::max(n_links, 1));
+  for (int i = 0; i < n_frames; i++) gl_to_tf12(joint_origin + 16 * (size_t)i, &org[12 * (size_t)i]);
+  for (int l = 0; l < n_links; l++) gl_to_tf12(link_offset + 16 * (size_t)l, &off[12 * (size_t)l]);
+  const size_t N = (size_t)c->max_streams;
+  HIP_TRY(c, hipMalloc(&k.d_parent, sizeof(int32_t) * n_frames));
+  HIP_TRY(c, hipMalloc(&k.d_type, sizeof(int32_t) * n_frames));
+  HIP_TRY(c, hipMalloc(&k.d_origin, sizeof(double) * 12 * n_frames));
+  HIP_TRY(c, hipMalloc(&k.d_axis, sizeof(double) * 3 * n_frames));
+  HIP_TRY(c, hipMalloc(&k.d_link_frame, sizeof(int32_t) * std::max(n_links, 1)));
+  HIP_TRY(c, hipMalloc(&k.d_link_offset, sizeof(double) * off.size()));
+  HIP_TRY(c, hipMalloc(&k.d_q, sizeof(double) * N * n_frames));
+  HIP_TRY(c, hipMalloc(&k.d_root, sizeof(double) * N * 12));
+  HIP_TRY(c, hipMalloc(&k.d_enabled, N));
+  HIP_TRY(c, hipHostMalloc(&k.h_q, sizeof(double) * N * n_frames));
+  HIP_TRY(c, hipHostMalloc(&k.h_root, sizeof(double) * N * 12));
+  HIP_TRY(c, hipHostMalloc(&k.h_enabled, N));
+  memset(k.h_enabled, 0, N);
+  memset(k.h_q, 0, sizeof(double) * N * n_frames);
+  HIP_TRY(c, hipMemcpy(k.d_parent, parent, sizeof(int32_t) * n_frames, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(k.d_type, joint_type, sizeof(int32_t) * n_frames, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(k.d_origin, org.data(), sizeof(double) * org.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(k.d_axis, joint_axis, sizeof(double) * 3 * n_frames, hipMemcpyHostToDevice));
+  if (n_links) HIP_TRY(c, hipMemcpy(k.d_link_frame, link_frame, sizeof(int32_t) * n_links, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(k.d_link_offset, off.data(), sizeof(double) * off.size(), hipMemcpyHostToDevice));
+  k.n_frames = n_frames;
+  return RTUF_OK;
+}
+
+int rtuf_set_joint_positions(rtuf_context* c, int first, int n, int model, const double* q, const double* root_tf, int camera_frame)
+{
+  if (!c || !q) return RTUF_ERR_INVALID;
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
+  if (first < 0 || n < 0 || first + n > c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream range %d+%d", first, n);
+  Kinematics& k = c->models[model].kin;
+  if (!k.n_frames) return c->fail(RTUF_ERR_STATE, "call rtuf_set_kinematics for model %d first", model);
+  if (camera_frame < -1 || camera_frame >= k.n_frames) return c->fail(RTUF_ERR_INVALID, "bad camera frame %d", camera_frame);
+  memcpy(k.h_q + (size_t)first * k.n_frames, q, sizeof(double) * (size_t)n * k.n_frames);
+  static const double I12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+  for (int s = 0; s < n; s++) {
+    if (root_tf) gl_to_tf12(root_tf + 16 * (size_t)s, k.h_root + 12 * (size_t)(first + s));
+    else memcpy(k.h_root + 12 * (size_t)(first + s), I12, sizeof I12);
+    k.h_enabled[first + s] = 1;
+  }
+  k.camera_frame = camera_frame;
+  k.any_enabled = true;
+  return RTUF_OK;
+}
+
+int rtuf_debug_read_poses(rtuf_context* c, int n, double* link_tf_out, double* cam_tf_out)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (!c->finalized || n <= 0 || n > c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad arguments");
+  hipSetDevice(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const size_t L = (size_t)std::max(c->n_links, 1);
+  if (link_tf_out) HIP_TRY(c, hipMemcpy(link_tf_out, c->d_link_tf, sizeof(double) * 16 * L * n, hipMemcpyDeviceToHost));
+  if (cam_tf_out) {
+    std::vector<Camera> cams(n);
+    HIP_TRY(c, hipMemcpy(cams.data(), c->d_cams, sizeof(Camera) * n, hipMemcpyDeviceToHost));
+    for (int s = 0; s < n; s++) memcpy(cam_tf_out + 16 * (size_t)s, cams[s].cam_tf, sizeof(double) * 16);
+  }
   return RTUF_OK;
 }
 
@@ -538,6 +654,21 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
   HIP_TRY(c, hipMemcpyAsync(c->d_link_tf, c->h_link_tf, sizeof(double) * 16 * L * n, hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemcpyAsync(c->d_model_mask, c->h_model_mask, sizeof(uint64_t) * n, hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(Counters), st));
+  // on-device forward kinematics overwrites the link matrices (and camera) of the streams that use it
+  for (HostModel& m : c->models) {
+    Kinematics& k = m.kin;
+    if (!k.n_frames || !k.any_enabled) continue;
+    HIP_TRY(c, hipMemcpyAsync(k.d_q, k.h_q, sizeof(double) * (size_t)n * k.n_frames, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(k.d_root, k.h_root, sizeof(double) * 12 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(k.d_enabled, k.h_enabled, (size_t)n, hipMemcpyHostToDevice, st));
+    FkArgs fa{};
+    fa.parent = k.d_parent; fa.joint_type = k.d_type; fa.joint_origin = k.d_origin; fa.joint_axis = k.d_axis;
+    fa.link_frame = k.d_link_frame; fa.link_offset = k.d_link_offset; fa.q = k.d_q; fa.root_tf = k.d_root;
+    fa.enabled = k.d_enabled; fa.link_tf = c->d_link_tf; fa.cams = c->d_cams;
+    fa.n_streams = n; fa.n_frames = k.n_frames; fa.n_links_model = (int)m.links.size(); fa.link_base = m.link_base;
+    fa.n_links_total = (int)L; fa.camera_frame = k.camera_frame;
+    launch_fk(fa, st);
+  }
   PoseArgs pa{};
   pa.cams = c->d_cams; pa.link_tf = c->d_link_tf; pa.draws = c->d_draws; pa.mvp = c->d_mvp;
   pa.bg_z = c->d_bg_z; pa.bg_mode = c->d_bg_mode;

@@ -183,6 +183,21 @@ struct CompareArgs {
 };
 
 
+struct FkArgs {
+  const int32_t* parent;        // [F]
+  const int32_t* joint_type;    // [F]
+  const double* joint_origin;   // [F][12]  row-major 3x3 basis + origin
+  const double* joint_axis;     // [F][3]
+  const int32_t* link_frame;    // [L_model]
+  const double* link_offset;    // [L_model][12]
+  const double* q;              // [N][F]
+  const double* root_tf;        // [N][12] or nullptr
+  const uint8_t* enabled;       // [N] stream uses FK for this model
+  double* link_tf;              // [N][L_total][16]
+  Camera* cams;                 // [N]
+  int n_streams, n_frames, n_links_model, link_base, n_links_total, camera_frame;
+};
+void launch_fk(const FkArgs& a, hipStream_t st);
 void launch_pose(const PoseArgs& a, hipStream_t st);
 void launch_setup(const SetupArgs& a, int n_chunks, hipStream_t st);
 void launch_clip(const SetupArgs& a, hipStream_t st);

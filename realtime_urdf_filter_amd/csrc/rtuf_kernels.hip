@@ -197,6 +197,112 @@ __global__ void pose_kernel(PoseArgs a)
 }
 
 // ---------------------------------------------------------------------------------------
+// fk_kernel: forward kinematics in double precision, one thread per (stream, frame).  The chain
+// root -> frame is multiplied top-down, T_child = (T_parent * origin) * motion(q), the same
+// association order as the host-side forward kinematics.
+// ---------------------------------------------------------------------------------------
+struct Tf12 { double m[9]; double o[3]; };
+
+__device__ __forceinline__ Tf12 tf_mul(const Tf12& a, const Tf12& b)
+{
+  Tf12 r;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      r.m[3 * i + j] = __dadd_rn(__dadd_rn(__dmul_rn(a.m[3 * i], b.m[j]), __dmul_rn(a.m[3 * i + 1], b.m[3 + j])), __dmul_rn(a.m[3 * i + 2], b.m[6 + j]));
+    r.o[i] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(a.m[3 * i], b.o[0]), __dmul_rn(a.m[3 * i + 1], b.o[1])), __dmul_rn(a.m[3 * i + 2], b.o[2])), a.o[i]);
+  }
+  return r;
+}
+
+__device__ __forceinline__ Tf12 tf_load(const double* p)
+{
+  Tf12 t;
+#pragma unroll
+  for (int k = 0; k < 9; k++) t.m[k] = p[k];
+  t.o[0] = p[9]; t.o[1] = p[10]; t.o[2] = p[11];
+  return t;
+}
+
+__device__ __forceinline__ Tf12 tf_from_quat(double x, double y, double z, double w)
+{
+  // Matrix3x3::setRotation
+  Tf12 t;
+  const double d = x * x + y * y + z * z + w * w;
+  const double s = 2.0 / d;
+  const double xs = x * s, ys = y * s, zs = z * s;
+  const double wx = w * xs, wy = w * ys, wz = w * zs;
+  const double xx = x * xs, xy = x * ys, xz = x * zs;
+  const double yy = y * ys, yz = y * zs, zz = z * zs;
+  t.m[0] = 1.0 - (yy + zz); t.m[1] = xy - wz; t.m[2] = xz + wy;
+  t.m[3] = xy + wz; t.m[4] = 1.0 - (xx + zz); t.m[5] = yz - wx;
+  t.m[6] = xz - wy; t.m[7] = yz + wx; t.m[8] = 1.0 - (xx + yy);
+  t.o[0] = t.o[1] = t.o[2] = 0.0;
+  return t;
+}
+
+__device__ __forceinline__ void tf_store_gl(const Tf12& t, double* g)
+{
+  g[0] = t.m[0]; g[1] = t.m[3]; g[2] = t.m[6]; g[3] = 0.0;
+  g[4] = t.m[1]; g[5] = t.m[4]; g[6] = t.m[7]; g[7] = 0.0;
+  g[8] = t.m[2]; g[9] = t.m[5]; g[10] = t.m[8]; g[11] = 0.0;
+  g[12] = t.o[0]; g[13] = t.o[1]; g[14] = t.o[2]; g[15] = 1.0;
+}
+
+__device__ Tf12 fk_frame(const FkArgs& a, int s, int frame)
+{
+  int chain[64];
+  int n = 0;
+  for (int f = frame; f >= 0 && n < 64; f = a.parent[f]) chain[n++] = f;
+  Tf12 t;
+  if (a.root_tf) t = tf_load(a.root_tf + (size_t)s * 12);
+  else { for (int k = 0; k < 9; k++) t.m[k] = (k % 4 == 0) ? 1.0 : 0.0; t.o[0] = t.o[1] = t.o[2] = 0.0; }
+  for (int k = n - 1; k >= 0; k--) {
+    const int f = chain[k];
+    if (a.parent[f] < 0) continue;                  // the root frame carries no joint
+    t = tf_mul(t, tf_load(a.joint_origin + (size_t)f * 12));
+    const int jt = a.joint_type[f];
+    if (jt == 1) {
+      const double q = a.q[(size_t)s * a.n_frames + f];
+      const double ax = a.joint_axis[3 * f], ay = a.joint_axis[3 * f + 1], az = a.joint_axis[3 * f + 2];
+      const double nn = sqrt(ax * ax + ay * ay + az * az);
+      const double ux = nn > 0 ? ax / nn : 1.0, uy = nn > 0 ? ay / nn : 0.0, uz = nn > 0 ? az / nn : 0.0;
+      const double sh = sin(0.5 * q), ch = cos(0.5 * q);
+      t = tf_mul(t, tf_from_quat(ux * sh, uy * sh, uz * sh, ch));
+    } else if (jt == 2) {
+      const double q = a.q[(size_t)s * a.n_frames + f];
+      Tf12 m;
+      for (int k2 = 0; k2 < 9; k2++) m.m[k2] = (k2 % 4 == 0) ? 1.0 : 0.0;
+      m.o[0] = a.joint_axis[3 * f] * q; m.o[1] = a.joint_axis[3 * f + 1] * q; m.o[2] = a.joint_axis[3 * f + 2] * q;
+      t = tf_mul(t, m);
+    }
+  }
+  return t;
+}
+
+__global__ void fk_kernel(FkArgs a)
+{
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per = a.n_links_model + 1;
+  if (gid >= a.n_streams * per) return;
+  const int s = gid / per, l = gid - s * per;
+  if (!a.enabled[s]) return;
+  if (l < a.n_links_model) {
+    // link matrix = (fixed<-frame) * link_offset   (Renderable::applyTransform)
+    const Tf12 t = tf_mul(fk_frame(a, s, a.link_frame[l]), tf_load(a.link_offset + (size_t)l * 12));
+    tf_store_gl(t, a.link_tf + ((size_t)s * a.n_links_total + a.link_base + l) * 16);
+  } else if (a.camera_frame >= 0) {
+    // camera_transform = lookupTransform(cam_frame, fixed_frame) = inverse(fixed<-camera)
+    const Tf12 t = fk_frame(a, s, a.camera_frame);
+    Tf12 inv;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) inv.m[3 * i + j] = t.m[3 * j + i];
+    for (int i = 0; i < 3; i++) inv.o[i] = inv.m[3 * i] * (-t.o[0]) + inv.m[3 * i + 1] * (-t.o[1]) + inv.m[3 * i + 2] * (-t.o[2]);
+    tf_store_gl(inv, a.cams[s].cam_tf);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // triangle set-up
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int snap(float v)
@@ -1013,6 +1119,11 @@ __global__ void reset_clip_kernel(Counters* c)
 void launch_reset_clip(Counters* c, hipStream_t st)
 {
   hipLaunchKernelGGL(reset_clip_kernel, dim3(1), dim3(kCounterShards), 0, st, c);
+}
+void launch_fk(const FkArgs& a, hipStream_t st)
+{
+  const int total = a.n_streams * (a.n_links_model + 1);
+  hipLaunchKernelGGL(fk_kernel, dim3((total + 63) / 64), dim3(64), 0, st, a);
 }
 void launch_pose(const PoseArgs& a, hipStream_t st)
 {

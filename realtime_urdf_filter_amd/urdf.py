@@ -256,3 +256,42 @@ class StaticTransformProvider:
     def lookup_transform(self, target, source, stamp=None):
         t, s = self.frames[target], self.frames[source]
         return t.inverse() * s
+
+
+def kinematic_arrays(model, link_names, link_offsets):
+    """Arrays for rtuf_set_kinematics: frames = the model's links in topological order.
+
+    link_names: for every renderable (in upload order) the URDF link it is attached to;
+    link_offsets: their Renderable.link_offset transforms.
+    Returns dict(parent, joint_type, joint_origin [F,16], joint_axis [F,3], link_frame, link_offset [L,16],
+    frame_index {link name: index}, joint_of_frame [joint name or None per frame])."""
+    by_parent = {}
+    for j in model.joints.values():
+        by_parent.setdefault(j.parent, []).append(j)
+    order, parent, jtype, origin, axis, jname = [], [], [], [], [], []
+    index = {}
+    stack = [(model.root_link(), None)]
+    while stack:
+        name, joint = stack.pop()
+        index[name] = len(order)
+        order.append(name)
+        if joint is None:
+            parent.append(-1); jtype.append(0); origin.append(Transform().opengl_matrix()); axis.append((1.0, 0.0, 0.0)); jname.append(None)
+        else:
+            parent.append(index[joint.parent])
+            jtype.append(1 if joint.type in ("revolute", "continuous") else 2 if joint.type == "prismatic" else 0)
+            origin.append(pose_to_transform(joint.xyz, joint.rpy).opengl_matrix())
+            axis.append(tuple(float(a) for a in joint.axis))
+            jname.append(joint.name)
+        for j in sorted(by_parent.get(name, []), key=lambda jj: jj.name, reverse=True):
+            stack.append((j.child, j))
+    return {"parent": np.asarray(parent, np.int32), "joint_type": np.asarray(jtype, np.int32),
+            "joint_origin": np.stack(origin), "joint_axis": np.asarray(axis, np.float64),
+            "link_frame": np.asarray([index[n] for n in link_names], np.int32),
+            "link_offset": np.stack([t.opengl_matrix() for t in link_offsets]) if link_offsets else np.zeros((0, 16)),
+            "frame_index": index, "joint_of_frame": jname}
+
+
+def joint_vector(kin, joint_positions):
+    """q vector (one entry per frame) from a {joint name: position} dict."""
+    return np.asarray([float(joint_positions.get(j, 0.0)) if j else 0.0 for j in kin["joint_of_frame"]], np.float64)

@@ -39,6 +39,9 @@ class Workload:
         self.near, self.far = 0.1, 8.0
         self.max_diff, self.replace_value = 0.05, 5.0      # launch/filter_parameters.yaml:14-16
         self.meta = {}
+        self.kinematics = None      # arrays for rtuf_set_kinematics (model 0), see urdf.kinematic_arrays
+        self.camera_frame_index = -1
+        self.joint_q = None         # [N, frames]
 
     def n_triangles(self):
         return int(sum(len(d.tris) for m in self.models for l in m for d in l))
@@ -73,6 +76,20 @@ class Workload:
         for m, tf in zip(model_ids, self.link_tf):
             if tf.shape[1]:
                 ctx.set_link_poses_batch(0, m, tf[sl])
+
+    def stage_joint_positions(self, ctx, model_ids, first=0, n=None):
+        """Same poses through on-device forward kinematics: only joint positions cross the bus."""
+        n = self.n_streams if n is None else n
+        sl = slice(first, first + n)
+        ctx.set_cameras(0, self.projection[sl], self.offset_inv[sl], None)
+        ctx.set_joint_positions(0, model_ids[0], self.joint_q[sl], None, self.camera_frame_index)
+        for m, tf in list(zip(model_ids, self.link_tf))[1:]:
+            if tf.shape[1]:
+                ctx.set_link_poses_batch(0, m, tf[sl])
+
+    def load_kinematics(self, ctx, model_ids):
+        k = self.kinematics
+        ctx.set_kinematics(model_ids[0], k["parent"], k["joint_type"], k["joint_origin"], k["joint_axis"], k["link_frame"], k["link_offset"])
 
     def oracle_draws(self, stream):
         """Draw list of one stream in the oracle's format."""
@@ -172,4 +189,9 @@ def pr2_workload(n_streams, width=640, height=480, total_triangles=250000, seed=
     w.cam_tf = cam_tf
     w.meta = {"robot": "synthetic PR2-like", "links": len(robot.links), "links_with_geometry": L,
               "triangles": w.n_triangles(), "vertices": w.n_vertices()}
+    # on-device forward kinematics inputs: the tree once, joint positions per stream
+    strip = lambda n: n[1:] if n.startswith("/") else n
+    w.kinematics = urdf.kinematic_arrays(model, [strip(r.name) for r in rd.renderables_], [r.link_offset for r in rd.renderables_])
+    w.camera_frame_index = w.kinematics["frame_index"][robot.camera_frame]
+    w.joint_q = np.stack([urdf.joint_vector(w.kinematics, robot.random_joint_state(first_state_seed + s)) for s in range(n_streams)])
     return w

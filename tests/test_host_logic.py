@@ -174,3 +174,33 @@ def test_cpp_facade_parses_reference_style_urdf(tmp_path):
     f.write_text(xml)
     out = subprocess.check_output([exe, "--parse", str(f)]).decode()
     assert out.strip() == "renderables=3 draws=4 triangles=%d first=/P/a" % (24 + 180 + 220)
+
+
+def test_kinematic_arrays_reproduce_forward_kinematics():
+    """The FK tree handed to the GPU (urdf.kinematic_arrays) evaluates to the same transforms as
+    urdf.forward_kinematics when multiplied top-down in numpy."""
+    robot = synthetic.SyntheticRobot(2000, 3)
+    model = urdf.Model.from_string(robot.to_urdf_xml())
+    q = robot.random_joint_state(5)
+    fk = urdf.forward_kinematics(model, q)
+    names = sorted(model.links)
+    kin = urdf.kinematic_arrays(model, names, [urdf.Transform() for _ in names])
+    qv = urdf.joint_vector(kin, q)
+    assert kin["parent"][0] == -1 and all(kin["parent"][i] < i for i in range(1, len(kin["parent"])))
+    T = {}
+    for i in range(len(kin["parent"])):
+        p = kin["parent"][i]
+        if p < 0:
+            T[i] = np.eye(4)
+            continue
+        O4 = kin["joint_origin"][i].reshape(4, 4).T
+        M = np.eye(4)
+        if kin["joint_type"][i] == 1:
+            ax = kin["joint_axis"][i] / np.linalg.norm(kin["joint_axis"][i])
+            h = 0.5 * qv[i]
+            M[:3, :3] = urdf.Transform.from_quaternion((ax[0] * math.sin(h), ax[1] * math.sin(h), ax[2] * math.sin(h), math.cos(h))).basis
+        elif kin["joint_type"][i] == 2:
+            M[:3, 3] = kin["joint_axis"][i] * qv[i]
+        T[i] = T[p] @ O4 @ M
+    for name, idx in kin["frame_index"].items():
+        assert np.allclose(T[idx][:3, :3], fk[name].basis, atol=1e-12) and np.allclose(T[idx][:3, 3], fk[name].origin, atol=1e-12)

@@ -309,3 +309,36 @@ def test_cpp_facade_example_matches_reference(tmp_path):
     masked = np.fromfile(tmp_path / "o.f32", np.float32).reshape(480, 640)
     mask = np.fromfile(tmp_path / "o.u8", np.uint8).reshape(480, 640)
     fx.check(masked, mask)
+
+
+def test_on_device_forward_kinematics():
+    """Joint positions in, link matrices + head-camera transform computed on the GPU: the matrices agree
+    with the host-side forward kinematics to 1e-12 and the filter output is what the oracle computes
+    from exactly those matrices."""
+    n = 5
+    wl = WL.pr2_workload(n, 320, 240, total_triangles=8000)
+    ctx = R.Context(320, 240, n, 0, params(wl.replace_value, wl.max_diff))
+    ids = wl.load_into(ctx)
+    depth = wl.depth_batch()
+    wl.stage(ctx, ids)
+    host_masked, host_mask = ctx.filter_batch(depth)
+    wl.load_kinematics(ctx, ids)
+    wl.stage_joint_positions(ctx, ids)
+    dev_masked, dev_mask = ctx.filter_batch(depth)
+    L = wl.link_tf[0].shape[1]
+    tf, cam = ctx.read_poses(n, L)
+    assert np.abs(tf - wl.link_tf[0]).max() < 1e-12 and np.abs(cam - wl.cam_tf).max() < 1e-12
+    for s in range(n):
+        draws = []
+        for li, dl in enumerate(wl.models[0]):
+            for d in dl:
+                draws.append((tf[s, li], d.pre_op, d.op, d.verts, d.tris))
+        om, ok = O.filter_frame(depth[s], wl.projection[s], draws, wl.offset_inv[s], cam[s], max_diff=wl.max_diff, replace_value=wl.replace_value)
+        assert (ok != dev_mask[s]).sum() == 0 and bits_equal(om, dev_masked[s])
+    # the two pose sources differ by at most rounding noise in the 16th digit: pixel flips are (almost) impossible
+    assert (host_mask != dev_mask).sum() <= 2
+    # handing explicit matrices again switches the model back to host poses
+    wl.stage(ctx, ids)
+    again_masked, again_mask = ctx.filter_batch(depth)
+    assert np.array_equal(again_mask, host_mask) and bits_equal(again_masked, host_masked)
+    ctx.close()
