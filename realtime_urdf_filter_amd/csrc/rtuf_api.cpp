@@ -71,7 +71,7 @@ struct rtuf_context {
   // rasteriser working set
   int group = 0;                       // in-flight streams per launch group
   uint32_t capacity = 0, fcapacity = 0, clip_capacity = 0;
-  TriRec* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr;
+  PackedTri* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr;
   Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
   Counters* d_counters = nullptr; Counters* h_counters = nullptr;
   float* d_zsurface = nullptr;
@@ -86,6 +86,10 @@ struct rtuf_context {
   // last device batch (for overflow re-run at sync time)
   bool pending = false;
   int last_n = 0; const float* last_depth = nullptr; float* last_masked = nullptr; uint8_t* last_mask = nullptr;
+
+  // host staging areas changed since the last upload?
+  bool dirty_cams = true, dirty_link_tf = true, dirty_mask = true;
+  int uploaded_streams = 0;
 
   rtuf_stats stats{};
   bool timing = false;
@@ -129,7 +133,7 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
 {
   if (!out) return RTUF_ERR_INVALID;
   *out = nullptr;
-  if (width <= 0 || height <= 0 || width > 4096 || height > 4096 || max_streams <= 0) {
+  if (width <= 0 || height <= 0 || width > 2048 || height > 2048 || max_streams <= 0) {
     snprintf(g_create_error, sizeof g_create_error, "invalid size %dx%d or stream count %d", width, height, max_streams);
     return RTUF_ERR_INVALID;
   }
@@ -290,12 +294,12 @@ static int alloc_frame_buffers(rtuf_context* c)
   if (!cap) cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->n_tris + 16, 256), 4096);
   // keep the bins under ~24 GiB by shrinking the in-flight group
   const size_t budget = (size_t)24 << 30;
-  while (G > 1 && (size_t)G * tiles * cap * sizeof(TriRec) > budget) G = (G + 1) / 2;
+  while (G > 1 && (size_t)G * tiles * cap * sizeof(PackedTri) > budget) G = (G + 1) / 2;
   c->group = G;
   c->capacity = cap;
   c->clip_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 8192 / kCounterShards, 1024), (size_t)1 << 22);   // per shard
   c->fcapacity = std::max<uint32_t>(cap, 1024);
-  HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(TriRec)));
+  HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(PackedTri)));
   HIP_TRY(c, hipMalloc(&c->d_bin_count, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(c->d_bin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&c->d_fbins, (size_t)G * tiles * c->fcapacity * sizeof(Frag)));
@@ -437,6 +441,7 @@ int rtuf_set_stream_models(rtuf_context* c, int stream, const int* model_ids, in
     mask |= 1ull << model_ids[i];
   }
   c->h_model_mask[stream] = mask;
+  c->dirty_mask = true;
   return RTUF_OK;
 }
 
@@ -451,6 +456,7 @@ int rtuf_set_camera(rtuf_context* c, int stream, const double projection[16], co
   if (projection) memcpy(cam.projection, projection, sizeof cam.projection);
   if (camera_offset_inv) memcpy(cam.offset_inv, camera_offset_inv, sizeof cam.offset_inv);
   if (camera_tf) memcpy(cam.cam_tf, camera_tf, sizeof cam.cam_tf);
+  c->dirty_cams = true;
   return RTUF_OK;
 }
 
@@ -481,6 +487,7 @@ int rtuf_set_link_poses(rtuf_context* c, int stream, int model, const double* li
   if (n_links != (int)m.links.size()) return c->fail(RTUF_ERR_INVALID, "model %d has %d links, got %d", model, (int)m.links.size(), n_links);
   memcpy(c->h_link_tf + ((size_t)stream * c->n_links + m.link_base) * 16, link_tf, sizeof(double) * 16 * (size_t)n_links);
   if (m.kin.h_enabled) c->models[model].kin.h_enabled[stream] = 0;
+  c->dirty_link_tf = true;
   return RTUF_OK;
 }
 
@@ -496,6 +503,7 @@ int rtuf_set_cameras(rtuf_context* c, int first, int n, const double* projection
     if (offset_inv) memcpy(cam.offset_inv, offset_inv + 16 * (size_t)s, sizeof cam.offset_inv);
     if (cam_tf) memcpy(cam.cam_tf, cam_tf + 16 * (size_t)s, sizeof cam.cam_tf);
   }
+  c->dirty_cams = true;
   return RTUF_OK;
 }
 
@@ -512,6 +520,7 @@ int rtuf_set_link_poses_batch(rtuf_context* c, int first, int n, int model, cons
            sizeof(double) * 16 * (size_t)n_links);
     if (m.kin.h_enabled) c->models[model].kin.h_enabled[first + s] = 0;
   }
+  c->dirty_link_tf = true;
   return RTUF_OK;
 }
 
@@ -630,13 +639,13 @@ static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
   hipFree(c->d_fbins); c->d_fbins = nullptr;
   int G = c->group;
   const size_t budget = (size_t)48 << 30;
-  auto bytes = [&](int g) { return (size_t)g * tiles * ((size_t)cap * sizeof(TriRec) + (size_t)fcap * sizeof(Frag)); };
+  auto bytes = [&](int g) { return (size_t)g * tiles * ((size_t)cap * sizeof(PackedTri) + (size_t)fcap * sizeof(Frag)); };
   while (G > 1 && bytes(G) > budget) G = (G + 1) / 2;
   if (bytes(G) > ((size_t)160 << 30)) return c->fail(RTUF_ERR_CAPACITY, "bin capacity %u/%u too large", cap, fcap);
   c->group = G;
   c->capacity = cap;
   c->fcapacity = fcap;
-  HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(TriRec)));
+  HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(PackedTri)));
   HIP_TRY(c, hipMalloc(&c->d_fbins, (size_t)G * tiles * fcap * sizeof(Frag)));
   c->stats.regrowths++;
   return RTUF_OK;
@@ -650,9 +659,14 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
   const size_t plane = (size_t)c->width * c->height;
   size_t ev = 0;
   if (c->timing) hipEventRecord(get_event(c, ev++), st);
-  HIP_TRY(c, hipMemcpyAsync(c->d_cams, c->h_cams, sizeof(Camera) * n, hipMemcpyHostToDevice, st));
-  HIP_TRY(c, hipMemcpyAsync(c->d_link_tf, c->h_link_tf, sizeof(double) * 16 * L * n, hipMemcpyHostToDevice, st));
-  HIP_TRY(c, hipMemcpyAsync(c->d_model_mask, c->h_model_mask, sizeof(uint64_t) * n, hipMemcpyHostToDevice, st));
+  // only what the host changed since the last batch crosses the bus (with on-device forward
+  // kinematics that is just the joint positions below)
+  const bool more = n > c->uploaded_streams;
+  if (c->dirty_cams || more) HIP_TRY(c, hipMemcpyAsync(c->d_cams, c->h_cams, sizeof(Camera) * n, hipMemcpyHostToDevice, st));
+  if (c->dirty_link_tf || more) HIP_TRY(c, hipMemcpyAsync(c->d_link_tf, c->h_link_tf, sizeof(double) * 16 * L * n, hipMemcpyHostToDevice, st));
+  if (c->dirty_mask || more) HIP_TRY(c, hipMemcpyAsync(c->d_model_mask, c->h_model_mask, sizeof(uint64_t) * n, hipMemcpyHostToDevice, st));
+  c->dirty_cams = c->dirty_link_tf = c->dirty_mask = false;
+  c->uploaded_streams = std::max(c->uploaded_streams, n);
   HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(Counters), st));
   // on-device forward kinematics overwrites the link matrices (and camera) of the streams that use it
   for (HostModel& m : c->models) {

@@ -14,7 +14,7 @@
 //     mvp    f32[N][D][16]  written by pose_kernel
 //     depth  f32[N][H][W] in, masked f32[N][H][W] + mask u8[N][H][W] out
 //   rasteriser working set, per in-flight stream g and screen tile
-//     bin_count u32[G][tiles], bins TriRec[G][tiles][capacity]     (triangles, 64 B records)
+//     bin_count u32[G][tiles], bins PackedTri[G][tiles][capacity]  (triangles, 32 B records)
 //     fbin_count u32[G][tiles], fbins Frag[G][tiles][fcapacity]    (pixels of tiny triangles, 16 B)
 //     clip_list ClipItem[], zsurface f32[G][H][W] (two-kernel mode only)
 #pragma once
@@ -46,6 +46,14 @@ struct alignas(16) TriRec {     // 64 B: one rasterisable triangle inside one ti
   uint32_t pad;
 };
 static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
+
+struct alignas(16) PackedTri {  // 32 B: what a triangle bin stores; the tile kernel rebuilds TriRec from it
+  unsigned long long v01;       // (x0+128) | (y0+128) << 20 | (x1+128) << 40   snapped 1/256-px coordinates,
+  unsigned long long v12;       // (y1+128) | (x2+128) << 20 | (y2+128) << 40   already oriented (area > 0)
+  float a0, dzdx, dzdy;         // z plane
+  uint32_t order;
+};
+static_assert(sizeof(PackedTri) == 32, "PackedTri must be 32 bytes");
 
 struct alignas(16) Frag {       // 16 B: one covered pixel of a tiny (<= 2x2 px bounding box) triangle
   uint32_t xy;                  // x | y << 16
@@ -137,7 +145,7 @@ struct SetupArgs {
   const float* mvp;              // [n_streams][n_draws + 1][16]
   const uint64_t* model_mask;    // [n_streams] bit m set: stream renders model m
   const uint32_t* bg_mode;       // [n_streams]
-  TriRec* bins;                  // [G][tiles][capacity]   triangles with a bounding box > 2x2 px
+  PackedTri* bins;               // [G][tiles][capacity]   triangles with a bounding box > 2x2 px
   uint32_t* bin_count;           // [G][tiles]
   Frag* fbins;                   // [G][tiles][fcapacity]  covered pixels of the tiny triangles
   uint32_t* fbin_count;          // [G][tiles]
@@ -154,7 +162,7 @@ struct SetupArgs {
 };
 
 struct TileArgs {
-  const TriRec* bins;
+  const PackedTri* bins;
   uint32_t* bin_count;           // reset to 0 by this kernel after use
   const Frag* fbins;
   uint32_t* fbin_count;          // reset to 0 by this kernel after use

@@ -310,10 +310,36 @@ __device__ __forceinline__ int snap(float v)
   return __float2int_rn(__fmul_rn(__fsub_rn(v, 0.5f), 256.0f));
 }
 
+// Integer edge functions + bounding box of an ORIENTED (area > 0) snapped triangle.  Used by the
+// set-up kernel (fragment path) and by the tile kernel when it unpacks a 32-byte bin record.
+__device__ __forceinline__ void edges_from_snapped(int x0, int y0, int x1, int y1, int x2, int y2, int width, int height,
+                                                   TriRec& r)
+{
+  const int minx = min(x0, min(x1, x2)), maxx = max(x0, max(x1, x2));
+  const int miny = min(y0, min(y1, y2)), maxy = max(y0, max(y1, y2));
+  const int bx0 = max((minx + 255) >> 8, 0), bx1 = min((maxx - 1) >> 8, width - 1);
+  const int by0 = max((miny + 255) >> 8, 0), by1 = min((maxy - 1) >> 8, height - 1);
+  const int xs[3] = {x0, x1, x2}, ys[3] = {y0, y1, y2};
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int j = (i + 1) % 3;
+    const int dcdx = ys[i] - ys[j];
+    const int dcdy = xs[i] - xs[j];
+    long long c = (long long)dcdx * xs[i] - (long long)dcdy * ys[i];
+    if (dcdx < 0 || (dcdx == 0 && dcdy > 0)) c += 1;   // inclusive on low-x / low-row edges
+    // inside <=> c - dcdx*256*px + dcdy*256*py > 0  <=>  ceil(c/256) - dcdx*px + dcdy*py > 0
+    r.A[i] = -dcdx;
+    r.B[i] = dcdy;
+    r.C[i] = (int)(-((-c) >> 8));
+  }
+  r.bbx = (uint32_t)bx0 | ((uint32_t)bx1 << 16);
+  r.bby = (uint32_t)by0 | ((uint32_t)by1 << 16);
+}
+
 // Builds the raster record of one window-space triangle.  Returns false when it covers no
-// pixel centre of the width x height frame.
+// pixel centre of the width x height frame.  `pk` receives the 32-byte bin form.
 __device__ __forceinline__ bool make_record(Win v0, Win v1, Win v2, uint32_t order, int width, int height,
-                                            TriRec& r)
+                                            TriRec& r, PackedTri& pk)
 {
   int x0 = snap(v0.x), y0 = snap(v0.y);
   int x1 = snap(v1.x), y1 = snap(v1.y);
@@ -333,20 +359,7 @@ __device__ __forceinline__ bool make_record(Win v0, Win v1, Win v2, uint32_t ord
     t = y0; y0 = y1; y1 = t;
     Win tw = v0; v0 = v1; v1 = tw;
   }
-
-  const int xs[3] = {x0, x1, x2}, ys[3] = {y0, y1, y2};
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    const int j = (i + 1) % 3;
-    const int dcdx = ys[i] - ys[j];
-    const int dcdy = xs[i] - xs[j];
-    long long c = (long long)dcdx * xs[i] - (long long)dcdy * ys[i];
-    if (dcdx < 0 || (dcdx == 0 && dcdy > 0)) c += 1;   // inclusive on low-x / low-row edges
-    // inside <=> c - dcdx*256*px + dcdy*256*py > 0  <=>  ceil(c/256) - dcdx*px + dcdy*py > 0
-    r.A[i] = -dcdx;
-    r.B[i] = dcdy;
-    r.C[i] = (int)(-((-c) >> 8));
-  }
+  edges_from_snapped(x0, y0, x1, y1, x2, y2, width, height, r);
   // z plane from the unsnapped float vertices
   const float x0c = __fsub_rn(v0.x, 0.5f), y0c = __fsub_rn(v0.y, 0.5f);
   const float dx01 = __fsub_rn(v0.x, v1.x), dy01 = __fsub_rn(v0.y, v1.y);
@@ -358,24 +371,35 @@ __device__ __forceinline__ bool make_record(Win v0, Win v1, Win v2, uint32_t ord
   r.dzdx = __fsub_rn(__fmul_rn(da01, dy20o), __fmul_rn(da20, dy01o));
   r.dzdy = __fsub_rn(__fmul_rn(da20, dx01o), __fmul_rn(da01, dx20o));
   r.a0 = __fsub_rn(v0.z, __fadd_rn(__fmul_rn(r.dzdx, x0c), __fmul_rn(r.dzdy, y0c)));
-  r.bbx = (uint32_t)bx0 | ((uint32_t)bx1 << 16);
-  r.bby = (uint32_t)by0 | ((uint32_t)by1 << 16);
   r.order = order;
   r.pad = 0;
+  // snapped coordinates of in-frustum vertices lie in [-128, 2048*256]: 20 bits after the +128 bias
+  pk.v01 = (unsigned long long)(uint32_t)(x0 + 128) | ((unsigned long long)(uint32_t)(y0 + 128) << 20) | ((unsigned long long)(uint32_t)(x1 + 128) << 40);
+  pk.v12 = (unsigned long long)(uint32_t)(y1 + 128) | ((unsigned long long)(uint32_t)(x2 + 128) << 20) | ((unsigned long long)(uint32_t)(y2 + 128) << 40);
+  pk.a0 = r.a0; pk.dzdx = r.dzdx; pk.dzdy = r.dzdy; pk.order = order;
   return true;
 }
 
+__device__ __forceinline__ TriRec unpack_record(const PackedTri& pk, int width, int height)
+{
+  TriRec r;
+  const int x0 = (int)(pk.v01 & 0xfffffu) - 128, y0 = (int)((pk.v01 >> 20) & 0xfffffu) - 128, x1 = (int)((pk.v01 >> 40) & 0xfffffu) - 128;
+  const int y1 = (int)(pk.v12 & 0xfffffu) - 128, x2 = (int)((pk.v12 >> 20) & 0xfffffu) - 128, y2 = (int)((pk.v12 >> 40) & 0xfffffu) - 128;
+  edges_from_snapped(x0, y0, x1, y1, x2, y2, width, height, r);
+  r.a0 = pk.a0; r.dzdx = pk.dzdx; r.dzdy = pk.dzdy; r.order = pk.order; r.pad = 0;
+  return r;
+}
 
-__device__ __forceinline__ void store_record(TriRec* dst, const TriRec& r)
+__device__ __forceinline__ void store_record(PackedTri* dst, const PackedTri& r)
 {
   const uint4* s = reinterpret_cast<const uint4*>(&r);
   uint4* d = reinterpret_cast<uint4*>(dst);
-  d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+  d[0] = s[0]; d[1] = s[1];
 }
 
 // Appends the record to every tile bin its bounding box touches (one lane, plain atomics):
 // used by the rare clip path.
-__device__ __forceinline__ uint32_t emit_record(const SetupArgs& a, int slot, const TriRec& r)
+__device__ __forceinline__ uint32_t emit_record(const SetupArgs& a, int slot, const TriRec& r, const PackedTri& pk)
 {
   const int tx0 = (int)(r.bbx & 0xffff) / kTileW, tx1 = (int)(r.bbx >> 16) / kTileW;
   const int ty0 = (int)(r.bby & 0xffff) / kTileH, ty1 = (int)(r.bby >> 16) / kTileH;
@@ -385,7 +409,7 @@ __device__ __forceinline__ uint32_t emit_record(const SetupArgs& a, int slot, co
     for (int tx = tx0; tx <= tx1; tx++) {
       const size_t bin = (size_t)slot * tiles + (size_t)ty * a.tiles_x + tx;
       const uint32_t pos = atomicAdd(&a.bin_count[bin], 1u);
-      if (pos < a.capacity) store_record(a.bins + bin * a.capacity + pos, r);
+      if (pos < a.capacity) store_record(a.bins + bin * a.capacity + pos, pk);
       n++;
     }
   return n;
@@ -396,7 +420,7 @@ __device__ __forceinline__ uint32_t emit_record(const SetupArgs& a, int slot, co
 // atomicAdd in the SAME instruction, so a wave pays one atomic round trip per tile index
 // instead of one per distinct bin; group members get consecutive slots, which makes the
 // 64-byte record stores of neighbouring mesh triangles contiguous.
-__device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slot, bool have, const TriRec& r)
+__device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slot, bool have, const TriRec& r, const PackedTri& pk)
 {
   const int lane = threadIdx.x & 63;
   int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
@@ -431,7 +455,7 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slo
     base = __shfl(base, myleader);
     if (act) {
       const uint32_t pos = base + (uint32_t)__popcll(mymask & ((1ull << lane) - 1ull));
-      if (pos < a.capacity) store_record(a.bins + (size_t)bin * a.capacity + pos, r);
+      if (pos < a.capacity) store_record(a.bins + (size_t)bin * a.capacity + pos, pk);
       n++;
     }
   }
@@ -450,9 +474,10 @@ __device__ __forceinline__ uint32_t z24_of(float z)
 
 __device__ __forceinline__ bool inside(const TriRec& r, int px, int py)
 {
-  const int e0 = r.A[0] * px + r.B[0] * py + r.C[0];
-  const int e1 = r.A[1] * px + r.B[1] * py + r.C[1];
-  const int e2 = r.A[2] * px + r.B[2] * py + r.C[2];
+  // |A|, |B| < 2^20 and px, py < 2^11: 24-bit multiplies (full rate) are exact
+  const int e0 = __mul24(r.A[0], px) + __mul24(r.B[0], py) + r.C[0];
+  const int e1 = __mul24(r.A[1], px) + __mul24(r.B[1], py) + r.C[1];
+  const int e2 = __mul24(r.A[2], px) + __mul24(r.B[2], py) + r.C[2];
   return (e0 > 0) & (e1 > 0) & (e2 > 0);
 }
 
@@ -653,6 +678,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
     const uint32_t j = base + tid;
     bool have = false;
     TriRec r;
+    PackedTri pk;
     int slot = 0;
     if (j < nlist) {
       const uint32_t e = s_list[j];
@@ -664,7 +690,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
       v0.x = w0.x; v0.y = w0.y; v0.z = w0.z;
       v1.x = w1.x; v1.y = w1.y; v1.z = w1.z;
       v2.x = w2.x; v2.y = w2.y; v2.z = w2.z;
-      have = make_record(v0, v1, v2, is_bg ? 0u : ch.order_base + (uint32_t)t, a.width, a.height, r);
+      have = make_record(v0, v1, v2, is_bg ? 0u : ch.order_base + (uint32_t)t, a.width, a.height, r, pk);
     }
     if (__ballot(have)) {
       // Tiny triangles (bounding box <= 2x2 pixel centres) are resolved to their covered pixels
@@ -673,7 +699,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
       const int by0 = (int)(r.bby & 0xffff), by1 = (int)(r.bby >> 16);
       const bool tiny = have && (bx1 - bx0) <= 1 && (by1 - by0) <= 1;
       nfrag += emit_fragments_wave(a, slot, tiny, r, bx0, bx1, by0, by1);
-      entries += emit_record_wave(a, slot, have && !tiny, r);
+      entries += emit_record_wave(a, slot, have && !tiny, r, pk);
       binned += have ? 1u : 0u;
     }
   }
@@ -799,9 +825,10 @@ __device__ void clip_one(const SetupArgs& a, const ClipItem it, int shard_id)
   uint32_t binned = 0, entries = 0;
   for (int i = 2; i < nv; i++) {
     TriRec r;
-    if (make_record(pool[inl[i - 1]].w, pool[inl[i]].w, pool[inl[0]].w, order, a.width, a.height, r)) {
+    PackedTri pk;
+    if (make_record(pool[inl[i - 1]].w, pool[inl[i]].w, pool[inl[0]].w, order, a.width, a.height, r, pk)) {
       binned++;
-      entries += emit_record(a, slot, r);
+      entries += emit_record(a, slot, r, pk);
     }
   }
   if (binned) {
@@ -851,19 +878,31 @@ __device__ __forceinline__ TriRec broadcast_record(const TriRec& r, int src_lane
 // (no workgroup barrier inside): lane-per-triangle for tiny bounding boxes, the whole wave in
 // 8x8 stamps for anything larger.
 template <int MODE>
-__device__ __forceinline__ void raster_bin(unsigned long long* keys, const TriRec* recs, uint32_t n,
-                                           int x_base, int y_base, int tid, bool dbg_load_only)
+__device__ __forceinline__ void raster_bin(unsigned long long* keys, const PackedTri* recs, uint32_t n,
+                                           int x_base, int y_base, int tid, bool dbg_load_only, int width, int height)
 {
   const int lane = tid & 63;
+  // software pipeline: the records of batch b+1 are in flight while batch b is rasterised
+  uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = nx0;
+  if ((uint32_t)tid < n) {
+    const uint4* src = reinterpret_cast<const uint4*>(recs + tid);
+    nx0 = src[0]; nx1 = src[1];
+  }
   for (uint32_t base = 0; base < n; base += kBlock) {
     const uint32_t i = base + tid;
     const bool have = i < n;
+    const uint4 c0 = nx0, c1 = nx1;
+    if (i + kBlock < n) {
+      const uint4* src = reinterpret_cast<const uint4*>(recs + i + kBlock);
+      nx0 = src[0]; nx1 = src[1];
+    }
     TriRec r;
     int lx0 = 0, lx1 = -1, ly0 = 0, ly1 = -1;
     if (have) {
-      const uint4* src = reinterpret_cast<const uint4*>(recs + i);
-      uint4* dst = reinterpret_cast<uint4*>(&r);
-      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+      PackedTri pk;
+      uint4* dst = reinterpret_cast<uint4*>(&pk);
+      dst[0] = c0; dst[1] = c1;
+      r = unpack_record(pk, width, height);
       lx0 = max((int)(r.bbx & 0xffff) - x_base, 0);
       lx1 = min((int)(r.bbx >> 16) - x_base, kTileW - 1);
       ly0 = max((int)(r.bby & 0xffff) - y_base, 0);
@@ -914,11 +953,12 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const TriRe
       const int qw = qx1 - qx0 + 1;
       const int qarea = src < 0 ? 0 : qw * (qy1 - qy0 + 1);
       // idx / qw for idx < 4096, qw <= 64 via an exact reciprocal multiply
-      const uint32_t inv = (uint32_t)ceilf(__fdiv_rn(65536.0f, (float)max(qw, 1)));
+      // (1 ulp of v_rcp_f32 is ~0.004 here, the fractional part of 65536/qw is 0 or >= 1/64)
+      const uint32_t inv = (uint32_t)ceilf(65536.0f * __builtin_amdgcn_rcpf((float)max(qw, 1)));
       for (int idx = sub; __ballot(idx < qarea); idx += 16) {
         if (idx < qarea) {
-          const int yy = (int)(((uint32_t)idx * inv) >> 16);
-          const int lx = qx0 + idx - yy * qw, ly = qy0 + yy;
+          const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 16);
+          const int lx = qx0 + idx - __mul24(yy, qw), ly = qy0 + yy;
           const int px = x_base + lx, py = y_base + ly;
           if (inside(q, px, py)) fragment<MODE>(keys, q, px, py, ly * kTileW + lx);
         }
@@ -981,8 +1021,19 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
   const ShadeConsts sc = shade_consts(a.z_near, a.z_far, a.max_diff, a.replace_value);
 
   const uint32_t count = a.bin_count[bin], fcount = a.fbin_count[bin];
+  // The sensor pixels this lane will resolve are requested before anything else so that their HBM
+  // latency overlaps the bin-counter round trip and all of the rasterisation.
+  constexpr int kLanesPerRow = kTileW / 4, kRowsPerPass = kBlock / kLanesPerRow;
+  static_assert(kRowsPerPass >= kTileH, "one resolve pass per tile expected");
+  const bool vec = (a.width & 3) == 0;
+  const int r_ly = tid / kLanesPerRow, r_lx = (tid % kLanesPerRow) * 4;
+  const int r_px = x_base + r_lx, r_py = y_base + r_ly;
+  const bool r_valid = r_ly < kTileH && r_py < a.height && r_px < a.width;
+  const size_t gofs = ((size_t)stream * a.height + r_py) * a.width + r_px;
+  float4 sens = make_float4(0, 0, 0, 0);
+  if (!TWO_KERNEL && r_valid && vec) sens = *reinterpret_cast<const float4*>(a.depth + gofs);
   const uint32_t n = min(count, a.capacity), nf = min(fcount, a.fcapacity);
-  const TriRec* recs = a.bins + (size_t)bin * a.capacity;
+  const PackedTri* recs = a.bins + (size_t)bin * a.capacity;
   const uint4* frags = reinterpret_cast<const uint4*>(a.fbins) + (size_t)bin * a.fcapacity;
   // flags bits 8.. are timing experiments only (wrong results): 0x100 skip rasterisation, 0x200 skip pixel loops
   const bool empty = (n == 0 && nf == 0) || (a.flags & 0x100u);   // no geometry in this tile: pure streaming compare
@@ -996,8 +1047,8 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
       if (count) atomicMax(&sh.max_bin_fill, count);
       if (fcount) atomicMax(&sh.max_fbin_fill, fcount);
     }
-    raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0);
-    raster_frags<0>(keys, frags, nf, x_base, y_base, tid);
+    if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height);
+    if (!(a.flags & 0x400u)) raster_frags<0>(keys, frags, nf, x_base, y_base, tid);
     __syncthreads();
 
     // Does any pixel need the exact float z of its winner?  Only when the winning depth is in the
@@ -1008,20 +1059,15 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
       if (k != bgkey && (uint32_t)(k >> 32) <= 8388608u) need = true;
     }
     if (__syncthreads_or(need)) {
-      raster_bin<1>(keys, recs, n, x_base, y_base, tid, false);
+      raster_bin<1>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height);
       raster_frags<1>(keys, frags, nf, x_base, y_base, tid);
       __syncthreads();
     }
   }
 
-  // resolve: 16 lanes x 4 pixels per tile row, 16 rows per pass
-  const bool vec = (a.width & 3) == 0;
-  constexpr int kLanesPerRow = kTileW / 4, kRowsPerPass = kBlock / kLanesPerRow;
-  for (int pass = 0; pass < (kTileH + kRowsPerPass - 1) / kRowsPerPass; pass++) {
-    const int ly = pass * kRowsPerPass + tid / kLanesPerRow, lx = (tid % kLanesPerRow) * 4;
-    if (ly >= kTileH) continue;
-    const int px = x_base + lx, py = y_base + ly;
-    if (py >= a.height || px >= a.width) continue;
+  // resolve: kLanesPerRow lanes x 4 pixels per tile row, the whole tile in one pass
+  if (r_valid) {
+    const int ly = r_ly, lx = r_lx, px = r_px, py = r_py;
     float z[4];
     bool frag[4];
 #pragma unroll
@@ -1032,7 +1078,6 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
       else if (k == bgkey) { z[j] = bgz; frag[j] = analytic_bg; }
       else z[j] = __fmul_rn((float)((uint32_t)(k >> 32) + 1u), 5.9604644775390625e-08f);
     }
-    const size_t gofs = ((size_t)stream * a.height + py) * a.width + px;
     const int nvalid = min(4, a.width - px);
     if (TWO_KERNEL) {
       const size_t zofs = ((size_t)slot * a.height + py) * a.width + px;
@@ -1044,8 +1089,7 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
     } else {
       float s[4];
       if (vec) {
-        const float4 v = *reinterpret_cast<const float4*>(a.depth + gofs);
-        s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
+        s[0] = sens.x; s[1] = sens.y; s[2] = sens.z; s[3] = sens.w;
       } else {
         for (int j = 0; j < 4; j++) s[j] = j < nvalid ? a.depth[gofs + j] : 0.0f;
       }
