@@ -342,3 +342,52 @@ def test_on_device_forward_kinematics():
     again_masked, again_mask = ctx.filter_batch(depth)
     assert np.array_equal(again_mask, host_mask) and bits_equal(again_masked, host_masked)
     ctx.close()
+
+
+def test_config_c4_720p_pr2_plus_walls():
+    """BASELINE config 4 shape: 1280x720, PR2-like robot + two static wall URDFs (full-screen boxes incl.
+    quirk Q1: exercises the large-triangle path), several streams."""
+    n = 3
+    wl = WL.pr2_workload(n, 1280, 720, total_triangles=20000, walls=True)
+    ctx = R.Context(1280, 720, n, 0, params(wl.replace_value, wl.max_diff))
+    ids = wl.load_into(ctx)
+    wl.stage(ctx, ids)
+    depth = wl.depth_batch()
+    masked, mask = ctx.filter_batch(depth)
+    for s in range(n):
+        om, ok = O.filter_frame(depth[s], wl.projection[s], wl.oracle_draws(s), wl.offset_inv[s], wl.cam_tf[s],
+                                max_diff=wl.max_diff, replace_value=wl.replace_value)
+        assert (ok != mask[s]).sum() == 0 and bits_equal(om, masked[s])
+    ctx.close()
+
+
+def test_config_c5_distinct_urdfs_share_a_context():
+    """BASELINE config 5 shape: several distinct articulated URDFs, a few streams each, one context per
+    GPU; every stream renders only its own robot (rtuf_set_stream_models)."""
+    robots = [WL.pr2_workload(3, 320, 240, total_triangles=t, seed=sd, first_state_seed=fs)
+              for t, sd, fs in ((3000, 7, 3000), (6000, 8, 3100), (4500, 9, 3200), (9000, 10, 3300))]
+    n = 3 * len(robots)
+    ctx = R.Context(320, 240, n, 0, params())
+    mids = []
+    for wl in robots:
+        m = ctx.add_model()
+        for draws in wl.models[0]:
+            l = ctx.add_link(m)
+            for d in draws:
+                ctx.add_draw(m, l, d.verts, d.tris, d.pre_op, d.op)
+        mids.append(m)
+    ctx.finalize_models()
+    depth = np.stack([S.sensor_depth(320, 240, 0.11 * s) for s in range(n)])
+    for r, wl in enumerate(robots):
+        for k in range(3):
+            s = 3 * r + k
+            ctx.set_camera(s, wl.projection[k], wl.offset_inv[k], wl.cam_tf[k])
+            ctx.set_stream_models(s, [mids[r]])
+            ctx.set_link_poses(s, mids[r], wl.link_tf[0][k])
+    masked, mask = ctx.filter_batch(depth)
+    for r, wl in enumerate(robots):
+        for k in range(3):
+            s = 3 * r + k
+            om, ok = O.filter_frame(depth[s], wl.projection[k], wl.oracle_draws(k), wl.offset_inv[k], wl.cam_tf[k], replace_value=5.0)
+            assert (ok != mask[s]).sum() == 0 and bits_equal(om, masked[s]), "robot %d stream %d" % (r, k)
+    ctx.close()
