@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--variants", type=int, default=2, help="distinct input batches rotated through the steps")
     ap.add_argument("--two-kernel", action="store_true", help="rasteriser + separate compare kernel")
     ap.add_argument("--host-poses", action="store_true", help="stage explicit link matrices from the host instead of joint positions + on-device forward kinematics")
+    ap.add_argument("--u16", action="store_true", help="16UC1 depth in/out (uint16 millimetres) with the conversions fused into the kernels")
     ap.add_argument("--no-mask", action="store_true", help="need_mask_ == false: no mask output")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--debug-flags", type=lambda x: int(x, 0), default=0, help="timing experiments only (results are wrong)")
@@ -84,8 +85,10 @@ def main():
     d_depth = []
     for v, wl in enumerate(variants):
         host = np.stack([wl.depth(s + 7 * v + 1000 * rank) for s in range(n)])
+        if args.u16:
+            host = np.clip(np.rint(np.nan_to_num(host, nan=0.0, posinf=0.0) * 1000.0), 0, 65535).astype(np.uint16).view(np.int16)
         d_depth.append(torch.from_numpy(host).to(dev))
-    d_masked = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+    d_masked = torch.empty((n, H, W), dtype=torch.int16 if args.u16 else torch.float32, device=dev)
     d_mask = None if args.no_mask else torch.empty((n, H, W), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
@@ -95,7 +98,7 @@ def main():
             variants[v].stage(ctx, ids)
         else:
             variants[v].stage_joint_positions(ctx, ids)      # joint angles in, forward kinematics on the GPU
-        ctx.filter_batch_device(n, d_depth[v].data_ptr(), d_masked.data_ptr(), d_mask.data_ptr() if d_mask is not None else 0)
+        (ctx.filter_batch_device_u16 if args.u16 else ctx.filter_batch_device)(n, d_depth[v].data_ptr(), d_masked.data_ptr(), d_mask.data_ptr() if d_mask is not None else 0)
         ctx.sync()
 
     def barrier():
@@ -137,7 +140,8 @@ def main():
         if two:
             cands = {"tile_kernel<two_kernel>": (per["ms_raster"], 4 * px * n), "compare_kernel": (per["ms_compare"], (13 if d_mask is not None else 12) * px * n)}
         else:
-            cands = {"tile_kernel<fused>": (per["ms_raster"], (9 if d_mask is not None else 8) * px * n)}
+            bpp = (4 if args.u16 else 8) + (1 if d_mask is not None else 0)
+            cands = {"tile_kernel<fused>": (per["ms_raster"], bpp * px * n)}
         cands["setup_kernel+clip_kernel"] = (per["ms_setup"], 12 * wl0.n_vertices() + 16 * wl0.n_triangles())
         dom = max((k for k in cands if not k.startswith("setup")), key=lambda k: cands[k][0])
         dur_ms, alg_bytes = cands[dom]
@@ -149,7 +153,7 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
             if (tj["kernel"] == dom and tj["streams"] == n and tj["width"] == W and tj["height"] == H
-                    and tj["triangles"] == wl0.meta["triangles"] and d_mask is not None):
+                    and tj["triangles"] == wl0.meta["triangles"] and d_mask is not None and not args.u16):
                 traffic = tj["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -157,7 +161,7 @@ def main():
             "metric": "filtered depth frames/sec (640x480, PR2 URDF)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "depth_format": "16UC1" if args.u16 else "32FC1",
             "config": {"workload": "C3: %dx%d depth, synthetic PR2-like URDF (%d links with meshes, %d triangles), batch=%d concurrent streams per GPU, new joint state + camera pose every step"
                                    % (W, H, wl0.meta["links_with_geometry"], wl0.meta["triangles"], n),
                        "streams_per_gpu": n, "poses": "host matrices" if args.host_poses else "joint positions, forward kinematics on the GPU", "mode": "two-kernel" if two else "fused", "mask_output": d_mask is not None,
@@ -176,11 +180,15 @@ def main():
         # ---- parity spot check + CPU baseline (oracle = checker / reported baseline only) ------
         if world == 1:
             from oracle import bindings as O
+            from realtime_urdf_filter_amd.filter import depth_f32_to_u16, depth_u16_to_f32
             v_last = (args.warmup + args.steps - 1) % len(variants)
             wl = variants[v_last]
             hm = d_masked.cpu().numpy()
             hk = d_mask.cpu().numpy() if d_mask is not None else None
             hd = d_depth[v_last].cpu().numpy()
+            if args.u16:
+                hm = hm.view(np.uint16)
+                hd = depth_u16_to_f32(hd.view(np.uint16))
             if args.host_poses:
                 link_tf_all, cam_all = wl.link_tf[0], wl.cam_tf
             else:
@@ -201,7 +209,7 @@ def main():
                 n_cpu += 1
                 if hk is not None:
                     bad_mask += int((ok != hk[s]).sum())
-                bad_depth += int((om.view(np.uint32) != hm[s].view(np.uint32)).sum())
+                bad_depth += int((depth_f32_to_u16(om) != hm[s]).sum()) if args.u16 else int((om.view(np.uint32) != hm[s].view(np.uint32)).sum())
                 s += 1
             out["parity"] = {"frames_checked": n_cpu, "mask_mismatch_pixels": bad_mask, "depth_mismatch_pixels": bad_depth}
             if n_cpu:

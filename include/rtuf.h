@@ -170,6 +170,14 @@ int rtuf_filter_batch(rtuf_context *ctx, int n_streams, const float *const *dept
  * NULL.  Asynchronous on the context's stream; rtuf_sync() waits. */
 int rtuf_filter_batch_device(rtuf_context *ctx, int n_streams, const float *d_depth,
                              float *d_masked, uint8_t *d_mask);
+/* 16UC1 variants: depth in / out as uint16 millimetres with the reference's conversions fused into the
+ * kernels (filter_callback, src/urdf_filter.cpp:280-289: convertTo(CV_32F, 0.001); :308-312:
+ * convertTo(CV_16U, 1000.0), i.e. filtered pixels become filter_replace_value * 1000).  Halves the
+ * HBM and PCIe bytes per pixel (5 instead of 9). */
+int rtuf_filter_batch_u16(rtuf_context *ctx, int n_streams, const uint16_t *const *depth_mm_in,
+                          uint16_t *const *masked_mm_out, uint8_t *const *mask_out);
+int rtuf_filter_batch_device_u16(rtuf_context *ctx, int n_streams, const uint16_t *d_depth_mm,
+                                 uint16_t *d_masked_mm, uint8_t *d_mask);
 /* Exact single-stream shape of RealtimeURDFFilter::filter(buffer, glTf, w, h)
  * (include/realtime_urdf_filter/urdf_filter.h:70-72): stream 0, projection given per call,
  * results kept in library-owned host buffers like masked_depth_/mask_. */

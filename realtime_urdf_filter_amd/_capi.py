@@ -24,7 +24,7 @@ SYMBOLS = [
     "rtuf_set_params", "rtuf_add_model", "rtuf_add_link", "rtuf_add_draw", "rtuf_finalize_models",
     "rtuf_num_links", "rtuf_num_triangles", "rtuf_set_stream_models", "rtuf_set_camera",
     "rtuf_projection_from_intrinsics", "rtuf_set_link_poses", "rtuf_set_cameras", "rtuf_set_link_poses_batch", "rtuf_set_kinematics", "rtuf_set_joint_positions", "rtuf_debug_read_poses", "rtuf_filter_batch",
-    "rtuf_filter_batch_device", "rtuf_filter", "rtuf_get_masked_depth", "rtuf_get_mask", "rtuf_sync",
+    "rtuf_filter_batch_device", "rtuf_filter_batch_u16", "rtuf_filter_batch_device_u16", "rtuf_filter", "rtuf_get_masked_depth", "rtuf_get_mask", "rtuf_sync",
     "rtuf_stream", "rtuf_get_stats", "rtuf_enable_timing", "rtuf_debug_read_zsurface",
 ]
 
@@ -96,6 +96,8 @@ def load_library(path=None):
     lib.rtuf_debug_read_poses.argtypes = [vp, ci, vp, vp]
     lib.rtuf_filter_batch.argtypes = [vp, ci, vp, vp, vp]
     lib.rtuf_filter_batch_device.argtypes = [vp, ci, vp, vp, vp]
+    lib.rtuf_filter_batch_u16.argtypes = [vp, ci, vp, vp, vp]
+    lib.rtuf_filter_batch_device_u16.argtypes = [vp, ci, vp, vp, vp]
     lib.rtuf_filter.argtypes = [vp, vp, vp, ci, ci]
     lib.rtuf_get_masked_depth.argtypes = [vp]
     lib.rtuf_get_masked_depth.restype = ctypes.POINTER(ctypes.c_float)
@@ -242,6 +244,23 @@ class Context:
         kout = PP(*[mask[i].ctypes.data for i in range(n)]) if want_mask else None
         self._check(self._lib.rtuf_filter_batch(self._h, n, din, mout, kout))
         return masked, mask
+
+    def filter_batch_u16(self, depth_mm, want_mask=True):
+        """16UC1: depth_mm [n,H,W] uint16 millimetres -> (masked uint16 [n,H,W], mask)."""
+        d = np.ascontiguousarray(depth_mm, np.uint16).reshape(-1, self.height, self.width)
+        n = d.shape[0]
+        masked = np.empty_like(d)
+        mask = np.empty(d.shape, np.uint8) if want_mask else None
+        PP = ctypes.c_void_p * n
+        din = PP(*[d[i].ctypes.data for i in range(n)])
+        mout = PP(*[masked[i].ctypes.data for i in range(n)])
+        kout = PP(*[mask[i].ctypes.data for i in range(n)]) if want_mask else None
+        self._check(self._lib.rtuf_filter_batch_u16(self._h, n, din, mout, kout))
+        return masked, mask
+
+    def filter_batch_device_u16(self, n, d_depth, d_masked, d_mask=None):
+        self._check(self._lib.rtuf_filter_batch_device_u16(self._h, n, ctypes.c_void_p(d_depth), ctypes.c_void_p(d_masked),
+                                                           ctypes.c_void_p(d_mask) if d_mask else None))
 
     def filter_batch_device(self, n, d_depth, d_masked, d_mask=None):
         """Device pointers (ints): enqueue only; call sync()."""

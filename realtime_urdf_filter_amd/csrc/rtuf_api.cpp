@@ -86,6 +86,7 @@ struct rtuf_context {
   // last device batch (for overflow re-run at sync time)
   bool pending = false;
   int last_n = 0; const float* last_depth = nullptr; float* last_masked = nullptr; uint8_t* last_mask = nullptr;
+  bool last_u16 = false;
 
   // host staging areas changed since the last upload?
   bool dirty_cams = true, dirty_link_tf = true, dirty_mask = true;
@@ -651,8 +652,9 @@ static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
   return RTUF_OK;
 }
 
-static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask)
+static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask, bool io_u16)
 {
+  const size_t esz = io_u16 ? sizeof(uint16_t) : sizeof(float);
   hipStream_t st = c->stream;
   const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
   const size_t L = (size_t)std::max(c->n_links, 1);
@@ -712,12 +714,14 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
     ta.tiles_x = c->tiles_x; ta.tiles_y = c->tiles_y; ta.capacity = c->capacity; ta.flags = c->params.flags;
     ta.z_near = c->params.near_plane; ta.z_far = c->params.far_plane;
     ta.max_diff = c->params.depth_distance_threshold; ta.replace_value = c->params.filter_replace_value;
+    ta.io_u16 = io_u16 ? 1 : 0;
     launch_tile(ta, two, st);
     if (c->timing) hipEventRecord(get_event(c, ev++), st);
     if (two) {
       CompareArgs ca{};
-      ca.depth = d_depth + (size_t)base * plane; ca.zsurface = c->d_zsurface;
-      ca.masked = d_masked + (size_t)base * plane; ca.mask = d_mask ? d_mask + (size_t)base * plane : nullptr;
+      ca.depth = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_depth) + (size_t)base * plane * esz); ca.zsurface = c->d_zsurface;
+      ca.masked = reinterpret_cast<float*>(reinterpret_cast<char*>(d_masked) + (size_t)base * plane * esz);
+      ca.io_u16 = io_u16 ? 1 : 0; ca.mask = d_mask ? d_mask + (size_t)base * plane : nullptr;
       ca.n_pixels = (size_t)gs * plane;
       ca.z_near = ta.z_near; ca.z_far = ta.z_far; ca.max_diff = ta.max_diff; ca.replace_value = ta.replace_value;
       launch_compare(ca, st);
@@ -739,7 +743,25 @@ int rtuf_filter_batch_device(rtuf_context* c, int n, const float* d_depth, float
     HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));
   if (c->pending) { const int rc = rtuf_sync(c); if (rc != RTUF_OK) return rc; }
   c->last_n = n; c->last_depth = d_depth; c->last_masked = d_masked; c->last_mask = d_mask;
-  const int rc = enqueue_batch(c, n, d_depth, d_masked, d_mask);
+  c->last_u16 = false;
+  const int rc = enqueue_batch(c, n, d_depth, d_masked, d_mask, false);
+  if (rc == RTUF_OK) c->pending = true;
+  return rc;
+}
+
+int rtuf_filter_batch_device_u16(rtuf_context* c, int n, const uint16_t* d_depth, uint16_t* d_masked, uint8_t* d_mask)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (n <= 0 || n > c->max_streams || !d_depth || !d_masked) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
+  if (c->width & 3) return c->fail(RTUF_ERR_INVALID, "16UC1 path needs a width that is a multiple of 4");
+  hipSetDevice(c->device);
+  if ((c->params.flags & RTUF_FLAG_TWO_KERNEL) && !c->d_zsurface)
+    HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));
+  if (c->pending) { const int rc = rtuf_sync(c); if (rc != RTUF_OK) return rc; }
+  c->last_n = n; c->last_depth = reinterpret_cast<const float*>(d_depth); c->last_masked = reinterpret_cast<float*>(d_masked); c->last_mask = d_mask;
+  c->last_u16 = true;
+  const int rc = enqueue_batch(c, n, c->last_depth, c->last_masked, d_mask, true);
   if (rc == RTUF_OK) c->pending = true;
   return rc;
 }
@@ -800,7 +822,7 @@ int rtuf_sync(rtuf_context* c)
     const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
     HIP_TRY(c, hipMemsetAsync(c->d_bin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_fbin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->stream));
-    const int rc = enqueue_batch(c, c->last_n, c->last_depth, c->last_masked, c->last_mask);
+    const int rc = enqueue_batch(c, c->last_n, c->last_depth, c->last_masked, c->last_mask, c->last_u16);
     if (rc != RTUF_OK) { c->pending = false; return rc; }
   }
   c->pending = false;
@@ -843,6 +865,37 @@ int rtuf_filter_batch(rtuf_context* c, int n, const float* const* depth_in, floa
   if (rc != RTUF_OK) return rc;
   for (int s = 0; s < n; s++) {
     HIP_TRY(c, hipMemcpyAsync(masked_out[s], c->d_masked + s * plane, plane * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (mask_out && mask_out[s])
+      HIP_TRY(c, hipMemcpyAsync(mask_out[s], c->d_mask + s * plane, plane, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return RTUF_OK;
+}
+
+int rtuf_filter_batch_u16(rtuf_context* c, int n, const uint16_t* const* depth_in, uint16_t* const* masked_out,
+                          uint8_t* const* mask_out)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (n <= 0 || n > c->max_streams || !depth_in || !masked_out) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
+  hipSetDevice(c->device);
+  int rc = ensure_staging(c, (size_t)n);       // float-sized staging is large enough for uint16 planes
+  if (rc != RTUF_OK) return rc;
+  const size_t plane = (size_t)c->width * c->height;
+  uint16_t* din = reinterpret_cast<uint16_t*>(c->d_depth);
+  uint16_t* dout = reinterpret_cast<uint16_t*>(c->d_masked);
+  for (int s = 0; s < n; s++) {
+    if (!depth_in[s] || !masked_out[s]) return c->fail(RTUF_ERR_INVALID, "null plane for stream %d", s);
+    HIP_TRY(c, hipMemcpyAsync(din + s * plane, depth_in[s], plane * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  }
+  bool any_mask = false;
+  if (mask_out) for (int s = 0; s < n; s++) any_mask |= mask_out[s] != nullptr;
+  rc = rtuf_filter_batch_device_u16(c, n, din, dout, any_mask ? c->d_mask : nullptr);
+  if (rc != RTUF_OK) return rc;
+  rc = rtuf_sync(c);
+  if (rc != RTUF_OK) return rc;
+  for (int s = 0; s < n; s++) {
+    HIP_TRY(c, hipMemcpyAsync(masked_out[s], dout + s * plane, plane * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
     if (mask_out && mask_out[s])
       HIP_TRY(c, hipMemcpyAsync(mask_out[s], c->d_mask + s * plane, plane, hipMemcpyDeviceToHost, c->stream));
   }

@@ -167,8 +167,8 @@ struct TileArgs {
   const Frag* fbins;
   uint32_t* fbin_count;          // reset to 0 by this kernel after use
   uint32_t fcapacity;
-  const float* depth;            // [n][H][W]
-  float* masked;                 // [n][H][W]
+  const float* depth;            // [n][H][W]   (f32 metres) or, with io_u16, uint16 millimetres
+  float* masked;                 // [n][H][W]   same element type as depth
   uint8_t* mask;                 // [n][H][W] or nullptr
   float* zsurface;               // [G][H][W]  (two-kernel mode)
   const float* bg_z;             // [n]
@@ -179,6 +179,7 @@ struct TileArgs {
   uint32_t capacity;
   uint32_t flags;
   float z_near, z_far, max_diff, replace_value;
+  int io_u16;                    // 16UC1 in/out fused into the kernel (src/urdf_filter.cpp:287-288, :309-312)
 };
 
 struct CompareArgs {
@@ -188,6 +189,7 @@ struct CompareArgs {
   uint8_t* mask;          // may be nullptr
   size_t n_pixels;        // multiple of 4 handled vectorised, tail scalar
   float z_near, z_far, max_diff, replace_value;
+  int io_u16;
 };
 
 
@@ -210,7 +212,7 @@ void launch_pose(const PoseArgs& a, hipStream_t st);
 void launch_setup(const SetupArgs& a, int n_chunks, hipStream_t st);
 void launch_clip(const SetupArgs& a, hipStream_t st);
 void launch_reset_clip(Counters* c, hipStream_t st);
-void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st);
+void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st);   // a.io_u16 selects the 16UC1 variant
 void launch_compare(const CompareArgs& a, hipStream_t st);
 
 }  // namespace rtuf

@@ -981,6 +981,19 @@ __device__ __forceinline__ void raster_frags(unsigned long long* keys, const uin
   }
 }
 
+// 16UC1 <-> float exactly like the reference's cv::Mat::convertTo calls:
+//   in : convertTo(CV_32F, 0.001)  -> float(u16) * 0.001f               (src/urdf_filter.cpp:287-288)
+//   out: convertTo(CV_16U, 1000.0) -> saturate_cast<ushort>(cvRound(v * 1000.0f)): round half to even,
+//        NaN / out-of-int-range -> "integer indefinite" -> 0, otherwise clamped to [0, 65535]   (:309-312)
+__device__ __forceinline__ float u16_to_metres(uint32_t u) { return __fmul_rn((float)u, 0.001f); }
+__device__ __forceinline__ uint32_t metres_to_u16(float m)
+{
+  const float v = __fmul_rn(m, 1000.0f);
+  if (!(v >= -2147483648.0f && v < 2147483648.0f)) return 0u;
+  const int i = __float2int_rn(v);
+  return (uint32_t)min(max(i, 0), 65535);
+}
+
 // urdf_filter.frag:14-35.  num = z_near*z_far/(z_near-z_far) and off = z_far/(z_far-z_near)
 // depend on uniforms only and are evaluated once per thread (same float operations).
 struct ShadeConsts { float num, off, max_diff, replace_value; };
@@ -1002,7 +1015,7 @@ __device__ __forceinline__ float shade(float sensor, float z, const ShadeConsts&
   return filt ? k.replace_value : sensor;
 }
 
-template <bool TWO_KERNEL>
+template <bool TWO_KERNEL, bool U16>
 __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
 {
   __shared__ unsigned long long keys[kTileW * kTileH];
@@ -1031,7 +1044,14 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
   const bool r_valid = r_ly < kTileH && r_py < a.height && r_px < a.width;
   const size_t gofs = ((size_t)stream * a.height + r_py) * a.width + r_px;
   float4 sens = make_float4(0, 0, 0, 0);
-  if (!TWO_KERNEL && r_valid && vec) sens = *reinterpret_cast<const float4*>(a.depth + gofs);
+  if (!TWO_KERNEL && r_valid && vec) {
+    if (U16) {
+      const ushort4 q = *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(a.depth) + gofs);
+      sens = make_float4(u16_to_metres(q.x), u16_to_metres(q.y), u16_to_metres(q.z), u16_to_metres(q.w));
+    } else {
+      sens = *reinterpret_cast<const float4*>(a.depth + gofs);
+    }
+  }
   const uint32_t n = min(count, a.capacity), nf = min(fcount, a.fcapacity);
   const PackedTri* recs = a.bins + (size_t)bin * a.capacity;
   const uint4* frags = reinterpret_cast<const uint4*>(a.fbins) + (size_t)bin * a.fcapacity;
@@ -1091,7 +1111,8 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
       if (vec) {
         s[0] = sens.x; s[1] = sens.y; s[2] = sens.z; s[3] = sens.w;
       } else {
-        for (int j = 0; j < 4; j++) s[j] = j < nvalid ? a.depth[gofs + j] : 0.0f;
+        for (int j = 0; j < 4; j++)
+          s[j] = j < nvalid ? (U16 ? u16_to_metres(reinterpret_cast<const uint16_t*>(a.depth)[gofs + j]) : a.depth[gofs + j]) : 0.0f;
       }
       float o[4];
       uint32_t mbits = 0;
@@ -1103,11 +1124,19 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
         if (f) mbits |= 0xffu << (8 * j);
       }
       if (vec) {
-        *reinterpret_cast<float4*>(a.masked + gofs) = make_float4(o[0], o[1], o[2], o[3]);
+        if (U16) {
+          ushort4 q;
+          q.x = (unsigned short)metres_to_u16(o[0]); q.y = (unsigned short)metres_to_u16(o[1]);
+          q.z = (unsigned short)metres_to_u16(o[2]); q.w = (unsigned short)metres_to_u16(o[3]);
+          *reinterpret_cast<ushort4*>(reinterpret_cast<uint16_t*>(a.masked) + gofs) = q;
+        } else {
+          *reinterpret_cast<float4*>(a.masked + gofs) = make_float4(o[0], o[1], o[2], o[3]);
+        }
         if (a.mask) *reinterpret_cast<uint32_t*>(a.mask + gofs) = mbits;
       } else {
         for (int j = 0; j < nvalid; j++) {
-          a.masked[gofs + j] = o[j];
+          if (U16) reinterpret_cast<uint16_t*>(a.masked)[gofs + j] = (uint16_t)metres_to_u16(o[j]);
+          else a.masked[gofs + j] = o[j];
           if (a.mask) a.mask[gofs + j] = (uint8_t)(mbits >> (8 * j));
         }
       }
@@ -1119,15 +1148,25 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
 // compare_kernel (two-kernel mode): streaming, 13 B/pixel (4 sensor + 4 z + 4 masked + 1 mask)
 // ---------------------------------------------------------------------------------------
 
+template <bool U16>
 __global__ __launch_bounds__(kBlock) void compare_kernel(CompareArgs a)
 {
   const ShadeConsts sc = shade_consts(a.z_near, a.z_far, a.max_diff, a.replace_value);
   const size_t n4 = a.n_pixels >> 2;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const uint16_t* in16 = reinterpret_cast<const uint16_t*>(a.depth);
+  uint16_t* out16 = reinterpret_cast<uint16_t*>(a.masked);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const float4 s = reinterpret_cast<const float4*>(a.depth)[i];
+    float sv[4];
+    if (U16) {
+      const ushort4 q = reinterpret_cast<const ushort4*>(in16)[i];
+      sv[0] = u16_to_metres(q.x); sv[1] = u16_to_metres(q.y); sv[2] = u16_to_metres(q.z); sv[3] = u16_to_metres(q.w);
+    } else {
+      const float4 s = reinterpret_cast<const float4*>(a.depth)[i];
+      sv[0] = s.x; sv[1] = s.y; sv[2] = s.z; sv[3] = s.w;
+    }
     const float4 z = reinterpret_cast<const float4*>(a.zsurface)[i];
-    const float sv[4] = {s.x, s.y, s.z, s.w}, zv[4] = {z.x, z.y, z.z, z.w};
+    const float zv[4] = {z.x, z.y, z.z, z.w};
     float o[4];
     uint32_t mbits = 0;
 #pragma unroll
@@ -1137,16 +1176,25 @@ __global__ __launch_bounds__(kBlock) void compare_kernel(CompareArgs a)
       if (zv[j] != zv[j]) { o[j] = 0.0f; f = false; }
       if (f) mbits |= 0xffu << (8 * j);
     }
-    reinterpret_cast<float4*>(a.masked)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (U16) {
+      ushort4 q;
+      q.x = (unsigned short)metres_to_u16(o[0]); q.y = (unsigned short)metres_to_u16(o[1]);
+      q.z = (unsigned short)metres_to_u16(o[2]); q.w = (unsigned short)metres_to_u16(o[3]);
+      reinterpret_cast<ushort4*>(out16)[i] = q;
+    } else {
+      reinterpret_cast<float4*>(a.masked)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
     if (a.mask) reinterpret_cast<uint32_t*>(a.mask)[i] = mbits;
   }
   // tail
   if (blockIdx.x == 0 && threadIdx.x < (a.n_pixels & 3)) {
     const size_t i = (n4 << 2) + threadIdx.x;
     bool f;
-    float o = shade(a.depth[i], a.zsurface[i], sc, f);
+    const float sen = U16 ? u16_to_metres(in16[i]) : a.depth[i];
+    float o = shade(sen, a.zsurface[i], sc, f);
     if (a.zsurface[i] != a.zsurface[i]) { o = 0.0f; f = false; }
-    a.masked[i] = o;
+    if (U16) out16[i] = (uint16_t)metres_to_u16(o);
+    else a.masked[i] = o;
     if (a.mask) a.mask[i] = f ? 255 : 0;
   }
 }
@@ -1187,8 +1235,9 @@ void launch_clip(const SetupArgs& a, hipStream_t st)
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st)
 {
   const int blocks = a.group_size * a.tiles_x * a.tiles_y;
-  if (two_kernel) hipLaunchKernelGGL(tile_kernel<true>, dim3(blocks), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL(tile_kernel<false>, dim3(blocks), dim3(kBlock), 0, st, a);
+  if (two_kernel) hipLaunchKernelGGL((tile_kernel<true, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+  else if (a.io_u16) hipLaunchKernelGGL((tile_kernel<false, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL((tile_kernel<false, false>), dim3(blocks), dim3(kBlock), 0, st, a);
 }
 void launch_compare(const CompareArgs& a, hipStream_t st)
 {
@@ -1196,7 +1245,8 @@ void launch_compare(const CompareArgs& a, hipStream_t st)
   size_t blocks = (n4 + kBlock - 1) / kBlock;
   if (blocks > 8192) blocks = 8192;
   if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(compare_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+  if (a.io_u16) hipLaunchKernelGGL(compare_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL(compare_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
 }
 
 }  // namespace rtuf

@@ -371,8 +371,11 @@ def depth_u16_to_f32(img_u16):
 
 def depth_f32_to_u16(img_f32):
     """cv::Mat::convertTo(CV_16U, 1000.0) (src/urdf_filter.cpp:311): float32 product, round half to even,
-    saturate; NaN -> 0."""
+    saturate; NaN / +-inf -> 0."""
     with np.errstate(invalid="ignore", over="ignore"):
-        v = np.rint((np.asarray(img_f32, np.float32) * np.float32(1000.0)).astype(np.float32))
-        v = np.where(np.isnan(v), 0.0, v)
-        return np.clip(v, 0, 65535).astype(np.uint16)
+        v = (np.asarray(img_f32, np.float32) * np.float32(1000.0)).astype(np.float32)
+        # cvRound on NaN / values outside the int32 range yields the "integer indefinite" value, which
+        # saturate_cast<ushort> maps to 0
+        bad = ~((v >= np.float32(-2147483648.0)) & (v < np.float32(2147483648.0)))
+        r = np.rint(np.where(bad, 0.0, v))
+        return np.clip(r, 0, 65535).astype(np.uint16)

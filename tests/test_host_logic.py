@@ -111,7 +111,7 @@ def test_depth_conversions_16uc1():
     f = depth_u16_to_f32(u)
     assert f.dtype == np.float32 and f[0, 3] == np.float32(1000) * np.float32(0.001)
     back = depth_f32_to_u16(np.array([[0.0005, 0.0015, 0.0025, 5.0, np.nan, np.inf, -1.0, 70.0]], np.float32))
-    assert list(back[0]) == [0, 2, 2, 5000, 0, 65535, 0, 65535]         # half-to-even, saturate, NaN -> 0
+    assert list(back[0]) == [0, 2, 2, 5000, 0, 0, 0, 65535]             # half-to-even, saturate, NaN / inf -> 0
 
 
 def test_stl_roundtrip_and_solid_header_quirk():

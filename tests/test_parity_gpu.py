@@ -391,3 +391,25 @@ def test_config_c5_distinct_urdfs_share_a_context():
             om, ok = O.filter_frame(depth[s], wl.projection[k], wl.oracle_draws(k), wl.offset_inv[k], wl.cam_tf[k], replace_value=5.0)
             assert (ok != mask[s]).sum() == 0 and bits_equal(om, masked[s]), "robot %d stream %d" % (r, k)
     ctx.close()
+
+
+@pytest.mark.parametrize("two_kernel", [False, True])
+def test_fused_16uc1_io(two_kernel):
+    """uint16 millimetres in/out with the reference's convertTo arithmetic fused into the kernels."""
+    wl = WL.pr2_workload(3, 320, 240, total_triangles=6000)
+    ctx = R.Context(320, 240, 3, 0, params(wl.replace_value, wl.max_diff, two_kernel))
+    ids = wl.load_into(ctx)
+    wl.stage(ctx, ids)
+    rng = np.random.default_rng(4)
+    mm = np.clip(np.nan_to_num(wl.depth_batch(), nan=0.0, posinf=0.0) * 1000.0 + rng.integers(-3, 4, (3, 240, 320)), 0, 65535).astype(np.uint16)
+    mm[:, 0, :4] = [0, 1, 65535, 7900]
+    out16, mask = ctx.filter_batch_u16(mm)
+    for s in range(3):
+        d32 = depth_u16_to_f32(mm[s])
+        om, ok = O.filter_frame(d32, wl.projection[s], wl.oracle_draws(s), wl.offset_inv[s], wl.cam_tf[s],
+                                max_diff=wl.max_diff, replace_value=wl.replace_value)
+        assert (ok != mask[s]).sum() == 0
+        assert np.array_equal(out16[s], depth_f32_to_u16(om))
+        assert np.array_equal(out16[s][ok == 0], mm[s][ok == 0])          # unfiltered pixels round-trip exactly
+        assert (out16[s][ok > 0] == 5000).all()
+    ctx.close()
