@@ -882,26 +882,16 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
                                            int x_base, int y_base, int tid, bool dbg_load_only, int width, int height)
 {
   const int lane = tid & 63;
-  // software pipeline: the records of batch b+1 are in flight while batch b is rasterised
-  uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = nx0;
-  if ((uint32_t)tid < n) {
-    const uint4* src = reinterpret_cast<const uint4*>(recs + tid);
-    nx0 = src[0]; nx1 = src[1];
-  }
   for (uint32_t base = 0; base < n; base += kBlock) {
     const uint32_t i = base + tid;
     const bool have = i < n;
-    const uint4 c0 = nx0, c1 = nx1;
-    if (i + kBlock < n) {
-      const uint4* src = reinterpret_cast<const uint4*>(recs + i + kBlock);
-      nx0 = src[0]; nx1 = src[1];
-    }
     TriRec r;
     int lx0 = 0, lx1 = -1, ly0 = 0, ly1 = -1;
     if (have) {
       PackedTri pk;
+      const uint4* src = reinterpret_cast<const uint4*>(recs + i);
       uint4* dst = reinterpret_cast<uint4*>(&pk);
-      dst[0] = c0; dst[1] = c1;
+      dst[0] = src[0]; dst[1] = src[1];
       r = unpack_record(pk, width, height);
       lx0 = max((int)(r.bbx & 0xffff) - x_base, 0);
       lx1 = min((int)(r.bbx >> 16) - x_base, kTileW - 1);
