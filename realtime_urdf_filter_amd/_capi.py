@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librtuf.so")
+_LIB_PATH = os.environ.get("RTUF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librtuf.so")
 
 RTUF_OK = 0
 RTUF_ERR_NO_DEVICE = -2

@@ -33,7 +33,10 @@ constexpr int kTileW = RTUF_TILE_W;      // screen tile of one raster workgroup 
 constexpr int kTileH = RTUF_TILE_H;
 constexpr int kBlock = 256;
 constexpr int kMaxChunkVerts = 256;     // unique vertices per set-up chunk (one per lane; LDS: 24 B each per stream)
-constexpr int kStreamsPerBlock = 4;     // streams a set-up workgroup loops over per chunk
+#ifndef RTUF_STREAMS_PER_BLOCK
+#define RTUF_STREAMS_PER_BLOCK 3
+#endif
+constexpr int kStreamsPerBlock = RTUF_STREAMS_PER_BLOCK;     // streams a set-up workgroup loops over per chunk
 
 struct alignas(16) TriRec {     // 64 B: one rasterisable triangle inside one tile bin
   int32_t A[3];                 // edge i is inside  <=>  A[i]*px + B[i]*py + C[i] > 0

@@ -860,7 +860,14 @@ __device__ __forceinline__ void fragment(unsigned long long* keys, const TriRec&
 }
 
 
-constexpr int kSmallArea = 12;     // bounding boxes up to this many pixels are walked by their own lane
+#ifndef RTUF_SMALL_AREA
+#define RTUF_SMALL_AREA 32
+#endif
+#ifndef RTUF_QUARTER_AREA
+#define RTUF_QUARTER_AREA 256
+#endif
+constexpr int kSmallArea = RTUF_SMALL_AREA;     // bounding boxes up to this many pixels are walked by their own lane
+constexpr int kQuarterArea = RTUF_QUARTER_AREA;   // up to this many by a quarter wave (4 triangles at a time), larger by the whole wave
 
 // Broadcast of one lane's record to the whole wave through scalar registers (v_readlane): the
 // cooperative path then runs with the triangle's 16 words as SGPR operands.
@@ -879,7 +886,7 @@ __device__ __forceinline__ TriRec broadcast_record(const TriRec& r, int src_lane
 // 8x8 stamps for anything larger.
 template <int MODE>
 __device__ __forceinline__ void raster_bin(unsigned long long* keys, const PackedTri* recs, uint32_t n,
-                                           int x_base, int y_base, int tid, bool dbg_load_only, int width, int height)
+                                           int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, int dbg_skip = 0)
 {
   const int lane = tid & 63;
   for (uint32_t base = 0; base < n; base += kBlock) {
@@ -904,6 +911,8 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     const int w = lx1 - lx0 + 1, h = ly1 - ly0 + 1;
     int area = (have && w > 0 && h > 0) ? w * h : 0;
     if (dbg_load_only) { if (r.order == 0xdeadbeefu) keys[0] = 0; area = 0; }
+    if (dbg_skip == 1 && area <= kSmallArea) area = 0;      // timing experiment: no lane-per-triangle walk
+    if (dbg_skip == 2 && area > kSmallArea) area = 0;       // timing experiment: no quarter-wave walk
     const bool small = area > 0 && area <= kSmallArea;
     // lane-per-triangle: walk the bounding box as one run of `area` candidates
     {
@@ -920,7 +929,25 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     }
     // quarter-wave cooperative: four triangles at a time, 16 lanes each, one candidate pixel per
     // lane and step (the bounding box is walked as a linear run, so slivers waste nothing)
-    unsigned long long big = __ballot(area > kSmallArea);
+    // whole-wave cooperative: triangles that cover a large part of the tile, one at a time with the
+    // record in scalar registers (v_readlane), 64 candidate pixels per step
+    unsigned long long huge = __ballot(area > kQuarterArea);
+    while (huge) {
+      const int src = __ffsll((long long)huge) - 1;
+      huge &= huge - 1;
+      const TriRec q = broadcast_record(r, src);
+      const int qx0 = max((int)(q.bbx & 0xffff) - x_base, 0), qx1 = min((int)(q.bbx >> 16) - x_base, kTileW - 1);
+      const int qy0 = max((int)(q.bby & 0xffff) - y_base, 0), qy1 = min((int)(q.bby >> 16) - y_base, kTileH - 1);
+      const int qw = qx1 - qx0 + 1, qarea = qw * (qy1 - qy0 + 1);
+      const uint32_t inv = (uint32_t)ceilf(65536.0f * __builtin_amdgcn_rcpf((float)qw));
+      for (int idx = lane; idx < qarea; idx += 64) {
+        const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 16);
+        const int lx = qx0 + idx - __mul24(yy, qw), ly = qy0 + yy;
+        const int px = x_base + lx, py = y_base + ly;
+        if (inside(q, px, py)) fragment<MODE>(keys, q, px, py, ly * kTileW + lx);
+      }
+    }
+    unsigned long long big = __ballot(area > kSmallArea && area <= kQuarterArea);
     const int grp = lane >> 4, sub = lane & 15;
     while (big) {
       int src = -1;
@@ -1057,7 +1084,7 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
       if (count) atomicMax(&sh.max_bin_fill, count);
       if (fcount) atomicMax(&sh.max_fbin_fill, fcount);
     }
-    if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height);
+    if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, (int)((a.flags >> 12) & 3u));
     if (!(a.flags & 0x400u)) raster_frags<0>(keys, frags, nf, x_base, y_base, tid);
     __syncthreads();
 
