@@ -556,7 +556,7 @@ __device__ __forceinline__ bool chunk_outside_plane(const float* M, const Chunk&
 //                         set-up (edge functions, z plane) and binning
 __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
 {
-  __shared__ float4 s_win[kStreamsPerBlock][kMaxChunkVerts];   // window x, y, z + clip mask bits
+  __shared__ float s_win[kStreamsPerBlock][3][kMaxChunkVerts];  // window x, y, z (SoA: 12 B per vertex)
   __shared__ int2 s_snap[kStreamsPerBlock][kMaxChunkVerts];    // snapped x; snapped y << 8 | clip mask
   __shared__ uint32_t s_packed[kBlock];                         // the chunk's triangles
   __shared__ uint16_t s_list[kStreamsPerBlock * kBlock];        // survivors: stream k << 8 | triangle
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
       vs_position(M, pv.x, pv.y, pv.z, c);
       const Win w = viewport_vs(c, sx, sy);
       const unsigned cm = clipmask_of(c);
-      s_win[k][tid] = make_float4(w.x, w.y, w.z, __uint_as_float(cm));
+      s_win[k][0][tid] = w.x; s_win[k][1][tid] = w.y; s_win[k][2][tid] = w.z;
       s_snap[k][tid] = make_int2(snap(w.x), (int)(((unsigned)snap(w.y) << 8) | cm));
     }
     __syncthreads();
@@ -685,11 +685,11 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
       const int k = (int)(e >> 8), t = (int)(e & 255u);
       slot = blockIdx.x * kStreamsPerBlock + k;
       const uint32_t p = s_packed[t];
-      const float4 w0 = s_win[k][p & 1023u], w1 = s_win[k][(p >> 10) & 1023u], w2 = s_win[k][(p >> 20) & 1023u];
+      const uint32_t j0 = p & 1023u, j1 = (p >> 10) & 1023u, j2 = (p >> 20) & 1023u;
       Win v0, v1, v2;
-      v0.x = w0.x; v0.y = w0.y; v0.z = w0.z;
-      v1.x = w1.x; v1.y = w1.y; v1.z = w1.z;
-      v2.x = w2.x; v2.y = w2.y; v2.z = w2.z;
+      v0.x = s_win[k][0][j0]; v0.y = s_win[k][1][j0]; v0.z = s_win[k][2][j0];
+      v1.x = s_win[k][0][j1]; v1.y = s_win[k][1][j1]; v1.z = s_win[k][2][j1];
+      v2.x = s_win[k][0][j2]; v2.y = s_win[k][1][j2]; v2.z = s_win[k][2][j2];
       have = make_record(v0, v1, v2, is_bg ? 0u : ch.order_base + (uint32_t)t, a.width, a.height, r, pk);
     }
     if (__ballot(have)) {
