@@ -97,7 +97,7 @@ def main():
         if args.host_poses:
             variants[v].stage(ctx, ids)
         else:
-            variants[v].stage_joint_positions(ctx, ids)      # joint angles in, forward kinematics on the GPU
+            variants[v].stage_joint_positions(ctx, ids, first_call=(k == 0))      # joint angles in, forward kinematics on the GPU
         (ctx.filter_batch_device_u16 if args.u16 else ctx.filter_batch_device)(n, d_depth[v].data_ptr(), d_masked.data_ptr(), d_mask.data_ptr() if d_mask is not None else 0)
         ctx.sync()
 

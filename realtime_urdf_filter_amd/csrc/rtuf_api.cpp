@@ -30,8 +30,10 @@ struct HostDraw {
 };
 struct HostLink { std::vector<HostDraw> draws; };
 struct Kinematics {               // on-device forward kinematics of one model
-  int n_frames = 0, camera_frame = -1;
+  int n_frames = 0, camera_frame = -1, max_depth = 0;
+  int32_t* d_depth = nullptr;
   bool has_root = false, any_enabled = false;
+  bool dirty_q = true, dirty_aux = true;     // joint positions / root poses + enable flags changed on the host
   int32_t* d_parent = nullptr; int32_t* d_type = nullptr; double* d_origin = nullptr; double* d_axis = nullptr;
   int32_t* d_link_frame = nullptr; double* d_link_offset = nullptr;
   double* h_q = nullptr; double* d_q = nullptr;             // [max_streams][n_frames]
@@ -183,7 +185,7 @@ void rtuf_destroy(rtuf_context* c)
   if (c->stream) hipStreamSynchronize(c->stream);
   for (HostModel& m : c->models) {
     Kinematics& k = m.kin;
-    hipFree(k.d_parent); hipFree(k.d_type); hipFree(k.d_origin); hipFree(k.d_axis); hipFree(k.d_link_frame); hipFree(k.d_link_offset);
+    hipFree(k.d_depth); hipFree(k.d_parent); hipFree(k.d_type); hipFree(k.d_origin); hipFree(k.d_axis); hipFree(k.d_link_frame); hipFree(k.d_link_offset);
     hipFree(k.d_q); hipFree(k.d_root); hipFree(k.d_enabled);
     if (k.h_q) hipHostFree(k.h_q);
     if (k.h_root) hipHostFree(k.h_root);
@@ -487,7 +489,7 @@ int rtuf_set_link_poses(rtuf_context* c, int stream, int model, const double* li
   const HostModel& m = c->models[model];
   if (n_links != (int)m.links.size()) return c->fail(RTUF_ERR_INVALID, "model %d has %d links, got %d", model, (int)m.links.size(), n_links);
   memcpy(c->h_link_tf + ((size_t)stream * c->n_links + m.link_base) * 16, link_tf, sizeof(double) * 16 * (size_t)n_links);
-  if (m.kin.h_enabled) c->models[model].kin.h_enabled[stream] = 0;
+  if (m.kin.h_enabled && m.kin.h_enabled[stream]) { c->models[model].kin.h_enabled[stream] = 0; c->models[model].kin.dirty_aux = true; }
   c->dirty_link_tf = true;
   return RTUF_OK;
 }
@@ -519,7 +521,7 @@ int rtuf_set_link_poses_batch(rtuf_context* c, int first, int n, int model, cons
   for (int s = 0; s < n; s++) {
     memcpy(c->h_link_tf + ((size_t)(first + s) * c->n_links + m.link_base) * 16, link_tf + (size_t)s * n_links * 16,
            sizeof(double) * 16 * (size_t)n_links);
-    if (m.kin.h_enabled) c->models[model].kin.h_enabled[first + s] = 0;
+    if (m.kin.h_enabled && m.kin.h_enabled[first + s]) { c->models[model].kin.h_enabled[first + s] = 0; c->models[model].kin.dirty_aux = true; }
   }
   c->dirty_link_tf = true;
   return RTUF_OK;
@@ -560,6 +562,12 @@ int rtuf_set_kinematics(rtuf_context* c, int model, int n_frames, const int32_t*
   for (int i = 0; i < n_frames; i++) gl_to_tf12(joint_origin + 16 * (size_t)i, &org[12 * (size_t)i]);
   for (int l = 0; l < n_links; l++) gl_to_tf12(link_offset + 16 * (size_t)l, &off[12 * (size_t)l]);
   const size_t N = (size_t)c->max_streams;
+  std::vector<int32_t> depth(n_frames, 0);
+  int max_depth = 0;
+  for (int i = 0; i < n_frames; i++) { depth[i] = parent[i] < 0 ? 0 : depth[parent[i]] + 1; max_depth = std::max(max_depth, depth[i]); }
+  HIP_TRY(c, hipMalloc(&k.d_depth, sizeof(int32_t) * n_frames));
+  HIP_TRY(c, hipMemcpy(k.d_depth, depth.data(), sizeof(int32_t) * n_frames, hipMemcpyHostToDevice));
+  k.max_depth = max_depth;
   HIP_TRY(c, hipMalloc(&k.d_parent, sizeof(int32_t) * n_frames));
   HIP_TRY(c, hipMalloc(&k.d_type, sizeof(int32_t) * n_frames));
   HIP_TRY(c, hipMalloc(&k.d_origin, sizeof(double) * 12 * n_frames));
@@ -594,10 +602,14 @@ int rtuf_set_joint_positions(rtuf_context* c, int first, int n, int model, const
   if (!k.n_frames) return c->fail(RTUF_ERR_STATE, "call rtuf_set_kinematics for model %d first", model);
   if (camera_frame < -1 || camera_frame >= k.n_frames) return c->fail(RTUF_ERR_INVALID, "bad camera frame %d", camera_frame);
   memcpy(k.h_q + (size_t)first * k.n_frames, q, sizeof(double) * (size_t)n * k.n_frames);
+  k.dirty_q = true;
   static const double I12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
   for (int s = 0; s < n; s++) {
-    if (root_tf) gl_to_tf12(root_tf + 16 * (size_t)s, k.h_root + 12 * (size_t)(first + s));
-    else memcpy(k.h_root + 12 * (size_t)(first + s), I12, sizeof I12);
+    double r12[12];
+    if (root_tf) gl_to_tf12(root_tf + 16 * (size_t)s, r12);
+    else memcpy(r12, I12, sizeof r12);
+    double* dst = k.h_root + 12 * (size_t)(first + s);
+    if (memcmp(dst, r12, sizeof r12) != 0 || !k.h_enabled[first + s]) { memcpy(dst, r12, sizeof r12); k.dirty_aux = true; }
     k.h_enabled[first + s] = 1;
   }
   k.camera_frame = camera_frame;
@@ -674,11 +686,14 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
   for (HostModel& m : c->models) {
     Kinematics& k = m.kin;
     if (!k.n_frames || !k.any_enabled) continue;
-    HIP_TRY(c, hipMemcpyAsync(k.d_q, k.h_q, sizeof(double) * (size_t)n * k.n_frames, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(k.d_root, k.h_root, sizeof(double) * 12 * (size_t)n, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(k.d_enabled, k.h_enabled, (size_t)n, hipMemcpyHostToDevice, st));
+    if (k.dirty_q || more) HIP_TRY(c, hipMemcpyAsync(k.d_q, k.h_q, sizeof(double) * (size_t)n * k.n_frames, hipMemcpyHostToDevice, st));
+    if (k.dirty_aux || more) {
+      HIP_TRY(c, hipMemcpyAsync(k.d_root, k.h_root, sizeof(double) * 12 * (size_t)n, hipMemcpyHostToDevice, st));
+      HIP_TRY(c, hipMemcpyAsync(k.d_enabled, k.h_enabled, (size_t)n, hipMemcpyHostToDevice, st));
+    }
+    k.dirty_q = k.dirty_aux = false;
     FkArgs fa{};
-    fa.parent = k.d_parent; fa.joint_type = k.d_type; fa.joint_origin = k.d_origin; fa.joint_axis = k.d_axis;
+    fa.parent = k.d_parent; fa.depth = k.d_depth; fa.max_depth = k.max_depth; fa.joint_type = k.d_type; fa.joint_origin = k.d_origin; fa.joint_axis = k.d_axis;
     fa.link_frame = k.d_link_frame; fa.link_offset = k.d_link_offset; fa.q = k.d_q; fa.root_tf = k.d_root;
     fa.enabled = k.d_enabled; fa.link_tf = c->d_link_tf; fa.cams = c->d_cams;
     fa.n_streams = n; fa.n_frames = k.n_frames; fa.n_links_model = (int)m.links.size(); fa.link_base = m.link_base;

@@ -199,6 +199,7 @@ struct CompareArgs {
 struct FkArgs {
   const int32_t* parent;        // [F]
   const int32_t* joint_type;    // [F]
+  const int32_t* depth;         // [F] distance from the root (0 for the root)
   const double* joint_origin;   // [F][12]  row-major 3x3 basis + origin
   const double* joint_axis;     // [F][3]
   const int32_t* link_frame;    // [L_model]
@@ -208,7 +209,7 @@ struct FkArgs {
   const uint8_t* enabled;       // [N] stream uses FK for this model
   double* link_tf;              // [N][L_total][16]
   Camera* cams;                 // [N]
-  int n_streams, n_frames, n_links_model, link_base, n_links_total, camera_frame;
+  int n_streams, n_frames, n_links_model, link_base, n_links_total, camera_frame, max_depth;
 };
 void launch_fk(const FkArgs& a, hipStream_t st);
 void launch_pose(const PoseArgs& a, hipStream_t st);

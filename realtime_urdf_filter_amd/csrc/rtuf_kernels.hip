@@ -302,6 +302,61 @@ __global__ void fk_kernel(FkArgs a)
   }
 }
 
+// Same arithmetic, organised as a tree sweep: one workgroup per stream keeps every frame's
+// fixed<-frame transform in LDS and fills it level by level (all frames of one depth in parallel,
+// T_child = (T_parent * origin) * motion(q)), then the links and the camera read it.  Used when the
+// tree fits in LDS (kFkMaxFrames frames); fk_kernel above is the general fallback.
+constexpr int kFkMaxFrames = 256;
+__global__ __launch_bounds__(128) void fk_tree_kernel(FkArgs a)
+{
+  __shared__ double s_t[kFkMaxFrames][12];
+  const int s = blockIdx.x;
+  if (!a.enabled[s]) return;
+  const int tid = threadIdx.x;
+  for (int d = 0; d <= a.max_depth; d++) {
+    for (int f = tid; f < a.n_frames; f += blockDim.x) {
+      if (a.depth[f] != d) continue;
+      Tf12 t;
+      if (d == 0) {
+        if (a.root_tf) t = tf_load(a.root_tf + (size_t)s * 12);
+        else { for (int k = 0; k < 9; k++) t.m[k] = (k % 4 == 0) ? 1.0 : 0.0; t.o[0] = t.o[1] = t.o[2] = 0.0; }
+      } else {
+        t = tf_mul(tf_load(s_t[a.parent[f]]), tf_load(a.joint_origin + (size_t)f * 12));
+        const int jt = a.joint_type[f];
+        if (jt == 1) {
+          const double q = a.q[(size_t)s * a.n_frames + f];
+          const double ax = a.joint_axis[3 * f], ay = a.joint_axis[3 * f + 1], az = a.joint_axis[3 * f + 2];
+          const double nn = sqrt(ax * ax + ay * ay + az * az);
+          const double ux = nn > 0 ? ax / nn : 1.0, uy = nn > 0 ? ay / nn : 0.0, uz = nn > 0 ? az / nn : 0.0;
+          const double sh = sin(0.5 * q), ch = cos(0.5 * q);
+          t = tf_mul(t, tf_from_quat(ux * sh, uy * sh, uz * sh, ch));
+        } else if (jt == 2) {
+          const double q = a.q[(size_t)s * a.n_frames + f];
+          Tf12 m;
+          for (int k2 = 0; k2 < 9; k2++) m.m[k2] = (k2 % 4 == 0) ? 1.0 : 0.0;
+          m.o[0] = a.joint_axis[3 * f] * q; m.o[1] = a.joint_axis[3 * f + 1] * q; m.o[2] = a.joint_axis[3 * f + 2] * q;
+          t = tf_mul(t, m);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 9; k++) s_t[f][k] = t.m[k];
+      s_t[f][9] = t.o[0]; s_t[f][10] = t.o[1]; s_t[f][11] = t.o[2];
+    }
+    __syncthreads();
+  }
+  for (int l = tid; l < a.n_links_model; l += blockDim.x) {
+    const Tf12 t = tf_mul(tf_load(s_t[a.link_frame[l]]), tf_load(a.link_offset + (size_t)l * 12));
+    tf_store_gl(t, a.link_tf + ((size_t)s * a.n_links_total + a.link_base + l) * 16);
+  }
+  if (tid == 0 && a.camera_frame >= 0) {
+    const Tf12 t = tf_load(s_t[a.camera_frame]);
+    Tf12 inv;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) inv.m[3 * i + j] = t.m[3 * j + i];
+    for (int i = 0; i < 3; i++) inv.o[i] = inv.m[3 * i] * (-t.o[0]) + inv.m[3 * i + 1] * (-t.o[1]) + inv.m[3 * i + 2] * (-t.o[2]);
+    tf_store_gl(inv, a.cams[s].cam_tf);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // triangle set-up
 // ---------------------------------------------------------------------------------------
@@ -1231,6 +1286,10 @@ void launch_reset_clip(Counters* c, hipStream_t st)
 }
 void launch_fk(const FkArgs& a, hipStream_t st)
 {
+  if (a.n_frames <= kFkMaxFrames) {
+    hipLaunchKernelGGL(fk_tree_kernel, dim3(a.n_streams), dim3(128), 0, st, a);
+    return;
+  }
   const int total = a.n_streams * (a.n_links_model + 1);
   hipLaunchKernelGGL(fk_kernel, dim3((total + 63) / 64), dim3(64), 0, st, a);
 }

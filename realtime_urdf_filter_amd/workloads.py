@@ -77,11 +77,12 @@ class Workload:
             if tf.shape[1]:
                 ctx.set_link_poses_batch(0, m, tf[sl])
 
-    def stage_joint_positions(self, ctx, model_ids, first=0, n=None):
+    def stage_joint_positions(self, ctx, model_ids, first=0, n=None, first_call=True):
         """Same poses through on-device forward kinematics: only joint positions cross the bus."""
         n = self.n_streams if n is None else n
         sl = slice(first, first + n)
-        ctx.set_cameras(0, self.projection[sl], self.offset_inv[sl], None)
+        if first_call:
+            ctx.set_cameras(0, self.projection[sl], self.offset_inv[sl], None)     # intrinsics do not change per frame
         ctx.set_joint_positions(0, model_ids[0], self.joint_q[sl], None, self.camera_frame_index)
         for m, tf in list(zip(model_ids, self.link_tf))[1:]:
             if tf.shape[1]:
