@@ -307,36 +307,47 @@ __global__ void fk_kernel(FkArgs a)
 // T_child = (T_parent * origin) * motion(q)), then the links and the camera read it.  Used when the
 // tree fits in LDS (kFkMaxFrames frames); fk_kernel above is the general fallback.
 constexpr int kFkMaxFrames = 256;
-__global__ __launch_bounds__(128) void fk_tree_kernel(FkArgs a)
+__global__ __launch_bounds__(kFkMaxFrames) void fk_tree_kernel(FkArgs a)
 {
   __shared__ double s_t[kFkMaxFrames][12];
   const int s = blockIdx.x;
   if (!a.enabled[s]) return;
-  const int tid = threadIdx.x;
+  const int f = threadIdx.x;                 // one frame per lane; everything it needs is fetched up front
+  const bool have = f < a.n_frames;
+  int parent = -1, depth = -1;
+  Tf12 origin, motion;
+  bool has_motion = false;
+  if (have) {
+    parent = a.parent[f];
+    depth = a.depth[f];
+    if (depth > 0) {
+      origin = tf_load(a.joint_origin + (size_t)f * 12);
+      const int jt = a.joint_type[f];
+      if (jt == 1) {
+        const double q = a.q[(size_t)s * a.n_frames + f];
+        const double ax = a.joint_axis[3 * f], ay = a.joint_axis[3 * f + 1], az = a.joint_axis[3 * f + 2];
+        const double nn = sqrt(ax * ax + ay * ay + az * az);
+        const double ux = nn > 0 ? ax / nn : 1.0, uy = nn > 0 ? ay / nn : 0.0, uz = nn > 0 ? az / nn : 0.0;
+        const double sh = sin(0.5 * q), ch = cos(0.5 * q);
+        motion = tf_from_quat(ux * sh, uy * sh, uz * sh, ch);
+        has_motion = true;
+      } else if (jt == 2) {
+        const double q = a.q[(size_t)s * a.n_frames + f];
+        for (int k2 = 0; k2 < 9; k2++) motion.m[k2] = (k2 % 4 == 0) ? 1.0 : 0.0;
+        motion.o[0] = a.joint_axis[3 * f] * q; motion.o[1] = a.joint_axis[3 * f + 1] * q; motion.o[2] = a.joint_axis[3 * f + 2] * q;
+        has_motion = true;
+      }
+    }
+  }
   for (int d = 0; d <= a.max_depth; d++) {
-    for (int f = tid; f < a.n_frames; f += blockDim.x) {
-      if (a.depth[f] != d) continue;
+    if (have && depth == d) {
       Tf12 t;
       if (d == 0) {
         if (a.root_tf) t = tf_load(a.root_tf + (size_t)s * 12);
         else { for (int k = 0; k < 9; k++) t.m[k] = (k % 4 == 0) ? 1.0 : 0.0; t.o[0] = t.o[1] = t.o[2] = 0.0; }
       } else {
-        t = tf_mul(tf_load(s_t[a.parent[f]]), tf_load(a.joint_origin + (size_t)f * 12));
-        const int jt = a.joint_type[f];
-        if (jt == 1) {
-          const double q = a.q[(size_t)s * a.n_frames + f];
-          const double ax = a.joint_axis[3 * f], ay = a.joint_axis[3 * f + 1], az = a.joint_axis[3 * f + 2];
-          const double nn = sqrt(ax * ax + ay * ay + az * az);
-          const double ux = nn > 0 ? ax / nn : 1.0, uy = nn > 0 ? ay / nn : 0.0, uz = nn > 0 ? az / nn : 0.0;
-          const double sh = sin(0.5 * q), ch = cos(0.5 * q);
-          t = tf_mul(t, tf_from_quat(ux * sh, uy * sh, uz * sh, ch));
-        } else if (jt == 2) {
-          const double q = a.q[(size_t)s * a.n_frames + f];
-          Tf12 m;
-          for (int k2 = 0; k2 < 9; k2++) m.m[k2] = (k2 % 4 == 0) ? 1.0 : 0.0;
-          m.o[0] = a.joint_axis[3 * f] * q; m.o[1] = a.joint_axis[3 * f + 1] * q; m.o[2] = a.joint_axis[3 * f + 2] * q;
-          t = tf_mul(t, m);
-        }
+        t = tf_mul(tf_load(s_t[parent]), origin);
+        if (has_motion) t = tf_mul(t, motion);
       }
 #pragma unroll
       for (int k = 0; k < 9; k++) s_t[f][k] = t.m[k];
@@ -344,11 +355,11 @@ __global__ __launch_bounds__(128) void fk_tree_kernel(FkArgs a)
     }
     __syncthreads();
   }
-  for (int l = tid; l < a.n_links_model; l += blockDim.x) {
+  for (int l = threadIdx.x; l < a.n_links_model; l += blockDim.x) {
     const Tf12 t = tf_mul(tf_load(s_t[a.link_frame[l]]), tf_load(a.link_offset + (size_t)l * 12));
     tf_store_gl(t, a.link_tf + ((size_t)s * a.n_links_total + a.link_base + l) * 16);
   }
-  if (tid == 0 && a.camera_frame >= 0) {
+  if (threadIdx.x == 0 && a.camera_frame >= 0) {
     const Tf12 t = tf_load(s_t[a.camera_frame]);
     Tf12 inv;
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) inv.m[3 * i + j] = t.m[3 * j + i];
@@ -1287,7 +1298,8 @@ void launch_reset_clip(Counters* c, hipStream_t st)
 void launch_fk(const FkArgs& a, hipStream_t st)
 {
   if (a.n_frames <= kFkMaxFrames) {
-    hipLaunchKernelGGL(fk_tree_kernel, dim3(a.n_streams), dim3(128), 0, st, a);
+    const int threads = a.n_frames <= 64 ? 64 : (a.n_frames <= 128 ? 128 : kFkMaxFrames);
+    hipLaunchKernelGGL(fk_tree_kernel, dim3(a.n_streams), dim3(threads), 0, st, a);
     return;
   }
   const int total = a.n_streams * (a.n_links_model + 1);
@@ -1306,7 +1318,7 @@ void launch_setup(const SetupArgs& a, int n_chunks, hipStream_t st)
 void launch_clip(const SetupArgs& a, hipStream_t st)
 {
   // the item count lives on the device: fixed grid, grid-stride loop
-  hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * 8), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * 32), dim3(kBlock), 0, st, a);
 }
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st)
 {
