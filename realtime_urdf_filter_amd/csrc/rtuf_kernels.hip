@@ -402,6 +402,57 @@ __device__ __forceinline__ void edges_from_snapped(int x0, int y0, int x1, int y
   r.bby = (uint32_t)by0 | ((uint32_t)by1 << 16);
 }
 
+// Snap, sub-pixel cull, orientation.  Returns false when the triangle covers no pixel centre or is
+// degenerate; on success the snapped coordinates are oriented (area > 0, v0/v1 swapped if needed)
+// and bx/by hold the inclusive pixel bounding box.
+__device__ __forceinline__ bool orient_and_bound(Win& v0, Win& v1, const Win& v2, int width, int height,
+                                                 int& x0, int& y0, int& x1, int& y1, int& x2, int& y2,
+                                                 int& bx0, int& bx1, int& by0, int& by1)
+{
+  x0 = snap(v0.x); y0 = snap(v0.y);
+  x1 = snap(v1.x); y1 = snap(v1.y);
+  x2 = snap(v2.x); y2 = snap(v2.y);
+  const int minx = min(x0, min(x1, x2)), maxx = max(x0, max(x1, x2));
+  const int miny = min(y0, min(y1, y2)), maxy = max(y0, max(y1, y2));
+  bx0 = max((minx + 255) >> 8, 0); bx1 = min((maxx - 1) >> 8, width - 1);
+  by0 = max((miny + 255) >> 8, 0); by1 = min((maxy - 1) >> 8, height - 1);
+  if (bx1 < bx0 || by1 < by0) return false;
+  const long long area = (long long)(x0 - x1) * (y2 - y0) - (long long)(x2 - x0) * (y0 - y1);
+  if (area == 0) return false;
+  if (area < 0) {   // orient: swap vertices 0 and 1 (fixed and float)
+    int t = x0; x0 = x1; x1 = t;
+    t = y0; y0 = y1; y1 = t;
+    Win tw = v0; v0 = v1; v1 = tw;
+  }
+  return true;
+}
+
+// z plane from the unsnapped float vertices (lp_state_setup.c order)
+__device__ __forceinline__ void z_plane(const Win& v0, const Win& v1, const Win& v2, float& a0, float& dzdx, float& dzdy)
+{
+  const float x0c = __fsub_rn(v0.x, 0.5f), y0c = __fsub_rn(v0.y, 0.5f);
+  const float dx01 = __fsub_rn(v0.x, v1.x), dy01 = __fsub_rn(v0.y, v1.y);
+  const float dx20 = __fsub_rn(v2.x, v0.x), dy20 = __fsub_rn(v2.y, v0.y);
+  const float ooa = __fdiv_rn(1.0f, __fsub_rn(__fmul_rn(dx01, dy20), __fmul_rn(dy01, dx20)));
+  const float dy20o = __fmul_rn(dy20, ooa), dy01o = __fmul_rn(dy01, ooa);
+  const float dx20o = __fmul_rn(dx20, ooa), dx01o = __fmul_rn(dx01, ooa);
+  const float da01 = __fsub_rn(v0.z, v1.z), da20 = __fsub_rn(v2.z, v0.z);
+  dzdx = __fsub_rn(__fmul_rn(da01, dy20o), __fmul_rn(da20, dy01o));
+  dzdy = __fsub_rn(__fmul_rn(da20, dx01o), __fmul_rn(da01, dx20o));
+  a0 = __fsub_rn(v0.z, __fadd_rn(__fmul_rn(dzdx, x0c), __fmul_rn(dzdy, y0c)));
+}
+
+__device__ __forceinline__ PackedTri pack_record(int x0, int y0, int x1, int y1, int x2, int y2, float a0, float dzdx,
+                                                 float dzdy, uint32_t order)
+{
+  // snapped coordinates of in-frustum vertices lie in [-128, 2048*256]: 20 bits after the +128 bias
+  PackedTri pk;
+  pk.v01 = (unsigned long long)(uint32_t)(x0 + 128) | ((unsigned long long)(uint32_t)(y0 + 128) << 20) | ((unsigned long long)(uint32_t)(x1 + 128) << 40);
+  pk.v12 = (unsigned long long)(uint32_t)(y1 + 128) | ((unsigned long long)(uint32_t)(x2 + 128) << 20) | ((unsigned long long)(uint32_t)(y2 + 128) << 40);
+  pk.a0 = a0; pk.dzdx = dzdx; pk.dzdy = dzdy; pk.order = order;
+  return pk;
+}
+
 // Builds the raster record of one window-space triangle.  Returns false when it covers no
 // pixel centre of the width x height frame.  `pk` receives the 32-byte bin form.
 __device__ __forceinline__ bool make_record(Win v0, Win v1, Win v2, uint32_t order, int width, int height,
@@ -486,13 +537,13 @@ __device__ __forceinline__ uint32_t emit_record(const SetupArgs& a, int slot, co
 // atomicAdd in the SAME instruction, so a wave pays one atomic round trip per tile index
 // instead of one per distinct bin; group members get consecutive slots, which makes the
 // 64-byte record stores of neighbouring mesh triangles contiguous.
-__device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slot, bool have, const TriRec& r, const PackedTri& pk)
+__device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slot, bool have, uint32_t bbx, uint32_t bby, const PackedTri& pk)
 {
   const int lane = threadIdx.x & 63;
   int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
   if (have) {
-    tx0 = (int)(r.bbx & 0xffff) / kTileW; tx1 = (int)(r.bbx >> 16) / kTileW;
-    ty0 = (int)(r.bby & 0xffff) / kTileH; ty1 = (int)(r.bby >> 16) / kTileH;
+    tx0 = (int)(bbx & 0xffff) / kTileW; tx1 = (int)(bbx >> 16) / kTileW;
+    ty0 = (int)(bby & 0xffff) / kTileH; ty1 = (int)(bby >> 16) / kTileH;
   }
   const int tw = tx1 - tx0 + 1;
   const int ntile = have ? tw * (ty1 - ty0 + 1) : 0;
@@ -547,49 +598,86 @@ __device__ __forceinline__ bool inside(const TriRec& r, int px, int py)
   return (e0 > 0) & (e1 > 0) & (e2 > 0);
 }
 
-// Wave-cooperative emission of the covered pixels of tiny triangles (bounding box <= 2x2): four
-// rounds (one per bounding-box corner), each with the same ballot grouping / single atomic
-// round trip as emit_record_wave.  A tiny triangle that covers no pixel centre emits nothing.
-__device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int slot, bool tiny, const TriRec& r,
-                                                        int bx0, int bx1, int by0, int by1)
+// Wave-cooperative emission of the covered pixels of tiny triangles (bounding box <= 2x2 pixel
+// centres).  `mask` holds the coverage of the four box positions (bit dy*2+dx).  Normally all of them
+// lie in one tile: lanes are grouped by bin with ballots, the group leaders reserve popcount(mask)
+// slots each in ONE atomic round trip and every lane writes its fragments to consecutive slots.
+// A box that straddles a tile boundary falls back to one plain atomic per fragment.
+__device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int slot, uint32_t mask, int bx0, int by0,
+                                                        float a0, float dzdx, float dzdy, uint32_t order)
 {
   const int lane = threadIdx.x & 63;
   const int tiles = a.tiles_x * a.tiles_y;
-  uint32_t n = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int px = bx0 + (k & 1), py = by0 + (k >> 1);
-    const bool act = tiny && px <= bx1 && py <= by1 && inside(r, px, py);
-    unsigned long long pending = __ballot(act);
-    if (!pending) continue;
-    const int bin = act ? slot * tiles + (py / kTileH) * a.tiles_x + (px / kTileW) : -1;
-    unsigned long long mymask = 0;
+  const bool straddle = mask && (((bx0 % kTileW) == kTileW - 1 && (mask & 0xAu)) || ((by0 % kTileH) == kTileH - 1 && (mask & 0xCu)));
+  const bool act = mask && !straddle;
+  const uint32_t cnt = (uint32_t)__popc(mask);
+  unsigned long long pending = __ballot(act);
+  if (pending) {
+    const int bin = act ? slot * tiles + (by0 / kTileH) * a.tiles_x + (bx0 / kTileW) : -1;
+    // exclusive prefix of cnt inside each bin group, group total at the leader
+    uint32_t base_in_group = 0, group_total = 0;
     int myleader = lane;
     while (pending) {
       const int leader = __ffsll((long long)pending) - 1;
       const int lbin = __shfl(bin, leader);
-      const unsigned long long m = __ballot(act && bin == lbin);
-      if (act && bin == lbin) { mymask = m; myleader = leader; }
+      const bool mine = act && bin == lbin;
+      const unsigned long long m = __ballot(mine);
+      // members are few (neighbouring triangles): serial scan over the group's lanes via shuffles
+      uint32_t run = 0;
+      unsigned long long mm = m;
+      while (mm) {
+        const int l2 = __ffsll((long long)mm) - 1;
+        mm &= mm - 1;
+        const uint32_t c2 = __shfl(cnt, l2);
+        if (mine && lane == l2) base_in_group = run;
+        run += c2;
+      }
+      if (mine) { group_total = run; myleader = leader; }
       pending &= ~m;
     }
     uint32_t base = 0;
-    if (act && lane == myleader) base = atomicAdd(&a.fbin_count[bin], (uint32_t)__popcll(mymask));
+    if (act && lane == myleader) base = atomicAdd(&a.fbin_count[bin], group_total);
     base = __shfl(base, myleader);
     if (act) {
-      const uint32_t pos = base + (uint32_t)__popcll(mymask & ((1ull << lane) - 1ull));
-      if (pos < a.fcapacity) {
-        const float z = __fmaf_rn(r.dzdy, (float)py, __fmaf_rn(r.dzdx, (float)px, r.a0));
-        uint4 f;
-        f.x = (uint32_t)px | ((uint32_t)py << 16);
-        f.y = z24_of(z);
-        f.z = r.order;
-        f.w = __float_as_uint(z);
-        reinterpret_cast<uint4*>(a.fbins)[(size_t)bin * a.fcapacity + pos] = f;
+      uint32_t pos = base + base_in_group;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (mask & (1u << k)) {
+          const int px = bx0 + (k & 1), py = by0 + (k >> 1);
+          if (pos < a.fcapacity) {
+            const float z = __fmaf_rn(dzdy, (float)py, __fmaf_rn(dzdx, (float)px, a0));
+            uint4 f;
+            f.x = (uint32_t)px | ((uint32_t)py << 16);
+            f.y = z24_of(z);
+            f.z = order;
+            f.w = __float_as_uint(z);
+            reinterpret_cast<uint4*>(a.fbins)[(size_t)bin * a.fcapacity + pos] = f;
+          }
+          pos++;
+        }
       }
-      n++;
     }
   }
-  return n;
+  if (straddle) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (mask & (1u << k)) {
+        const int px = bx0 + (k & 1), py = by0 + (k >> 1);
+        const int bin = slot * tiles + (py / kTileH) * a.tiles_x + (px / kTileW);
+        const uint32_t pos = atomicAdd(&a.fbin_count[bin], 1u);
+        if (pos < a.fcapacity) {
+          const float z = __fmaf_rn(dzdy, (float)py, __fmaf_rn(dzdx, (float)px, a0));
+          uint4 f;
+          f.x = (uint32_t)px | ((uint32_t)py << 16);
+          f.y = z24_of(z);
+          f.z = order;
+          f.w = __float_as_uint(z);
+          reinterpret_cast<uint4*>(a.fbins)[(size_t)bin * a.fcapacity + pos] = f;
+        }
+      }
+    }
+  }
+  return cnt;
 }
 
 // True when the chunk's bounding sphere lies completely outside frustum plane `plane` (0..5 =
@@ -626,13 +714,14 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
   __shared__ int2 s_snap[kStreamsPerBlock][kMaxChunkVerts];    // snapped x; snapped y << 8 | clip mask
   __shared__ uint32_t s_packed[kBlock];                         // the chunk's triangles
   __shared__ uint16_t s_list[kStreamsPerBlock * kBlock];        // survivors: stream k << 8 | triangle
-  __shared__ uint32_t s_nlist;
+  __shared__ uint32_t s_nlist, s_ntiny;
   __shared__ uint32_t s_stat[3];
   __shared__ float s_mvp[kStreamsPerBlock][16];
   __shared__ uint32_t s_on[kStreamsPerBlock];
   const int tid = threadIdx.x;
   if (tid < 3) s_stat[tid] = 0;
   if (tid == 3) s_nlist = 0;
+  if (tid == 4) s_ntiny = 0;
   const int chunk_id = blockIdx.y;
   const int shard_id = (int)((blockIdx.x + blockIdx.y) % kCounterShards);
   CounterShard& shard = a.counters->shard[shard_id];
@@ -693,7 +782,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
     }
     __syncthreads();
     // phase 2
-    bool survive = false, needs_clip = false;
+    bool survive = false, needs_clip = false, tiny = false;
     if (have_tri) {
       const int2 p0 = s_snap[k][i0], p1 = s_snap[k][i1], p2 = s_snap[k][i2];
       const unsigned m0 = (unsigned)p0.y & 63u, m1 = (unsigned)p1.y & 63u, m2 = (unsigned)p2.y & 63u;
@@ -707,6 +796,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
           const int bx0 = max((minx + 255) >> 8, 0), bx1 = min((maxx - 1) >> 8, a.width - 1);
           const int by0 = max((miny + 255) >> 8, 0), by1 = min((maxy - 1) >> 8, a.height - 1);
           survive = bx1 >= bx0 && by1 >= by0;
+          tiny = survive && (bx1 - bx0) <= 1 && (by1 - by0) <= 1;
         }
       }
     }
@@ -727,24 +817,34 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
         }
       }
     }
-    const unsigned long long sm = __ballot(survive);
+    // survivors go to one of two LDS work lists: tiny boxes (<= 2x2 pixel centres: resolved to
+    // fragments) grow from the top of s_list, everything else (binned as records) from the bottom
+    const unsigned long long sm = __ballot(survive && !tiny), tm = __ballot(tiny);
     if (sm) {
       const int leader = __ffsll((long long)sm) - 1;
       uint32_t base = 0;
       if (lane == leader) base = atomicAdd(&s_nlist, (uint32_t)__popcll(sm));
       base = __shfl(base, leader);
-      if (survive) s_list[base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = (uint16_t)((k << 8) | tid);
+      if (survive && !tiny) s_list[base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = (uint16_t)((k << 8) | tid);
+    }
+    if (tm) {
+      const int leader = __ffsll((long long)tm) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&s_ntiny, (uint32_t)__popcll(tm));
+      base = __shfl(base, leader);
+      if (tiny) s_list[kStreamsPerBlock * kBlock - 1 - (base + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull)))] = (uint16_t)((k << 8) | tid);
     }
   }
   __syncthreads();
-  // phase 3: dense set-up + binning of the survivors of all streams
-  const uint32_t nlist = s_nlist;
+  // phase 3a: dense set-up + binning of the larger survivors as 32-byte records (the tile kernel
+  // rebuilds the edge functions, so only orientation, bounding box and z plane are needed here)
+  const uint32_t nlist = s_nlist, ntiny = s_ntiny;
   uint32_t binned = 0, entries = 0, nfrag = 0;
   for (uint32_t base = 0; base < nlist; base += kBlock) {
     const uint32_t j = base + tid;
     bool have = false;
-    TriRec r;
     PackedTri pk;
+    uint32_t bbx = 0, bby = 0;
     int slot = 0;
     if (j < nlist) {
       const uint32_t e = s_list[j];
@@ -756,17 +856,57 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
       v0.x = s_win[k][0][j0]; v0.y = s_win[k][1][j0]; v0.z = s_win[k][2][j0];
       v1.x = s_win[k][0][j1]; v1.y = s_win[k][1][j1]; v1.z = s_win[k][2][j1];
       v2.x = s_win[k][0][j2]; v2.y = s_win[k][1][j2]; v2.z = s_win[k][2][j2];
-      have = make_record(v0, v1, v2, is_bg ? 0u : ch.order_base + (uint32_t)t, a.width, a.height, r, pk);
+      int x0, y0, x1, y1, x2, y2, bx0, bx1, by0, by1;
+      have = orient_and_bound(v0, v1, v2, a.width, a.height, x0, y0, x1, y1, x2, y2, bx0, bx1, by0, by1);
+      if (have) {
+        float a0, dzdx, dzdy;
+        z_plane(v0, v1, v2, a0, dzdx, dzdy);
+        pk = pack_record(x0, y0, x1, y1, x2, y2, a0, dzdx, dzdy, is_bg ? 0u : ch.order_base + (uint32_t)t);
+        bbx = (uint32_t)bx0 | ((uint32_t)bx1 << 16);
+        bby = (uint32_t)by0 | ((uint32_t)by1 << 16);
+      }
     }
     if (__ballot(have)) {
-      // Tiny triangles (bounding box <= 2x2 pixel centres) are resolved to their covered pixels
-      // right here and binned as 16-byte fragments; everything else as a 64-byte triangle record.
-      const int bx0 = (int)(r.bbx & 0xffff), bx1 = (int)(r.bbx >> 16);
-      const int by0 = (int)(r.bby & 0xffff), by1 = (int)(r.bby >> 16);
-      const bool tiny = have && (bx1 - bx0) <= 1 && (by1 - by0) <= 1;
-      nfrag += emit_fragments_wave(a, slot, tiny, r, bx0, bx1, by0, by1);
-      entries += emit_record_wave(a, slot, have && !tiny, r, pk);
+      entries += emit_record_wave(a, slot, have, bbx, bby, pk);
       binned += have ? 1u : 0u;
+    }
+  }
+  // phase 3b: tiny survivors -> coverage of their <= 4 box positions -> 16-byte fragments; the z plane
+  // (one division) is only evaluated for triangles that actually cover a pixel centre
+  for (uint32_t base = 0; base < ntiny; base += kBlock) {
+    const uint32_t j = base + tid;
+    uint32_t mask = 0;
+    int slot = 0, bx0 = 0, by0 = 0;
+    float a0 = 0, dzdx = 0, dzdy = 0;
+    uint32_t order = 0;
+    if (j < ntiny) {
+      const uint32_t e = s_list[kStreamsPerBlock * kBlock - 1 - j];
+      const int k = (int)(e >> 8), t = (int)(e & 255u);
+      slot = blockIdx.x * kStreamsPerBlock + k;
+      const uint32_t p = s_packed[t];
+      const uint32_t j0 = p & 1023u, j1 = (p >> 10) & 1023u, j2 = (p >> 20) & 1023u;
+      Win v0, v1, v2;
+      v0.x = s_win[k][0][j0]; v0.y = s_win[k][1][j0]; v0.z = s_win[k][2][j0];
+      v1.x = s_win[k][0][j1]; v1.y = s_win[k][1][j1]; v1.z = s_win[k][2][j1];
+      v2.x = s_win[k][0][j2]; v2.y = s_win[k][1][j2]; v2.z = s_win[k][2][j2];
+      int x0, y0, x1, y1, x2, y2, bx1, by1;
+      if (orient_and_bound(v0, v1, v2, a.width, a.height, x0, y0, x1, y1, x2, y2, bx0, bx1, by0, by1)) {
+        TriRec r;
+        edges_from_snapped(x0, y0, x1, y1, x2, y2, a.width, a.height, r);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int px = bx0 + (q & 1), py = by0 + (q >> 1);
+          if (px <= bx1 && py <= by1 && inside(r, px, py)) mask |= 1u << q;
+        }
+        if (mask) {
+          z_plane(v0, v1, v2, a0, dzdx, dzdy);
+          order = is_bg ? 0u : ch.order_base + (uint32_t)t;
+        }
+      }
+    }
+    if (__ballot(mask != 0)) {
+      nfrag += emit_fragments_wave(a, slot, mask, bx0, by0, a0, dzdx, dzdy, order);
+      binned += mask ? 1u : 0u;
     }
   }
   // statistics: one (sharded) atomic triple per workgroup
