@@ -172,7 +172,7 @@ def main():
                            "binned_triangles_per_s": st["triangles_binned"] / (per["ms_raster"] * 1e-3) if per["ms_raster"] > 0 else None,
                            "triangles_submitted": st["triangles_submitted"], "triangles_binned": st["triangles_binned"],
                            "triangles_clipped": st["triangles_clipped"], "bin_entries": st["bin_entries"],
-                           "max_bin_fill": st["max_bin_fill"], "bin_capacity": st["bin_capacity"], "regrowths": st["regrowths"]},
+                           "fragments_binned": st["fragments_binned"], "max_bin_fill": st["max_bin_fill"], "max_fragment_bin_fill": st["max_fbin_fill"], "bin_capacity": st["bin_capacity"], "regrowths": st["regrowths"]},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                          "frac": achieved / peak, "traffic": traffic, "launches_per_step": groups,
                          "avg_launch_ms": dur_ms, "algorithmic_bytes_per_launch": alg_bytes},

@@ -73,7 +73,7 @@ struct rtuf_context {
   // rasteriser working set
   int group = 0;                       // in-flight streams per launch group
   uint32_t capacity = 0, fcapacity = 0, clip_capacity = 0;
-  PackedTri* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr;
+  PackedTri* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr; WorkItem* d_items = nullptr;
   Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
   Counters* d_counters = nullptr; Counters* h_counters = nullptr;
   float* d_zsurface = nullptr;
@@ -172,7 +172,7 @@ static void free_frame_buffers(rtuf_context* c)
   auto dfree = [](auto*& p) { if (p) { hipFree(p); p = nullptr; } };
   auto hfree = [](auto*& p) { if (p) { hipHostFree(p); p = nullptr; } };
   dfree(c->d_cams); dfree(c->d_link_tf); dfree(c->d_model_mask); dfree(c->d_mvp); dfree(c->d_bg_z); dfree(c->d_bg_mode);
-  dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_counters); dfree(c->d_zsurface);
+  dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_items); dfree(c->d_counters); dfree(c->d_zsurface);
   dfree(c->d_depth); dfree(c->d_masked); dfree(c->d_mask);
   hfree(c->h_cams); hfree(c->h_link_tf); hfree(c->h_model_mask); hfree(c->h_counters);
   c->staged_streams = 0;
@@ -295,13 +295,13 @@ static int alloc_frame_buffers(rtuf_context* c)
   G = std::min(G, N);
   uint32_t cap = c->params.bin_capacity;
   if (!cap) cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->n_tris + 16, 256), 4096);
-  // keep the bins under ~24 GiB by shrinking the in-flight group
-  const size_t budget = (size_t)24 << 30;
-  while (G > 1 && (size_t)G * tiles * cap * sizeof(PackedTri) > budget) G = (G + 1) / 2;
+  // keep the bins (records + fragments) under ~32 GiB by shrinking the in-flight group
+  const size_t budget = (size_t)32 << 30;
+  while (G > 1 && (size_t)G * tiles * cap * (sizeof(PackedTri) + 2 * sizeof(Frag)) > budget) G = (G + 1) / 2;
   c->group = G;
   c->capacity = cap;
   c->clip_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 8192 / kCounterShards, 1024), (size_t)1 << 22);   // per shard
-  c->fcapacity = std::max<uint32_t>(cap, 1024);
+  c->fcapacity = std::max<uint32_t>(2 * cap, 1024);   // 16-byte fragments of all boxes up to 4x4 pixel centres
   HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(PackedTri)));
   HIP_TRY(c, hipMalloc(&c->d_bin_count, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(c->d_bin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
@@ -309,6 +309,7 @@ static int alloc_frame_buffers(rtuf_context* c)
   HIP_TRY(c, hipMalloc(&c->d_fbin_count, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(c->d_fbin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
+  HIP_TRY(c, hipMalloc(&c->d_items, (size_t)c->n_chunks * ((G + kStreamsPerBlock - 1) / kStreamsPerBlock) * sizeof(WorkItem)));
   if (c->params.flags & RTUF_FLAG_TWO_KERNEL)
     HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)G * c->width * c->height * sizeof(float)));
   return RTUF_OK;
@@ -718,7 +719,9 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
     sa.clip_list = c->d_clip_list; sa.counters = c->d_counters; sa.group_base = base; sa.group_size = gs;
     sa.n_draws = c->n_draws; sa.width = c->width; sa.height = c->height; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
     sa.capacity = c->capacity; sa.clip_capacity = c->clip_capacity; sa.bg_chunk = c->bg_chunk;
-    launch_setup(sa, c->n_chunks, st);
+    sa.items = c->d_items; sa.n_chunks = c->n_chunks;
+    launch_cull(sa, st);
+    launch_setup(sa, st);
     launch_clip(sa, st);
     if (c->timing) hipEventRecord(get_event(c, ev++), st);
     TileArgs ta{};

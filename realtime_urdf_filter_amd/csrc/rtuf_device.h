@@ -115,7 +115,16 @@ struct alignas(128) CounterShard {
   unsigned int pad[22];
 };
 static_assert(sizeof(CounterShard) == 128, "CounterShard must be one 128-byte line");
-struct Counters { CounterShard shard[kCounterShards]; };
+struct alignas(128) WorkCount { unsigned int n_items; unsigned int pad[31]; };
+struct Counters { CounterShard shard[kCounterShards]; WorkCount work; };
+
+// One set-up workgroup's job: a chunk and up to kStreamsPerBlock stream slots (of the in-flight
+// group) whose frustum the chunk's bounding sphere touches; 0xffff = unused.  Written by cull_kernel.
+struct WorkItem {
+  uint32_t chunk;
+  uint16_t slot[6];
+};
+static_assert(sizeof(WorkItem) == 16, "WorkItem is one 16-byte load");
 
 struct FrameConsts {
   int width, height;
@@ -154,7 +163,9 @@ struct SetupArgs {
   uint32_t* fbin_count;          // [G][tiles]
   uint32_t fcapacity;
   ClipItem* clip_list;
+  WorkItem* items;               // [n_chunks * ceil(group / kStreamsPerBlock)] visible (chunk, streams) jobs of this group
   Counters* counters;
+  int n_chunks;
   int group_base;                // first stream slot of this in-flight group
   int group_size;
   int n_draws;
@@ -213,7 +224,8 @@ struct FkArgs {
 };
 void launch_fk(const FkArgs& a, hipStream_t st);
 void launch_pose(const PoseArgs& a, hipStream_t st);
-void launch_setup(const SetupArgs& a, int n_chunks, hipStream_t st);
+void launch_cull(const SetupArgs& a, hipStream_t st);
+void launch_setup(const SetupArgs& a, hipStream_t st);
 void launch_clip(const SetupArgs& a, hipStream_t st);
 void launch_reset_clip(Counters* c, hipStream_t st);
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st);   // a.io_u16 selects the 16UC1 variant

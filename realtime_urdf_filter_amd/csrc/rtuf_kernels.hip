@@ -371,6 +371,10 @@ __global__ __launch_bounds__(kFkMaxFrames) void fk_tree_kernel(FkArgs a)
 // ---------------------------------------------------------------------------------------
 // triangle set-up
 // ---------------------------------------------------------------------------------------
+#ifndef RTUF_SMALL_FRAGS
+#define RTUF_SMALL_FRAGS 1      // resolve <= 4x4 single-tile boxes to fragments in the set-up kernel
+#endif
+
 __device__ __forceinline__ int snap(float v)
 {
   return __float2int_rn(__fmul_rn(__fsub_rn(v, 0.5f), 256.0f));
@@ -402,6 +406,8 @@ __device__ __forceinline__ void edges_from_snapped(int x0, int y0, int x1, int y
   r.bby = (uint32_t)by0 | ((uint32_t)by1 << 16);
 }
 
+__device__ __forceinline__ int sext21(int v) { return (v << 11) >> 11; }
+
 // Snap, sub-pixel cull, orientation.  Returns false when the triangle covers no pixel centre or is
 // degenerate; on success the snapped coordinates are oriented (area > 0, v0/v1 swapped if needed)
 // and bx/by hold the inclusive pixel bounding box.
@@ -409,9 +415,12 @@ __device__ __forceinline__ bool orient_and_bound(Win& v0, Win& v1, const Win& v2
                                                  int& x0, int& y0, int& x1, int& y1, int& x2, int& y2,
                                                  int& bx0, int& bx1, int& by0, int& by1)
 {
-  x0 = snap(v0.x); y0 = snap(v0.y);
-  x1 = snap(v1.x); y1 = snap(v1.y);
-  x2 = snap(v2.x); y2 = snap(v2.y);
+  // vertices of unclipped triangles lie inside the frustum: snapped values are in [-128, 2048*256+128].
+  // The (value-preserving) 21-bit sign extension tells the compiler so, which turns the 64-bit
+  // products below into full-rate 24-bit multiplies.
+  x0 = sext21(snap(v0.x)); y0 = sext21(snap(v0.y));
+  x1 = sext21(snap(v1.x)); y1 = sext21(snap(v1.y));
+  x2 = sext21(snap(v2.x)); y2 = sext21(snap(v2.y));
   const int minx = min(x0, min(x1, x2)), maxx = max(x0, max(x1, x2));
   const int miny = min(y0, min(y1, y2)), maxy = max(y0, max(y1, y2));
   bx0 = max((minx + 255) >> 8, 0); bx1 = min((maxx - 1) >> 8, width - 1);
@@ -545,19 +554,15 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slo
     tx0 = (int)(bbx & 0xffff) / kTileW; tx1 = (int)(bbx >> 16) / kTileW;
     ty0 = (int)(bby & 0xffff) / kTileH; ty1 = (int)(bby >> 16) / kTileH;
   }
-  const int tw = tx1 - tx0 + 1;
-  const int ntile = have ? tw * (ty1 - ty0 + 1) : 0;
   const int tiles = a.tiles_x * a.tiles_y;
   uint32_t n = 0;
-  for (int k = 0;; k++) {
-    const bool act = k < ntile;
+  int tx = tx0, ty = ty0;                  // walks the touched tiles row by row
+  for (;;) {
+    const bool act = have && ty <= ty1;
     unsigned long long pending = __ballot(act);
     if (!pending) break;
-    int bin = -1;
-    if (act) {
-      const int ty = ty0 + k / tw, tx = tx0 + k % tw;
-      bin = slot * tiles + ty * a.tiles_x + tx;
-    }
+    const int bin = act ? __mul24(slot, tiles) + __mul24(ty, a.tiles_x) + tx : -1;
+    if (++tx > tx1) { tx = tx0; ty++; }
     unsigned long long mymask = 0;
     int myleader = lane;
     while (pending) {
@@ -598,23 +603,85 @@ __device__ __forceinline__ bool inside(const TriRec& r, int px, int py)
   return (e0 > 0) & (e1 > 0) & (e2 > 0);
 }
 
-// Wave-cooperative emission of the covered pixels of tiny triangles (bounding box <= 2x2 pixel
-// centres).  `mask` holds the coverage of the four box positions (bit dy*2+dx).  Normally all of them
-// lie in one tile: lanes are grouped by bin with ballots, the group leaders reserve popcount(mask)
-// slots each in ONE atomic round trip and every lane writes its fragments to consecutive slots.
-// A box that straddles a tile boundary falls back to one plain atomic per fragment.
+// Set-up + coverage of a triangle whose pixel-centre bounding box is at most N x N (N <= 4): returns
+// the covered box positions (bit dy*4+dx, origin bx0,by0) and orients v0/v1 like orient_and_bound.
+// All integer work is done relative to the box origin, where vertex coordinates are within
+// [-256, (N+1)*256] and every product fits 32 bits (full-rate 24-bit multiplies); the values are
+// the same integers the absolute 64-bit form yields.  Straight-line: all N*N candidates per lane.
+template <int N>
+__device__ __forceinline__ uint32_t small_box_coverage(Win& v0, Win& v1, const Win& v2, int width, int height, int& bx0, int& by0)
+{
+  int x0 = snap(v0.x), y0 = snap(v0.y);
+  int x1 = snap(v1.x), y1 = snap(v1.y);
+  int x2 = snap(v2.x), y2 = snap(v2.y);
+  const int minx = min(x0, min(x1, x2)), maxx = max(x0, max(x1, x2));
+  const int miny = min(y0, min(y1, y2)), maxy = max(y0, max(y1, y2));
+  bx0 = max((minx + 255) >> 8, 0);
+  by0 = max((miny + 255) >> 8, 0);
+  const int bx1 = min((maxx - 1) >> 8, width - 1), by1 = min((maxy - 1) >> 8, height - 1);
+  if (bx1 < bx0 || by1 < by0) return 0;
+  const int ox = bx0 << 8, oy = by0 << 8;
+  x0 -= ox; x1 -= ox; x2 -= ox;
+  y0 -= oy; y1 -= oy; y2 -= oy;
+  const int area = __mul24(x0 - x1, y2 - y0) - __mul24(x2 - x0, y0 - y1);
+  if (area == 0) return 0;
+  if (area < 0) {
+    int t = x0; x0 = x1; x1 = t;
+    t = y0; y0 = y1; y1 = t;
+    Win tw = v0; v0 = v1; v1 = tw;
+  }
+  const int xs[3] = {x0, x1, x2}, ys[3] = {y0, y1, y2};
+  int A[3], B[3], E[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int j = (i + 1) % 3;
+    const int dcdx = ys[i] - ys[j], dcdy = xs[i] - xs[j];
+    int c = __mul24(dcdx, xs[i]) - __mul24(dcdy, ys[i]);
+    if (dcdx < 0 || (dcdx == 0 && dcdy > 0)) c += 1;
+    A[i] = -dcdx; B[i] = dcdy;
+    E[i] = -((-c) >> 8) - 1;          // inside <=> E + A*dx + B*dy >= 0 (see edges_from_snapped)
+  }
+  uint32_t out = 0;
+#pragma unroll
+  for (int dy = 0; dy < N; dy++) {
+#pragma unroll
+    for (int dx = 0; dx < N; dx++) {
+      const int v = (E[0] + dx * A[0] + dy * B[0]) | (E[1] + dx * A[1] + dy * B[1]) | (E[2] + dx * A[2] + dy * B[2]);
+      out |= (uint32_t)(~v >> 31 & 1) << (dy * 4 + dx);
+    }
+  }
+  const uint32_t cols = ((2u << (bx1 - bx0)) - 1u) * 0x1111u;
+  const uint32_t rows = (uint32_t)((1ull << (4 * (by1 - by0 + 1))) - 1ull);
+  return out & cols & rows;
+}
+
+// Wave-cooperative emission of the covered pixels of small triangles as 16-byte fragments.  `mask`
+// holds the coverage of the box positions (bit dy*4+dx, box origin bx0,by0).  Lanes are grouped by bin
+// with ballots, the group leaders reserve popcount(mask) slots each in ONE atomic round trip and
+// every lane writes its fragments to consecutive slots.  With MAY_STRADDLE a box whose covered
+// positions lie in more than one tile falls back to one plain atomic per fragment.
+template <bool MAY_STRADDLE>
 __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int slot, uint32_t mask, int bx0, int by0,
                                                         float a0, float dzdx, float dzdy, uint32_t order)
 {
   const int lane = threadIdx.x & 63;
   const int tiles = a.tiles_x * a.tiles_y;
-  const bool straddle = mask && (((bx0 % kTileW) == kTileW - 1 && (mask & 0xAu)) || ((by0 % kTileH) == kTileH - 1 && (mask & 0xCu)));
+  bool straddle = false;
+  if (MAY_STRADDLE) {
+    // position dx (dy) lies in the next tile when bx0 % kTileW + dx >= kTileW
+    const int rx = kTileW - (bx0 % kTileW), ry = kTileH - (by0 % kTileH);     // positions left in this tile
+    const uint32_t colmask = rx >= 4 ? 0xffffu : (((1u << rx) - 1u) * 0x1111u);
+    const uint32_t rowmask = ry >= 4 ? 0xffffu : ((1u << (4 * ry)) - 1u);
+    straddle = (mask & ~(colmask & rowmask)) != 0;
+  }
   const bool act = mask && !straddle;
   const uint32_t cnt = (uint32_t)__popc(mask);
   unsigned long long pending = __ballot(act);
   if (pending) {
-    const int bin = act ? slot * tiles + (by0 / kTileH) * a.tiles_x + (bx0 / kTileW) : -1;
-    // exclusive prefix of cnt inside each bin group, group total at the leader
+    const int bin = act ? __mul24(slot, tiles) + __mul24(by0 / kTileH, a.tiles_x) + (bx0 / kTileW) : -1;
+    const unsigned long long c0 = __ballot(act && (cnt & 1u)), c1 = __ballot(act && (cnt & 2u)), c2 = __ballot(act && (cnt & 4u)),
+                             c3 = __ballot(act && (cnt & 8u)), c4 = __ballot(act && (cnt & 16u));
+    const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t base_in_group = 0, group_total = 0;
     int myleader = lane;
     while (pending) {
@@ -622,17 +689,12 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
       const int lbin = __shfl(bin, leader);
       const bool mine = act && bin == lbin;
       const unsigned long long m = __ballot(mine);
-      // members are few (neighbouring triangles): serial scan over the group's lanes via shuffles
-      uint32_t run = 0;
-      unsigned long long mm = m;
-      while (mm) {
-        const int l2 = __ffsll((long long)mm) - 1;
-        mm &= mm - 1;
-        const uint32_t c2 = __shfl(cnt, l2);
-        if (mine && lane == l2) base_in_group = run;
-        run += c2;
+      if (mine) {
+        const unsigned long long lo = m & below;
+        base_in_group = (uint32_t)(__popcll(c0 & lo) + 2 * __popcll(c1 & lo) + 4 * __popcll(c2 & lo) + 8 * __popcll(c3 & lo) + 16 * __popcll(c4 & lo));
+        group_total = (uint32_t)(__popcll(c0 & m) + 2 * __popcll(c1 & m) + 4 * __popcll(c2 & m) + 8 * __popcll(c3 & m) + 16 * __popcll(c4 & m));
+        myleader = leader;
       }
-      if (mine) { group_total = run; myleader = leader; }
       pending &= ~m;
     }
     uint32_t base = 0;
@@ -640,31 +702,12 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
     base = __shfl(base, myleader);
     if (act) {
       uint32_t pos = base + base_in_group;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (mask & (1u << k)) {
-          const int px = bx0 + (k & 1), py = by0 + (k >> 1);
-          if (pos < a.fcapacity) {
-            const float z = __fmaf_rn(dzdy, (float)py, __fmaf_rn(dzdx, (float)px, a0));
-            uint4 f;
-            f.x = (uint32_t)px | ((uint32_t)py << 16);
-            f.y = z24_of(z);
-            f.z = order;
-            f.w = __float_as_uint(z);
-            reinterpret_cast<uint4*>(a.fbins)[(size_t)bin * a.fcapacity + pos] = f;
-          }
-          pos++;
-        }
-      }
-    }
-  }
-  if (straddle) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (mask & (1u << k)) {
-        const int px = bx0 + (k & 1), py = by0 + (k >> 1);
-        const int bin = slot * tiles + (py / kTileH) * a.tiles_x + (px / kTileW);
-        const uint32_t pos = atomicAdd(&a.fbin_count[bin], 1u);
+      uint4* dst = reinterpret_cast<uint4*>(a.fbins) + (size_t)bin * a.fcapacity;
+      uint32_t m = mask;
+      while (m) {
+        const int k = __ffs((int)m) - 1;
+        m &= m - 1;
+        const int px = bx0 + (k & 3), py = by0 + (k >> 2);
         if (pos < a.fcapacity) {
           const float z = __fmaf_rn(dzdy, (float)py, __fmaf_rn(dzdx, (float)px, a0));
           uint4 f;
@@ -672,8 +715,28 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
           f.y = z24_of(z);
           f.z = order;
           f.w = __float_as_uint(z);
-          reinterpret_cast<uint4*>(a.fbins)[(size_t)bin * a.fcapacity + pos] = f;
+          dst[pos] = f;
         }
+        pos++;
+      }
+    }
+  }
+  if (MAY_STRADDLE && straddle) {
+    uint32_t m = mask;
+    while (m) {
+      const int k = __ffs((int)m) - 1;
+      m &= m - 1;
+      const int px = bx0 + (k & 3), py = by0 + (k >> 2);
+      const int bin = __mul24(slot, tiles) + __mul24(py / kTileH, a.tiles_x) + (px / kTileW);
+      const uint32_t pos = atomicAdd(&a.fbin_count[bin], 1u);
+      if (pos < a.fcapacity) {
+        const float z = __fmaf_rn(dzdy, (float)py, __fmaf_rn(dzdx, (float)px, a0));
+        uint4 f;
+        f.x = (uint32_t)px | ((uint32_t)py << 16);
+        f.y = z24_of(z);
+        f.z = order;
+        f.w = __float_as_uint(z);
+        reinterpret_cast<uint4*>(a.fbins)[(size_t)bin * a.fcapacity + pos] = f;
       }
     }
   }
@@ -708,22 +771,87 @@ __device__ __forceinline__ bool chunk_outside_plane(const float* M, const Chunk&
 //                         (typically < 20 %) are appended to an LDS work list
 //   once:        phase 3  the work list of all streams is processed by DENSE waves: full
 //                         set-up (edge functions, z plane) and binning
+// cull_kernel: one workgroup per chunk, one thread per stream slot of the in-flight group.  Tests
+// the chunk's bounding sphere against the six frustum planes of every stream (plus model selection /
+// background mode) and appends the visible streams, kStreamsPerBlock at a time, to the work list
+// the set-up kernel runs from.  The test is conservative, so it never changes the image; it only
+// keeps ~70 % of the (chunk, stream) pairs of a robot that is partly in view from ever starting a
+// set-up workgroup.
+static_assert(kStreamsPerBlock <= 6, "WorkItem holds at most 6 stream slots");
+__global__ __launch_bounds__(kBlock) void cull_kernel(SetupArgs a)
+{
+  __shared__ uint16_t s_vis[kBlock];
+  __shared__ uint32_t s_wave_n[kBlock / 64];
+  __shared__ uint32_t s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk_id = blockIdx.x;
+  const Chunk ch = a.chunks[chunk_id];
+  const bool is_bg = (uint32_t)chunk_id == a.bg_chunk;
+  for (int first = 0; first < a.group_size; first += kBlock) {
+    const int slot = first + tid;
+    bool vis = false;
+    if (slot < a.group_size) {
+      const int stream = a.group_base + slot;
+      vis = is_bg ? (a.bg_mode[stream] == 0u) : (((a.model_mask[stream] >> ch.model) & 1ull) != 0ull);
+      if (vis) {
+        float M[16];
+        const float4* src = reinterpret_cast<const float4*>(a.mvp + ((size_t)stream * (a.n_draws + 1) + ch.draw) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float4 col = src[q];
+          M[4 * q] = col.x; M[4 * q + 1] = col.y; M[4 * q + 2] = col.z; M[4 * q + 3] = col.w;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 6; pl++) vis = vis && !chunk_outside_plane(M, ch, pl);
+      }
+    }
+    // ordered compaction (wave ballots + a 4-entry prefix): the list order is deterministic
+    const unsigned long long vm = __ballot(vis);
+    if (lane == 0) s_wave_n[wave] = (uint32_t)__popcll(vm);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) { const uint32_t c = s_wave_n[w]; if (w < wave) before += c; total += c; }
+    if (vis) s_vis[before + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] = (uint16_t)slot;
+    const uint32_t n_items = (total + kStreamsPerBlock - 1) / kStreamsPerBlock;
+    if (tid == 0 && n_items) s_base = atomicAdd(&a.counters->work.n_items, n_items);
+    __syncthreads();
+    if ((uint32_t)tid < n_items) {
+      WorkItem it;
+      it.chunk = (uint32_t)chunk_id;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const uint32_t j = (uint32_t)tid * kStreamsPerBlock + k;
+        it.slot[k] = (k < kStreamsPerBlock && j < total) ? s_vis[j] : (uint16_t)0xffffu;
+      }
+      *reinterpret_cast<uint4*>(&a.items[s_base + tid]) = *reinterpret_cast<const uint4*>(&it);
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
 {
   __shared__ float s_win[kStreamsPerBlock][3][kMaxChunkVerts];  // window x, y, z (SoA: 12 B per vertex)
   __shared__ int2 s_snap[kStreamsPerBlock][kMaxChunkVerts];    // snapped x; snapped y << 8 | clip mask
   __shared__ uint32_t s_packed[kBlock];                         // the chunk's triangles
   __shared__ uint16_t s_list[kStreamsPerBlock * kBlock];        // survivors: stream k << 8 | triangle
-  __shared__ uint32_t s_nlist, s_ntiny;
+  __shared__ uint16_t s_list2[kStreamsPerBlock * kBlock];       // survivors resolved as 4x4 fragment boxes
+  __shared__ uint32_t s_nlist, s_ntiny, s_nsmall;
   __shared__ uint32_t s_stat[3];
   __shared__ float s_mvp[kStreamsPerBlock][16];
   __shared__ uint32_t s_on[kStreamsPerBlock];
+  __shared__ int s_slot[kStreamsPerBlock];
   const int tid = threadIdx.x;
   if (tid < 3) s_stat[tid] = 0;
   if (tid == 3) s_nlist = 0;
   if (tid == 4) s_ntiny = 0;
-  const int chunk_id = blockIdx.y;
-  const int shard_id = (int)((blockIdx.x + blockIdx.y) % kCounterShards);
+  if (tid == 5) s_nsmall = 0;
+  if (blockIdx.x >= a.counters->work.n_items) return;      // the grid is sized for the worst case
+  const uint4 item_raw = reinterpret_cast<const uint4*>(a.items)[blockIdx.x];
+  const WorkItem& item = reinterpret_cast<const WorkItem&>(item_raw);
+  const int chunk_id = (int)item.chunk;
+  const int shard_id = (int)(blockIdx.x % kCounterShards);
   CounterShard& shard = a.counters->shard[shard_id];
   const Chunk ch = a.chunks[chunk_id];
   const bool is_bg = (uint32_t)chunk_id == a.bg_chunk;
@@ -737,33 +865,24 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
   const uint32_t i0 = packed & 1023u, i1 = (packed >> 10) & 1023u, i2 = (packed >> 20) & 1023u;
   const float sx = 0.5f * (float)a.width, sy = 0.5f * (float)a.height;
   const int lane = tid & 63;
-  // all matrices of the stream group are fetched up front (one global round trip per workgroup
+  // all matrices of the item's streams are fetched up front (one global round trip per workgroup
   // instead of one per stream) and kept in LDS
   if (tid < kStreamsPerBlock * 16) {
-    const int k = tid >> 4, slot = blockIdx.x * kStreamsPerBlock + k;
+    const int k = tid >> 4, slot = (int)item.slot[k];
     float v = 0.0f;
-    if (slot < a.group_size)
+    if (slot != 0xffff)
       v = a.mvp[((size_t)(a.group_base + slot) * (a.n_draws + 1) + ch.draw) * 16 + (tid & 15)];
     s_mvp[k][tid & 15] = v;
   }
   if (tid >= 64 && tid < 64 + kStreamsPerBlock) {
-    const int k = tid - 64, slot = blockIdx.x * kStreamsPerBlock + k;
-    uint32_t on = 0;
-    if (slot < a.group_size) {
-      const int stream = a.group_base + slot;
-      on = is_bg ? (a.bg_mode[stream] ? 0u : 1u) : (uint32_t)((a.model_mask[stream] >> ch.model) & 1ull);
-    }
-    s_on[k] = on;
-  }
-  __syncthreads();
-  if (tid < kStreamsPerBlock * 6) {
-    const int k = tid / 6;
-    if (s_on[k] && chunk_outside_plane(s_mvp[k], ch, tid % 6)) s_on[k] = 0;   // benign race: all writers store 0
+    const int k = tid - 64;
+    s_on[k] = item.slot[k] != 0xffff ? 1u : 0u;
+    s_slot[k] = (int)item.slot[k];
   }
   __syncthreads();
 
   for (int k = 0; k < kStreamsPerBlock; k++) {
-    const int slot = blockIdx.x * kStreamsPerBlock + k;
+    const int slot = s_slot[k];
     if (!s_on[k]) continue;                              // uniform per workgroup
     // phase 1
     if (have_vert) {
@@ -782,7 +901,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
     }
     __syncthreads();
     // phase 2
-    bool survive = false, needs_clip = false, tiny = false;
+    bool survive = false, needs_clip = false, tiny = false, small = false;
     if (have_tri) {
       const int2 p0 = s_snap[k][i0], p1 = s_snap[k][i1], p2 = s_snap[k][i2];
       const unsigned m0 = (unsigned)p0.y & 63u, m1 = (unsigned)p1.y & 63u, m2 = (unsigned)p2.y & 63u;
@@ -797,6 +916,10 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
           const int by0 = max((miny + 255) >> 8, 0), by1 = min((maxy - 1) >> 8, a.height - 1);
           survive = bx1 >= bx0 && by1 >= by0;
           tiny = survive && (bx1 - bx0) <= 1 && (by1 - by0) <= 1;
+          // up to 4x4 candidates inside ONE tile: also resolved to fragments here (boxes that straddle
+          // a tile boundary stay records)
+          small = survive && !tiny && (bx1 - bx0) <= 3 && (by1 - by0) <= 3 && RTUF_SMALL_FRAGS &&
+                  (bx0 / kTileW) == (bx1 / kTileW) && (by0 / kTileH) == (by1 / kTileH);
         }
       }
     }
@@ -819,13 +942,14 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
     }
     // survivors go to one of two LDS work lists: tiny boxes (<= 2x2 pixel centres: resolved to
     // fragments) grow from the top of s_list, everything else (binned as records) from the bottom
-    const unsigned long long sm = __ballot(survive && !tiny), tm = __ballot(tiny);
+    const bool rec = survive && !tiny && !small;
+    const unsigned long long sm = __ballot(rec), tm = __ballot(tiny), qm = __ballot(small);
     if (sm) {
       const int leader = __ffsll((long long)sm) - 1;
       uint32_t base = 0;
       if (lane == leader) base = atomicAdd(&s_nlist, (uint32_t)__popcll(sm));
       base = __shfl(base, leader);
-      if (survive && !tiny) s_list[base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = (uint16_t)((k << 8) | tid);
+      if (rec) s_list[base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = (uint16_t)((k << 8) | tid);
     }
     if (tm) {
       const int leader = __ffsll((long long)tm) - 1;
@@ -833,6 +957,13 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
       if (lane == leader) base = atomicAdd(&s_ntiny, (uint32_t)__popcll(tm));
       base = __shfl(base, leader);
       if (tiny) s_list[kStreamsPerBlock * kBlock - 1 - (base + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull)))] = (uint16_t)((k << 8) | tid);
+    }
+    if (qm) {
+      const int leader = __ffsll((long long)qm) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&s_nsmall, (uint32_t)__popcll(qm));
+      base = __shfl(base, leader);
+      if (small) s_list2[base + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull))] = (uint16_t)((k << 8) | tid);
     }
   }
   __syncthreads();
@@ -849,7 +980,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
     if (j < nlist) {
       const uint32_t e = s_list[j];
       const int k = (int)(e >> 8), t = (int)(e & 255u);
-      slot = blockIdx.x * kStreamsPerBlock + k;
+      slot = s_slot[k];
       const uint32_t p = s_packed[t];
       const uint32_t j0 = p & 1023u, j1 = (p >> 10) & 1023u, j2 = (p >> 20) & 1023u;
       Win v0, v1, v2;
@@ -871,42 +1002,41 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
       binned += have ? 1u : 0u;
     }
   }
-  // phase 3b: tiny survivors -> coverage of their <= 4 box positions -> 16-byte fragments; the z plane
-  // (one division) is only evaluated for triangles that actually cover a pixel centre
-  for (uint32_t base = 0; base < ntiny; base += kBlock) {
-    const uint32_t j = base + tid;
-    uint32_t mask = 0;
-    int slot = 0, bx0 = 0, by0 = 0;
-    float a0 = 0, dzdx = 0, dzdy = 0;
-    uint32_t order = 0;
-    if (j < ntiny) {
-      const uint32_t e = s_list[kStreamsPerBlock * kBlock - 1 - j];
-      const int k = (int)(e >> 8), t = (int)(e & 255u);
-      slot = blockIdx.x * kStreamsPerBlock + k;
-      const uint32_t p = s_packed[t];
-      const uint32_t j0 = p & 1023u, j1 = (p >> 10) & 1023u, j2 = (p >> 20) & 1023u;
-      Win v0, v1, v2;
-      v0.x = s_win[k][0][j0]; v0.y = s_win[k][1][j0]; v0.z = s_win[k][2][j0];
-      v1.x = s_win[k][0][j1]; v1.y = s_win[k][1][j1]; v1.z = s_win[k][2][j1];
-      v2.x = s_win[k][0][j2]; v2.y = s_win[k][1][j2]; v2.z = s_win[k][2][j2];
-      int x0, y0, x1, y1, x2, y2, bx1, by1;
-      if (orient_and_bound(v0, v1, v2, a.width, a.height, x0, y0, x1, y1, x2, y2, bx0, bx1, by0, by1)) {
-        TriRec r;
-        edges_from_snapped(x0, y0, x1, y1, x2, y2, a.width, a.height, r);
+  // phase 3b/3c: tiny (2x2) and small (4x4, single tile) survivors -> coverage of their box positions
+  // -> 16-byte fragments; the z plane (one division) is only evaluated for triangles that actually
+  // cover a pixel centre
+  const uint32_t nsmall = s_nsmall;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int px = bx0 + (q & 1), py = by0 + (q >> 1);
-          if (px <= bx1 && py <= by1 && inside(r, px, py)) mask |= 1u << q;
-        }
+  for (int cls = 0; cls < 2; cls++) {
+    const uint32_t ncls = cls == 0 ? ntiny : nsmall;
+    for (uint32_t base = 0; base < ncls; base += kBlock) {
+      const uint32_t j = base + tid;
+      uint32_t mask = 0;
+      int slot = 0, bx0 = 0, by0 = 0;
+      float a0 = 0, dzdx = 0, dzdy = 0;
+      uint32_t order = 0;
+      if (j < ncls) {
+        const uint32_t e = cls == 0 ? s_list[kStreamsPerBlock * kBlock - 1 - j] : s_list2[j];
+        const int k = (int)(e >> 8), t = (int)(e & 255u);
+        slot = s_slot[k];
+        const uint32_t p = s_packed[t];
+        const uint32_t j0 = p & 1023u, j1 = (p >> 10) & 1023u, j2 = (p >> 20) & 1023u;
+        Win v0, v1, v2;
+        v0.x = s_win[k][0][j0]; v0.y = s_win[k][1][j0]; v0.z = s_win[k][2][j0];
+        v1.x = s_win[k][0][j1]; v1.y = s_win[k][1][j1]; v1.z = s_win[k][2][j1];
+        v2.x = s_win[k][0][j2]; v2.y = s_win[k][1][j2]; v2.z = s_win[k][2][j2];
+        mask = cls == 0 ? small_box_coverage<2>(v0, v1, v2, a.width, a.height, bx0, by0)
+                        : small_box_coverage<4>(v0, v1, v2, a.width, a.height, bx0, by0);
         if (mask) {
           z_plane(v0, v1, v2, a0, dzdx, dzdy);
           order = is_bg ? 0u : ch.order_base + (uint32_t)t;
         }
       }
-    }
-    if (__ballot(mask != 0)) {
-      nfrag += emit_fragments_wave(a, slot, mask, bx0, by0, a0, dzdx, dzdy, order);
-      binned += mask ? 1u : 0u;
+      if (__ballot(mask != 0)) {
+        nfrag += cls == 0 ? emit_fragments_wave<true>(a, slot, mask, bx0, by0, a0, dzdx, dzdy, order)
+                          : emit_fragments_wave<false>(a, slot, mask, bx0, by0, a0, dzdx, dzdy, order);
+        binned += mask ? 1u : 0u;
+      }
     }
   }
   // statistics: one (sharded) atomic triple per workgroup
@@ -1428,12 +1558,13 @@ __global__ void reset_clip_kernel(Counters* c)
 {
   const int i = threadIdx.x;
   if (i < kCounterShards) c->shard[i].clip_count = 0;
+  if (i == kCounterShards) c->work.n_items = 0;
 }
 
 // host-callable launchers ---------------------------------------------------------------
 void launch_reset_clip(Counters* c, hipStream_t st)
 {
-  hipLaunchKernelGGL(reset_clip_kernel, dim3(1), dim3(kCounterShards), 0, st, c);
+  hipLaunchKernelGGL(reset_clip_kernel, dim3(1), dim3(2 * kCounterShards), 0, st, c);
 }
 void launch_fk(const FkArgs& a, hipStream_t st)
 {
@@ -1450,10 +1581,16 @@ void launch_pose(const PoseArgs& a, hipStream_t st)
   const int total = a.n_streams * (a.n_draws + 1);
   hipLaunchKernelGGL(pose_kernel, dim3((total + 127) / 128), dim3(128), 0, st, a);
 }
-void launch_setup(const SetupArgs& a, int n_chunks, hipStream_t st)
+void launch_cull(const SetupArgs& a, hipStream_t st)
 {
-  // x = stream group (fastest: consecutive workgroups share the chunk's geometry in L2), y = chunk
-  hipLaunchKernelGGL(setup_kernel, dim3((a.group_size + kStreamsPerBlock - 1) / kStreamsPerBlock, n_chunks), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL(cull_kernel, dim3(a.n_chunks), dim3(kBlock), 0, st, a);
+}
+void launch_setup(const SetupArgs& a, hipStream_t st)
+{
+  // worst case: every chunk visible in every stream; workgroups beyond the work list exit at once.
+  // Items of one chunk are consecutive, so neighbouring workgroups share its geometry in L2.
+  const int per_chunk = (a.group_size + kStreamsPerBlock - 1) / kStreamsPerBlock;
+  hipLaunchKernelGGL(setup_kernel, dim3((unsigned)(a.n_chunks * per_chunk)), dim3(kBlock), 0, st, a);
 }
 void launch_clip(const SetupArgs& a, hipStream_t st)
 {
