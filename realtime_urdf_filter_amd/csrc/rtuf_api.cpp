@@ -73,7 +73,7 @@ struct rtuf_context {
   // rasteriser working set
   int group = 0;                       // in-flight streams per launch group
   uint32_t capacity = 0, fcapacity = 0, clip_capacity = 0;
-  PackedTri* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr; WorkItem* d_items = nullptr;
+  PackedTri* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr; WorkItem* d_items = nullptr; uint32_t items_hint = 0;
   Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
   Counters* d_counters = nullptr; Counters* h_counters = nullptr;
   float* d_zsurface = nullptr;
@@ -721,7 +721,7 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
     sa.capacity = c->capacity; sa.clip_capacity = c->clip_capacity; sa.bg_chunk = c->bg_chunk;
     sa.items = c->d_items; sa.n_chunks = c->n_chunks;
     launch_cull(sa, st);
-    launch_setup(sa, st);
+    launch_setup(sa, c->items_hint, st);
     launch_clip(sa, st);
     if (c->timing) hipEventRecord(get_event(c, ev++), st);
     TileArgs ta{};
@@ -792,6 +792,7 @@ int rtuf_sync(rtuf_context* c)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (!c->pending) return RTUF_OK;
     struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0; unsigned max_bin_fill = 0, max_fbin_fill = 0, clip_overflow = 0; } k;
+    c->items_hint = c->h_counters->work.n_items;      // sizes the next batch's set-up grid
     for (int i = 0; i < kCounterShards; i++) {
       const CounterShard& sh = c->h_counters->shard[i];
       k.tris_binned += sh.tris_binned; k.bin_entries += sh.bin_entries; k.clip_count += sh.clip_count;

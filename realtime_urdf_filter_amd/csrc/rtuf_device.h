@@ -120,11 +120,16 @@ struct Counters { CounterShard shard[kCounterShards]; WorkCount work; };
 
 // One set-up workgroup's job: a chunk and up to kStreamsPerBlock stream slots (of the in-flight
 // group) whose frustum the chunk's bounding sphere touches; 0xffff = unused.  Written by cull_kernel.
-struct WorkItem {
+struct alignas(32) WorkItem {
   uint32_t chunk;
-  uint16_t slot[6];
+  uint32_t tri_begin;           // copies of the chunk's fields: the set-up workgroup needs no Chunk load
+  uint32_t vert_begin;
+  uint32_t order_base;
+  uint32_t draw;
+  uint16_t tri_count, vert_count;
+  uint16_t slot[4];
 };
-static_assert(sizeof(WorkItem) == 16, "WorkItem is one 16-byte load");
+static_assert(sizeof(WorkItem) == 32, "WorkItem is two 16-byte loads");
 
 struct FrameConsts {
   int width, height;
@@ -225,7 +230,7 @@ struct FkArgs {
 void launch_fk(const FkArgs& a, hipStream_t st);
 void launch_pose(const PoseArgs& a, hipStream_t st);
 void launch_cull(const SetupArgs& a, hipStream_t st);
-void launch_setup(const SetupArgs& a, hipStream_t st);
+void launch_setup(const SetupArgs& a, uint32_t items_hint, hipStream_t st);
 void launch_clip(const SetupArgs& a, hipStream_t st);
 void launch_reset_clip(Counters* c, hipStream_t st);
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st);   // a.io_u16 selects the 16UC1 variant

@@ -541,6 +541,44 @@ __device__ __forceinline__ uint32_t emit_record(const SetupArgs& a, int slot, co
   return n;
 }
 
+// Records whose bounding box touches more than kCoopTiles tiles (the robot's own arm in front of
+// the camera, clipped near-plane triangles) are appended cooperatively: one triangle at a time is
+// broadcast to the wave and the 64 lanes take one tile each, so a 7x7-tile triangle costs one
+// atomic round trip instead of 49 serial ones in a single lane.
+constexpr int kCoopTiles = 4;
+__device__ __forceinline__ uint32_t emit_big_records_wave(const SetupArgs& a, int slot, bool big, uint32_t bbx, uint32_t bby,
+                                                          const PackedTri& pk)
+{
+  const int lane = threadIdx.x & 63;
+  const int tiles = a.tiles_x * a.tiles_y;
+  uint32_t n = 0;
+  unsigned long long todo = __ballot(big);
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    PackedTri q;
+    {
+      const int* sp = reinterpret_cast<const int*>(&pk);
+      int* dp = reinterpret_cast<int*>(&q);
+#pragma unroll
+      for (int k = 0; k < 8; k++) dp[k] = __builtin_amdgcn_readlane(sp[k], src);
+    }
+    const uint32_t qx = (uint32_t)__builtin_amdgcn_readlane((int)bbx, src), qy = (uint32_t)__builtin_amdgcn_readlane((int)bby, src);
+    const int qslot = __builtin_amdgcn_readlane(slot, src);
+    const int tx0 = (int)(qx & 0xffff) / kTileW, tx1 = (int)(qx >> 16) / kTileW;
+    const int ty0 = (int)(qy & 0xffff) / kTileH, ty1 = (int)(qy >> 16) / kTileH;
+    const int tw = tx1 - tx0 + 1, ntile = tw * (ty1 - ty0 + 1);
+    for (int k = lane; k < ntile; k += 64) {
+      const int row = k / tw, tx = tx0 + k - row * tw;
+      const int bin = __mul24(qslot, tiles) + __mul24(ty0 + row, a.tiles_x) + tx;
+      const uint32_t pos = atomicAdd(&a.bin_count[bin], 1u);
+      if (pos < a.capacity) store_record(a.bins + (size_t)bin * a.capacity + pos, q);
+    }
+    if (lane == src) n += (uint32_t)ntile;
+  }
+  return n;
+}
+
 // Wave-cooperative form: all 64 lanes call it; lanes with `have` own a record.  Lanes that
 // target the same bin are grouped with ballots (ALU only), then every group leader issues its
 // atomicAdd in the SAME instruction, so a wave pays one atomic round trip per tile index
@@ -556,6 +594,9 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slo
   }
   const int tiles = a.tiles_x * a.tiles_y;
   uint32_t n = 0;
+  const bool big = have && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kCoopTiles;
+  if (__ballot(big)) n += emit_big_records_wave(a, slot, big, bbx, bby, pk);
+  have = have && !big;
   int tx = tx0, ty = ty0;                  // walks the touched tiles row by row
   for (;;) {
     const bool act = have && ty <= ty1;
@@ -777,7 +818,7 @@ __device__ __forceinline__ bool chunk_outside_plane(const float* M, const Chunk&
 // the set-up kernel runs from.  The test is conservative, so it never changes the image; it only
 // keeps ~70 % of the (chunk, stream) pairs of a robot that is partly in view from ever starting a
 // set-up workgroup.
-static_assert(kStreamsPerBlock <= 6, "WorkItem holds at most 6 stream slots");
+static_assert(kStreamsPerBlock <= 4, "WorkItem holds at most 4 stream slots");
 __global__ __launch_bounds__(kBlock) void cull_kernel(SetupArgs a)
 {
   __shared__ uint16_t s_vis[kBlock];
@@ -819,18 +860,23 @@ __global__ __launch_bounds__(kBlock) void cull_kernel(SetupArgs a)
     if ((uint32_t)tid < n_items) {
       WorkItem it;
       it.chunk = (uint32_t)chunk_id;
+      it.tri_begin = ch.tri_begin; it.vert_begin = ch.vert_begin; it.order_base = ch.order_base; it.draw = ch.draw;
+      it.tri_count = (uint16_t)ch.tri_count; it.vert_count = (uint16_t)ch.vert_count;
 #pragma unroll
-      for (int k = 0; k < 6; k++) {
+      for (int k = 0; k < 4; k++) {
         const uint32_t j = (uint32_t)tid * kStreamsPerBlock + k;
         it.slot[k] = (k < kStreamsPerBlock && j < total) ? s_vis[j] : (uint16_t)0xffffu;
       }
-      *reinterpret_cast<uint4*>(&a.items[s_base + tid]) = *reinterpret_cast<const uint4*>(&it);
+      uint4* dst = reinterpret_cast<uint4*>(&a.items[s_base + tid]);
+      dst[0] = reinterpret_cast<const uint4*>(&it)[0];
+      dst[1] = reinterpret_cast<const uint4*>(&it)[1];
     }
     __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
+template <bool STRIDED>
+__global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t item_base)
 {
   __shared__ float s_win[kStreamsPerBlock][3][kMaxChunkVerts];  // window x, y, z (SoA: 12 B per vertex)
   __shared__ int2 s_snap[kStreamsPerBlock][kMaxChunkVerts];    // snapped x; snapped y << 8 | clip mask
@@ -843,17 +889,38 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
   __shared__ uint32_t s_on[kStreamsPerBlock];
   __shared__ int s_slot[kStreamsPerBlock];
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
   if (tid < 3) s_stat[tid] = 0;
+  const int shard_id = (int)(blockIdx.x % kCounterShards);
+  CounterShard& shard = a.counters->shard[shard_id];
+  const float sx = 0.5f * (float)a.width, sy = 0.5f * (float)a.height;
+  uint32_t binned = 0, entries = 0, nfrag = 0;
+  // launch_setup sizes the main grid from the previous batch's work-list length: one item per
+  // workgroup (STRIDED = false, no loop: keeps the register count at 8 waves/SIMD).  Items beyond that
+  // grid, if the list grew, are swept by a small strided launch of the same code.
+  const uint32_t n_items = a.counters->work.n_items;
+  for (uint32_t item_id = item_base + blockIdx.x; item_id < n_items; item_id += gridDim.x) {
   if (tid == 3) s_nlist = 0;
   if (tid == 4) s_ntiny = 0;
   if (tid == 5) s_nsmall = 0;
-  if (blockIdx.x >= a.counters->work.n_items) return;      // the grid is sized for the worst case
-  const uint4 item_raw = reinterpret_cast<const uint4*>(a.items)[blockIdx.x];
-  const WorkItem& item = reinterpret_cast<const WorkItem&>(item_raw);
-  const int chunk_id = (int)item.chunk;
-  const int shard_id = (int)(blockIdx.x % kCounterShards);
-  CounterShard& shard = a.counters->shard[shard_id];
-  const Chunk ch = a.chunks[chunk_id];
+  // the item carries the chunk's ranges, so the geometry loads depend on it alone
+  struct { uint32_t tri_begin, vert_begin, order_base, draw, tri_count, vert_count; } ch;
+  uint32_t slots01, slots23;
+  int chunk_id;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(&a.items[item_id]);
+    uint4 w0 = src[0], w1 = src[1];
+    // same address in every lane: move the words to scalar registers so that everything derived
+    // from them (ranges, loop bounds, matrix addresses) is wave-uniform for the compiler as well
+    w0.x = __builtin_amdgcn_readfirstlane(w0.x); w0.y = __builtin_amdgcn_readfirstlane(w0.y);
+    w0.z = __builtin_amdgcn_readfirstlane(w0.z); w0.w = __builtin_amdgcn_readfirstlane(w0.w);
+    w1.x = __builtin_amdgcn_readfirstlane(w1.x); w1.y = __builtin_amdgcn_readfirstlane(w1.y);
+    w1.z = __builtin_amdgcn_readfirstlane(w1.z); w1.w = __builtin_amdgcn_readfirstlane(w1.w);
+    chunk_id = (int)w0.x; ch.tri_begin = w0.y; ch.vert_begin = w0.z; ch.order_base = w0.w;
+    ch.draw = w1.x; ch.tri_count = w1.y & 0xffffu; ch.vert_count = w1.y >> 16;
+    slots01 = w1.z; slots23 = w1.w;
+  }
+  auto item_slot = [&](int k) { return (int)(((k < 2 ? slots01 : slots23) >> (16 * (k & 1))) & 0xffffu); };
   const bool is_bg = (uint32_t)chunk_id == a.bg_chunk;
 
   float4 pv = make_float4(0, 0, 0, 1);
@@ -863,12 +930,10 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
   const uint32_t packed = have_tri ? a.ctris[ch.tri_begin + tid] : 0u;
   s_packed[tid] = packed;
   const uint32_t i0 = packed & 1023u, i1 = (packed >> 10) & 1023u, i2 = (packed >> 20) & 1023u;
-  const float sx = 0.5f * (float)a.width, sy = 0.5f * (float)a.height;
-  const int lane = tid & 63;
   // all matrices of the item's streams are fetched up front (one global round trip per workgroup
   // instead of one per stream) and kept in LDS
   if (tid < kStreamsPerBlock * 16) {
-    const int k = tid >> 4, slot = (int)item.slot[k];
+    const int k = tid >> 4, slot = item_slot(k);
     float v = 0.0f;
     if (slot != 0xffff)
       v = a.mvp[((size_t)(a.group_base + slot) * (a.n_draws + 1) + ch.draw) * 16 + (tid & 15)];
@@ -876,8 +941,8 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
   }
   if (tid >= 64 && tid < 64 + kStreamsPerBlock) {
     const int k = tid - 64;
-    s_on[k] = item.slot[k] != 0xffff ? 1u : 0u;
-    s_slot[k] = (int)item.slot[k];
+    s_on[k] = item_slot(k) != 0xffff ? 1u : 0u;
+    s_slot[k] = item_slot(k);
   }
   __syncthreads();
 
@@ -970,7 +1035,6 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
   // phase 3a: dense set-up + binning of the larger survivors as 32-byte records (the tile kernel
   // rebuilds the edge functions, so only orientation, bounding box and z plane are needed here)
   const uint32_t nlist = s_nlist, ntiny = s_ntiny;
-  uint32_t binned = 0, entries = 0, nfrag = 0;
   for (uint32_t base = 0; base < nlist; base += kBlock) {
     const uint32_t j = base + tid;
     bool have = false;
@@ -1039,6 +1103,9 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
       }
     }
   }
+  if (!STRIDED) break;
+  __syncthreads();        // LDS is reused by the next item
+  }
   // statistics: one (sharded) atomic triple per workgroup
   uint32_t b = binned, e = entries, f = nfrag;
   for (int off = 32; off > 0; off >>= 1) { b += __shfl_down(b, off); e += __shfl_down(e, off); f += __shfl_down(f, off); }
@@ -1061,7 +1128,6 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a)
 // from the end point closer to the plane; the polygon is emitted as the fan
 // (v[i-1], v[i], v[0]).
 // ---------------------------------------------------------------------------------------
-struct ClipVert { float c[4]; Win w; };
 
 __device__ __forceinline__ float clipdist(const float* c, int plane)
 {
@@ -1076,21 +1142,17 @@ __device__ __forceinline__ float clipdist(const float* c, int plane)
   return s;
 }
 
-__device__ void clip_one(const SetupArgs& a, const ClipItem it, int shard_id);
+constexpr int kClipBlock = 128;          // threads per clip workgroup (48 KB of LDS polygon storage)
+constexpr int kClipMaxV = 24;            // clip-space vertices per triangle: 3 + new ones
+constexpr int kClipMaxP = 12;            // polygon vertices (5-bit pool indices packed in one 64-bit register)
 
-__global__ __launch_bounds__(kBlock) void clip_kernel(SetupArgs a)
-{
-  // workgroups b, b + kCounterShards, ... serve shard b % kCounterShards
-  const int shard_id = blockIdx.x % kCounterShards;
-  const uint32_t n = min(a.counters->shard[shard_id].clip_count, a.clip_capacity);
-  const uint32_t per = gridDim.x / kCounterShards;
-  const ClipItem* list = a.clip_list + (size_t)shard_id * a.clip_capacity;
-  for (uint32_t i = (blockIdx.x / kCounterShards) * blockDim.x + threadIdx.x; i < n; i += per * blockDim.x)
-    clip_one(a, list[i], shard_id);
-}
+// Per-thread polygon clipper.  The vertex pool lives in LDS (thread-interleaved float4s: conflict
+// free, no scratch memory) and the two polygon index lists are 5-bit fields of 64-bit registers.
+__device__ __forceinline__ int list_get(unsigned long long l, int i) { return (int)((l >> (5 * i)) & 31ull); }
 
-__device__ void clip_one(const SetupArgs& a, const ClipItem it, int shard_id)
+__device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, int shard_id, float4 (*pool)[kClipBlock], bool valid)
 {
+  const int t = threadIdx.x;
   const int slot = (int)it.slot, stream = a.group_base + slot;
   const Chunk ch = a.chunks[it.chunk];
   const float* __restrict__ M = a.mvp + ((size_t)stream * (a.n_draws + 1) + ch.draw) * 16;
@@ -1098,78 +1160,118 @@ __device__ void clip_one(const SetupArgs& a, const ClipItem it, int shard_id)
   const uint32_t order = it.chunk == a.bg_chunk ? 0u : ch.order_base + it.tri;
   const float sx = 0.5f * (float)a.width, sy = 0.5f * (float)a.height;
 
-  constexpr int kMaxV = 24, kMaxP = 12;
-  ClipVert pool[kMaxV];
   int npool = 3;
   unsigned ormask = 0;
   {
     const uint32_t vi[3] = {packed & 1023u, (packed >> 10) & 1023u, (packed >> 20) & 1023u};
+#pragma unroll
     for (int i = 0; i < 3; i++) {
       const float4 p = a.cverts[ch.vert_begin + vi[i]];
-      vs_position(M, p.x, p.y, p.z, pool[i].c);
-      pool[i].w = viewport_vs(pool[i].c, sx, sy);
-      ormask |= clipmask_of(pool[i].c);
+      float c[4];
+      vs_position(M, p.x, p.y, p.z, c);
+      pool[i][t] = make_float4(c[0], c[1], c[2], c[3]);
+      ormask |= clipmask_of(c);
     }
   }
-  int la[kMaxP + 1], lb[kMaxP + 1];
-  int* inl = la; int* outl = lb;
-  int nv = 3;
-  inl[0] = 0; inl[1] = 1; inl[2] = 2;
+  unsigned long long inl = 0ull | (1ull << 5) | (2ull << 10), outl = 0;
+  int nv = valid ? 3 : 0;
   unsigned clipmask = ormask;
   bool bad = false;
   while (clipmask && nv >= 3 && !bad) {
     const int plane = __ffs((int)clipmask) - 1;
     clipmask &= ~(1u << plane);
-    if (nv >= kMaxP) { bad = true; break; }
-    int prev = inl[0];
-    float dp_prev = clipdist(pool[prev].c, plane);
+    if (nv >= kClipMaxP) { bad = true; break; }
+    int prev = list_get(inl, 0);
+    float4 cprev = pool[prev][t];
+    float dp_prev = clipdist(&cprev.x, plane);
     int outc = 0;
-    inl[nv] = inl[0];
+    outl = 0;
     for (int i = 1; i <= nv; i++) {
-      const int cur = inl[i];
-      const float dp = clipdist(pool[cur].c, plane);
+      const int cur = list_get(inl, i == nv ? 0 : i);
+      const float4 ccur = pool[cur][t];
+      const float dp = clipdist(&ccur.x, plane);
       bool diff;
       if (dp_prev >= 0.0f) {
-        if (outc >= kMaxP) { bad = true; break; }
-        outl[outc++] = prev;
+        if (outc >= kClipMaxP) { bad = true; break; }
+        outl |= (unsigned long long)prev << (5 * outc++);
         diff = dp < 0.0f;
       } else {
         diff = !(dp < 0.0f);
       }
       if (diff) {
-        if (npool >= kMaxV || outc >= kMaxP) { bad = true; break; }
+        if (npool >= kClipMaxV || outc >= kClipMaxP) { bad = true; break; }
         const float denom = __fsub_rn(dp, dp_prev);
         bool from_cur;
         if (dp < 0.0f) from_cur = dp_prev > -dp;        // going out
         else from_cur = !(dp > -dp_prev);               // coming in
         const float tt = from_cur ? __fdiv_rn(dp, denom) : __fdiv_rn(-dp_prev, denom);
-        const float* o = from_cur ? pool[cur].c : pool[prev].c;
-        const float* in = from_cur ? pool[prev].c : pool[cur].c;
-        ClipVert& nvx = pool[npool];
-#pragma unroll
-        for (int k = 0; k < 4; k++) nvx.c[k] = __fadd_rn(__fmul_rn(__fsub_rn(in[k], o[k]), tt), o[k]);
-        nvx.w = viewport_clip(nvx.c, sx, sy);
-        outl[outc++] = npool++;
+        const float4 o = from_cur ? ccur : cprev;
+        const float4 in = from_cur ? cprev : ccur;
+        float4 nc;
+        nc.x = __fadd_rn(__fmul_rn(__fsub_rn(in.x, o.x), tt), o.x);
+        nc.y = __fadd_rn(__fmul_rn(__fsub_rn(in.y, o.y), tt), o.y);
+        nc.z = __fadd_rn(__fmul_rn(__fsub_rn(in.z, o.z), tt), o.z);
+        nc.w = __fadd_rn(__fmul_rn(__fsub_rn(in.w, o.w), tt), o.w);
+        pool[npool][t] = nc;
+        outl |= (unsigned long long)npool << (5 * outc++);
+        npool++;
       }
       prev = cur;
+      cprev = ccur;
       dp_prev = dp;
     }
-    int* sw = inl; inl = outl; outl = sw;
+    inl = outl;
     nv = outc;
   }
-  if (bad || nv < 3) return;
+  if (bad || nv < 3) nv = 0;           // (all lanes stay for the cooperative emission below)
+  // window coordinates: shaded (original) vertices and clipper-made ones go through different
+  // viewport arithmetic (viewport_vs / viewport_clip)
+  auto window_of = [&](int idx) {
+    const float4 c4 = pool[idx][t];
+    const float c[4] = {c4.x, c4.y, c4.z, c4.w};
+    return idx < 3 ? viewport_vs(c, sx, sy) : viewport_clip(c, sx, sy);
+  };
+  Win w0, wprev;
+  if (nv) { w0 = window_of(list_get(inl, 0)); wprev = window_of(list_get(inl, 1)); }
   uint32_t binned = 0, entries = 0;
-  for (int i = 2; i < nv; i++) {
+  for (int i = 2; __ballot(i < nv); i++) {
+    bool have = false;
     TriRec r;
     PackedTri pk;
-    if (make_record(pool[inl[i - 1]].w, pool[inl[i]].w, pool[inl[0]].w, order, a.width, a.height, r, pk)) {
-      binned++;
-      entries += emit_record(a, slot, r, pk);
+    if (i < nv) {
+      const Win wi = window_of(list_get(inl, i));
+      have = make_record(wprev, wi, w0, order, a.width, a.height, r, pk);
+      wprev = wi;
     }
+    bool big = false;
+    if (have) {
+      binned++;
+      const int tw = (int)(r.bbx >> 16) / kTileW - (int)(r.bbx & 0xffff) / kTileW + 1;
+      const int th = (int)(r.bby >> 16) / kTileH - (int)(r.bby & 0xffff) / kTileH + 1;
+      big = tw * th > kCoopTiles;
+      if (!big) entries += emit_record(a, slot, r, pk);
+    }
+    if (__ballot(big)) entries += emit_big_records_wave(a, slot, big, r.bbx, r.bby, pk);
   }
   if (binned) {
     atomicAdd(&a.counters->shard[shard_id].tris_binned, (unsigned long long)binned);
     atomicAdd(&a.counters->shard[shard_id].bin_entries, (unsigned long long)entries);
+  }
+}
+
+__global__ __launch_bounds__(kClipBlock) void clip_kernel(SetupArgs a)
+{
+  __shared__ float4 s_pool[kClipMaxV][kClipBlock];
+  // workgroups b, b + kCounterShards, ... serve shard b % kCounterShards
+  const int shard_id = blockIdx.x % kCounterShards;
+  const uint32_t n = min(a.counters->shard[shard_id].clip_count, a.clip_capacity);
+  const uint32_t per = gridDim.x / kCounterShards;
+  const ClipItem* list = a.clip_list + (size_t)shard_id * a.clip_capacity;
+  for (uint32_t base = (blockIdx.x / kCounterShards) * blockDim.x; base < n; base += per * blockDim.x) {
+    const uint32_t i = base + threadIdx.x;          // whole waves stay in the loop (cooperative emission)
+    ClipItem it; it.slot = 0; it.chunk = 0; it.tri = 0; it.pad = 0;
+    if (i < n) it = list[i];
+    clip_one(a, it, shard_id, s_pool, i < n);
   }
 }
 
@@ -1585,17 +1687,23 @@ void launch_cull(const SetupArgs& a, hipStream_t st)
 {
   hipLaunchKernelGGL(cull_kernel, dim3(a.n_chunks), dim3(kBlock), 0, st, a);
 }
-void launch_setup(const SetupArgs& a, hipStream_t st)
+void launch_setup(const SetupArgs& a, uint32_t items_hint, hipStream_t st)
 {
-  // worst case: every chunk visible in every stream; workgroups beyond the work list exit at once.
-  // Items of one chunk are consecutive, so neighbouring workgroups share its geometry in L2.
-  const int per_chunk = (a.group_size + kStreamsPerBlock - 1) / kStreamsPerBlock;
-  hipLaunchKernelGGL(setup_kernel, dim3((unsigned)(a.n_chunks * per_chunk)), dim3(kBlock), 0, st, a);
+  // The work-list length is only known on the device.  The grid is sized from the previous batch's
+  // length (+25 %; robot and camera move little between frames) and the workgroups stride over the
+  // list, so a wrong guess costs time, never correctness.  Without a hint: the worst case (every
+  // chunk visible in every stream).  Neighbouring workgroups take neighbouring items, which share
+  // a chunk's geometry in L2.
+  const long long worst = (long long)a.n_chunks * ((a.group_size + kStreamsPerBlock - 1) / kStreamsPerBlock);
+  long long grid = worst;
+  if (items_hint) grid = std::min<long long>(worst, (long long)items_hint + items_hint / 4 + 64);
+  hipLaunchKernelGGL(setup_kernel<false>, dim3((unsigned)grid), dim3(kBlock), 0, st, a, 0u);
+  if (grid < worst) hipLaunchKernelGGL(setup_kernel<true>, dim3(256), dim3(kBlock), 0, st, a, (uint32_t)grid);
 }
 void launch_clip(const SetupArgs& a, hipStream_t st)
 {
   // the item count lives on the device: fixed grid, grid-stride loop
-  hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * 32), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * 64), dim3(kClipBlock), 0, st, a);
 }
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st)
 {
