@@ -80,7 +80,7 @@ def main():
     ids = wl0.load_into(ctx)
     if not args.host_poses:
         wl0.load_kinematics(ctx, ids)
-    ctx.enable_timing(True)
+    ctx.enable_timing(2)       # HIP events around the dominant kernel only (each event costs stream time)
 
     d_depth = []
     for v, wl in enumerate(variants):
@@ -92,19 +92,26 @@ def main():
     d_mask = None if args.no_mask else torch.empty((n, H, W), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
-    def step(k):
+    def stage(k):
         v = k % len(variants)
         if args.host_poses:
             variants[v].stage(ctx, ids)
         else:
             variants[v].stage_joint_positions(ctx, ids, first_call=(k == 0))      # joint angles in, forward kinematics on the GPU
+
+    def step(k):
+        # one step = one batch through the hot path.  The next batch's joint positions are staged (host
+        # memory only, double-buffered inside the library) while the GPU works on this one.
+        v = k % len(variants)
         (ctx.filter_batch_device_u16 if args.u16 else ctx.filter_batch_device)(n, d_depth[v].data_ptr(), d_masked.data_ptr(), d_mask.data_ptr() if d_mask is not None else 0)
+        stage(k + 1)
         ctx.sync()
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    stage(0)
     for k in range(args.warmup):
         step(k)
     torch.cuda.synchronize()
@@ -120,6 +127,18 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    # stage-by-stage breakdown: a few extra steps with every stage bracketed by events, outside the timed region
+    raster_ms = acc["ms_raster"] / max(args.steps, 1)
+    compare_ms = acc["ms_compare"] / max(args.steps, 1)
+    ctx.enable_timing(1)
+    extra = 3 * len(variants)       # a multiple of the variant cycle: the last step run is the last timed step's variant (parity below)
+    acc = {key: 0.0 for key in acc}
+    for k in range(extra):
+        step(args.warmup + args.steps + k)
+        st = ctx.stats()
+        for key in acc:
+            acc[key] += st[key]
+    breakdown = {key: v / extra for key, v in acc.items()}
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -130,7 +149,8 @@ def main():
         K = max(args.steps, 1)
         frames = n * world * args.steps
         value = frames / elapsed
-        per = {k: v / K for k, v in acc.items()}
+        per = dict(breakdown)
+        per_timed = {"ms_raster": raster_ms, "ms_compare": compare_ms}
         px = W * H
         two = args.two_kernel
         # dominant kernel and its algorithmic bytes per launch:
@@ -138,10 +158,10 @@ def main():
         #   two-kernel mode   : tile kernel writes the 4 B/pixel z-surface; compare moves 13 B/pixel
         groups = 1
         if two:
-            cands = {"tile_kernel<two_kernel>": (per["ms_raster"], 4 * px * n), "compare_kernel": (per["ms_compare"], (13 if d_mask is not None else 12) * px * n)}
+            cands = {"tile_kernel<two_kernel>": (per_timed["ms_raster"], 4 * px * n), "compare_kernel": (per_timed["ms_compare"], (13 if d_mask is not None else 12) * px * n)}
         else:
             bpp = (4 if args.u16 else 8) + (1 if d_mask is not None else 0)
-            cands = {"tile_kernel<fused>": (per["ms_raster"], bpp * px * n)}
+            cands = {"tile_kernel<fused>": (per_timed["ms_raster"], bpp * px * n)}
         cands["setup_kernel+clip_kernel"] = (per["ms_setup"], 12 * wl0.n_vertices() + 16 * wl0.n_triangles())
         dom = max((k for k in cands if not k.startswith("setup")), key=lambda k: cands[k][0])
         dur_ms, alg_bytes = cands[dom]
@@ -167,7 +187,7 @@ def main():
                        "streams_per_gpu": n, "poses": "host matrices" if args.host_poses else "joint positions, forward kinematics on the GPU", "mode": "two-kernel" if two else "fused", "mask_output": d_mask is not None,
                        "parallelism": "stream-sharded x%d" % world},
             "per_stream_fps": value / (n * world),
-            "kernel_ms_per_step": per,
+            "kernel_ms_per_step": dict(per, note="stage breakdown from %d extra steps after the timed region (every stage bracketed by HIP events); roofline.avg_launch_ms is measured inside the timed region" % extra),
             "rasteriser": {"triangles_per_s": wl0.n_triangles() * n / (per["ms_setup"] * 1e-3) if per["ms_setup"] > 0 else None,
                            "binned_triangles_per_s": st["triangles_binned"] / (per["ms_raster"] * 1e-3) if per["ms_raster"] > 0 else None,
                            "triangles_submitted": st["triangles_submitted"], "triangles_binned": st["triangles_binned"],

@@ -205,8 +205,9 @@ typedef struct {
   float ms_pose, ms_setup, ms_raster, ms_compare, ms_total;   /* last timed batch       */
 } rtuf_stats;
 int rtuf_get_stats(rtuf_context *ctx, rtuf_stats *out);
-/* Enable/disable per-kernel HIP-event timing (off by default: events serialise nothing but
- * cost a few microseconds each). */
+/* Per-kernel HIP-event timing (off by default: every event costs a few microseconds of stream
+ * time).  on = 1: every stage (ms_pose, ms_setup, ms_raster, ms_compare, ms_total);  on = 2: only
+ * around the tile kernel (and the compare kernel in two-kernel mode): ms_raster / ms_compare. */
 int rtuf_enable_timing(rtuf_context *ctx, int on);
 
 /* Debug / test access: copy the z-surface of the last batch (float window z of the winning

@@ -284,7 +284,8 @@ class Context:
         return self._lib.rtuf_stream(self._h)
 
     def enable_timing(self, on=True):
-        self._check(self._lib.rtuf_enable_timing(self._h, 1 if on else 0))
+        # True/1: every stage; 2: only around the tile (and compare) kernel; False/0: off
+        self._check(self._lib.rtuf_enable_timing(self._h, int(on)))
 
     def stats(self):
         s = Stats()

@@ -36,7 +36,12 @@ struct Kinematics {               // on-device forward kinematics of one model
   bool dirty_q = true, dirty_aux = true;     // joint positions / root poses + enable flags changed on the host
   int32_t* d_parent = nullptr; int32_t* d_type = nullptr; double* d_origin = nullptr; double* d_axis = nullptr;
   int32_t* d_link_frame = nullptr; double* d_link_offset = nullptr;
-  double* h_q = nullptr; double* d_q = nullptr;             // [max_streams][n_frames]
+  // joint positions are staged in two pinned buffers that the forward-kinematics kernel reads in place
+  // (zero-copy): the batch in flight owns h_q[q_live], rtuf_set_joint_positions writes h_q[q_write], so
+  // the next frame's joint states can be staged while the GPU filters the current one
+  double* h_q[2] = {nullptr, nullptr};                      // [max_streams][n_frames]
+  int q_live = 0, q_write = 0;
+  bool q_carried = true;                                    // h_q[q_write] holds everything h_q[q_live] does
   double* h_root = nullptr; double* d_root = nullptr;       // [max_streams][12]
   uint8_t* h_enabled = nullptr; uint8_t* d_enabled = nullptr;
 };
@@ -95,7 +100,7 @@ struct rtuf_context {
   int uploaded_streams = 0;
 
   rtuf_stats stats{};
-  bool timing = false;
+  int timing = 0;            // 0 off, 1 every stage, 2 only around the tile (and compare) kernel
   std::vector<hipEvent_t> events;
 
   int fail(int code, const char* fmt, ...)
@@ -113,6 +118,10 @@ struct rtuf_context {
     if (e_ != hipSuccess)                                                                  \
       return (ctx)->fail(e_ == hipErrorOutOfMemory ? RTUF_ERR_OOM : RTUF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
+
+// Setters whose staging buffers the batch in flight may still be reading (or would re-read on a bin
+// regrowth) wait for it; rtuf_set_joint_positions alone is double-buffered and never waits.
+#define WAIT_IF_PENDING(c) do { if ((c)->pending) { const int rc_ = rtuf_sync(c); if (rc_ != RTUF_OK) return rc_; } } while (0)
 
 extern "C" {
 
@@ -186,8 +195,9 @@ void rtuf_destroy(rtuf_context* c)
   for (HostModel& m : c->models) {
     Kinematics& k = m.kin;
     hipFree(k.d_depth); hipFree(k.d_parent); hipFree(k.d_type); hipFree(k.d_origin); hipFree(k.d_axis); hipFree(k.d_link_frame); hipFree(k.d_link_offset);
-    hipFree(k.d_q); hipFree(k.d_root); hipFree(k.d_enabled);
-    if (k.h_q) hipHostFree(k.h_q);
+    hipFree(k.d_root); hipFree(k.d_enabled);
+    if (k.h_q[0]) hipHostFree(k.h_q[0]);
+    if (k.h_q[1]) hipHostFree(k.h_q[1]);
     if (k.h_root) hipHostFree(k.h_root);
     if (k.h_enabled) hipHostFree(k.h_enabled);
   }
@@ -202,6 +212,7 @@ void rtuf_destroy(rtuf_context* c)
 int rtuf_set_params(rtuf_context* c, const rtuf_params* p)
 {
   if (!c || !p) return RTUF_ERR_INVALID;
+  WAIT_IF_PENDING(c);
   const uint32_t keep_cap = c->params.bin_capacity, keep_inf = c->params.max_inflight_streams;
   const bool two_before = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
   c->params = *p;
@@ -437,6 +448,7 @@ int rtuf_finalize_models(rtuf_context* c)
 int rtuf_set_stream_models(rtuf_context* c, int stream, const int* model_ids, int n_models)
 {
   if (!c) return RTUF_ERR_INVALID;
+  WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
   if (stream < 0 || stream >= c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream %d", stream);
   uint64_t mask = 0;
@@ -454,6 +466,7 @@ int rtuf_set_camera(rtuf_context* c, int stream, const double projection[16], co
                     const double camera_tf[16])
 {
   if (!c) return RTUF_ERR_INVALID;
+  WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
   if (stream < 0 || stream >= c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream %d", stream);
   Camera& cam = c->h_cams[stream];
@@ -484,6 +497,7 @@ void rtuf_projection_from_intrinsics(double fx, double fy, double cx, double cy,
 int rtuf_set_link_poses(rtuf_context* c, int stream, int model, const double* link_tf, int n_links)
 {
   if (!c || !link_tf) return RTUF_ERR_INVALID;
+  WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
   if (stream < 0 || stream >= c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream %d", stream);
   if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
@@ -499,6 +513,7 @@ int rtuf_set_cameras(rtuf_context* c, int first, int n, const double* projection
                      const double* cam_tf)
 {
   if (!c) return RTUF_ERR_INVALID;
+  WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
   if (first < 0 || n < 0 || first + n > c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream range %d+%d", first, n);
   for (int s = 0; s < n; s++) {
@@ -514,6 +529,7 @@ int rtuf_set_cameras(rtuf_context* c, int first, int n, const double* projection
 int rtuf_set_link_poses_batch(rtuf_context* c, int first, int n, int model, const double* link_tf, int n_links)
 {
   if (!c || !link_tf) return RTUF_ERR_INVALID;
+  WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
   if (first < 0 || n < 0 || first + n > c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream range %d+%d", first, n);
   if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
@@ -575,14 +591,15 @@ int rtuf_set_kinematics(rtuf_context* c, int model, int n_frames, const int32_t*
   HIP_TRY(c, hipMalloc(&k.d_axis, sizeof(double) * 3 * n_frames));
   HIP_TRY(c, hipMalloc(&k.d_link_frame, sizeof(int32_t) * std::max(n_links, 1)));
   HIP_TRY(c, hipMalloc(&k.d_link_offset, sizeof(double) * off.size()));
-  HIP_TRY(c, hipMalloc(&k.d_q, sizeof(double) * N * n_frames));
   HIP_TRY(c, hipMalloc(&k.d_root, sizeof(double) * N * 12));
   HIP_TRY(c, hipMalloc(&k.d_enabled, N));
-  HIP_TRY(c, hipHostMalloc(&k.h_q, sizeof(double) * N * n_frames));
+  HIP_TRY(c, hipHostMalloc(&k.h_q[0], sizeof(double) * N * n_frames));
+  HIP_TRY(c, hipHostMalloc(&k.h_q[1], sizeof(double) * N * n_frames));
   HIP_TRY(c, hipHostMalloc(&k.h_root, sizeof(double) * N * 12));
   HIP_TRY(c, hipHostMalloc(&k.h_enabled, N));
   memset(k.h_enabled, 0, N);
-  memset(k.h_q, 0, sizeof(double) * N * n_frames);
+  memset(k.h_q[0], 0, sizeof(double) * N * n_frames);
+  memset(k.h_q[1], 0, sizeof(double) * N * n_frames);
   HIP_TRY(c, hipMemcpy(k.d_parent, parent, sizeof(int32_t) * n_frames, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(k.d_type, joint_type, sizeof(int32_t) * n_frames, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(k.d_origin, org.data(), sizeof(double) * org.size(), hipMemcpyHostToDevice));
@@ -602,16 +619,31 @@ int rtuf_set_joint_positions(rtuf_context* c, int first, int n, int model, const
   Kinematics& k = c->models[model].kin;
   if (!k.n_frames) return c->fail(RTUF_ERR_STATE, "call rtuf_set_kinematics for model %d first", model);
   if (camera_frame < -1 || camera_frame >= k.n_frames) return c->fail(RTUF_ERR_INVALID, "bad camera frame %d", camera_frame);
-  memcpy(k.h_q + (size_t)first * k.n_frames, q, sizeof(double) * (size_t)n * k.n_frames);
-  k.dirty_q = true;
   static const double I12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+  // root transforms, enable flags and the camera frame are staged in single buffers: changing them
+  // while a batch is in flight waits for that batch first (joint positions alone never wait)
+  bool aux_changes = camera_frame != k.camera_frame;
+  std::vector<double> roots(12 * (size_t)n);
   for (int s = 0; s < n; s++) {
-    double r12[12];
+    double* r12 = &roots[12 * (size_t)s];
     if (root_tf) gl_to_tf12(root_tf + 16 * (size_t)s, r12);
-    else memcpy(r12, I12, sizeof r12);
-    double* dst = k.h_root + 12 * (size_t)(first + s);
-    if (memcmp(dst, r12, sizeof r12) != 0 || !k.h_enabled[first + s]) { memcpy(dst, r12, sizeof r12); k.dirty_aux = true; }
-    k.h_enabled[first + s] = 1;
+    else memcpy(r12, I12, sizeof I12);
+    if (memcmp(k.h_root + 12 * (size_t)(first + s), r12, sizeof I12) != 0 || !k.h_enabled[first + s]) aux_changes = true;
+  }
+  if (aux_changes && c->pending) { const int rc = rtuf_sync(c); if (rc != RTUF_OK) return rc; }
+  if (!k.q_carried) {
+    // first write after a batch took the other buffer: carry the streams this call does not set
+    if (first != 0 || n != c->max_streams) memcpy(k.h_q[k.q_write], k.h_q[k.q_live], sizeof(double) * (size_t)c->max_streams * k.n_frames);
+    k.q_carried = true;
+  }
+  memcpy(k.h_q[k.q_write] + (size_t)first * k.n_frames, q, sizeof(double) * (size_t)n * k.n_frames);
+  k.dirty_q = true;
+  if (aux_changes) {
+    for (int s = 0; s < n; s++) {
+      memcpy(k.h_root + 12 * (size_t)(first + s), &roots[12 * (size_t)s], sizeof I12);
+      k.h_enabled[first + s] = 1;
+    }
+    k.dirty_aux = true;
   }
   k.camera_frame = camera_frame;
   k.any_enabled = true;
@@ -665,7 +697,7 @@ static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
   return RTUF_OK;
 }
 
-static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask, bool io_u16)
+static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask, bool io_u16, bool rerun = false)
 {
   const size_t esz = io_u16 ? sizeof(uint16_t) : sizeof(float);
   hipStream_t st = c->stream;
@@ -673,7 +705,7 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
   const size_t L = (size_t)std::max(c->n_links, 1);
   const size_t plane = (size_t)c->width * c->height;
   size_t ev = 0;
-  if (c->timing) hipEventRecord(get_event(c, ev++), st);
+  if (c->timing == 1) hipEventRecord(get_event(c, ev++), st);
   // only what the host changed since the last batch crosses the bus (with on-device forward
   // kinematics that is just the joint positions below)
   const bool more = n > c->uploaded_streams;
@@ -682,20 +714,21 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
   if (c->dirty_mask || more) HIP_TRY(c, hipMemcpyAsync(c->d_model_mask, c->h_model_mask, sizeof(uint64_t) * n, hipMemcpyHostToDevice, st));
   c->dirty_cams = c->dirty_link_tf = c->dirty_mask = false;
   c->uploaded_streams = std::max(c->uploaded_streams, n);
-  HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(Counters), st));
   // on-device forward kinematics overwrites the link matrices (and camera) of the streams that use it
   for (HostModel& m : c->models) {
     Kinematics& k = m.kin;
     if (!k.n_frames || !k.any_enabled) continue;
-    if (k.dirty_q || more) HIP_TRY(c, hipMemcpyAsync(k.d_q, k.h_q, sizeof(double) * (size_t)n * k.n_frames, hipMemcpyHostToDevice, st));
+    if (k.dirty_q && !rerun) {               // this batch takes the staged joint positions; later writes go to the other buffer
+      k.q_live = k.q_write; k.q_write ^= 1; k.q_carried = false; k.dirty_q = false;
+    }
     if (k.dirty_aux || more) {
       HIP_TRY(c, hipMemcpyAsync(k.d_root, k.h_root, sizeof(double) * 12 * (size_t)n, hipMemcpyHostToDevice, st));
       HIP_TRY(c, hipMemcpyAsync(k.d_enabled, k.h_enabled, (size_t)n, hipMemcpyHostToDevice, st));
     }
-    k.dirty_q = k.dirty_aux = false;
+    k.dirty_aux = false;
     FkArgs fa{};
     fa.parent = k.d_parent; fa.depth = k.d_depth; fa.max_depth = k.max_depth; fa.joint_type = k.d_type; fa.joint_origin = k.d_origin; fa.joint_axis = k.d_axis;
-    fa.link_frame = k.d_link_frame; fa.link_offset = k.d_link_offset; fa.q = k.d_q; fa.root_tf = k.d_root;
+    fa.link_frame = k.d_link_frame; fa.link_offset = k.d_link_offset; fa.q = k.h_q[k.q_live]; fa.root_tf = k.d_root;
     fa.enabled = k.d_enabled; fa.link_tf = c->d_link_tf; fa.cams = c->d_cams;
     fa.n_streams = n; fa.n_frames = k.n_frames; fa.n_links_model = (int)m.links.size(); fa.link_base = m.link_base;
     fa.n_links_total = (int)L; fa.camera_frame = k.camera_frame;
@@ -703,11 +736,11 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
   }
   PoseArgs pa{};
   pa.cams = c->d_cams; pa.link_tf = c->d_link_tf; pa.draws = c->d_draws; pa.mvp = c->d_mvp;
-  pa.bg_z = c->d_bg_z; pa.bg_mode = c->d_bg_mode;
+  pa.bg_z = c->d_bg_z; pa.bg_mode = c->d_bg_mode; pa.counters = c->d_counters;
   pa.n_streams = n; pa.n_draws = c->n_draws; pa.n_links = (int)L; pa.z_far = c->params.far_plane;
   pa.width = c->width; pa.height = c->height;
   launch_pose(pa, st);
-  if (c->timing) hipEventRecord(get_event(c, ev++), st);
+  if (c->timing == 1) hipEventRecord(get_event(c, ev++), st);
   for (int base = 0; base < n; base += c->group) {
     const int gs = std::min(c->group, n - base);
     // clip list is per group
@@ -744,7 +777,7 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
       ca.z_near = ta.z_near; ca.z_far = ta.z_far; ca.max_diff = ta.max_diff; ca.replace_value = ta.replace_value;
       launch_compare(ca, st);
     }
-    if (c->timing) hipEventRecord(get_event(c, ev++), st);
+    if (c->timing == 1 || (c->timing == 2 && two)) hipEventRecord(get_event(c, ev++), st);
   }
   HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
   HIP_TRY(c, hipGetLastError());
@@ -811,7 +844,7 @@ int rtuf_sync(rtuf_context* c)
     const bool clip_over = k.clip_overflow != 0;
     if (!bin_over && !clip_over) {
       c->pending = false;
-      if (c->timing && c->events.size() >= 2) {
+      if (c->timing == 1 && c->events.size() >= 2) {
         // events: [start, pose_end, (setup_end, tile_end, compare_end) per group ...]
         float ms = 0;
         c->stats.ms_pose = c->stats.ms_setup = c->stats.ms_raster = c->stats.ms_compare = 0;
@@ -824,6 +857,17 @@ int rtuf_sync(rtuf_context* c)
           e += 3;
         }
         hipEventElapsedTime(&ms, c->events[0], c->events[e]); c->stats.ms_total = ms;
+      } else if (c->timing == 2 && c->events.size() >= 2) {
+        // events: (tile_begin, tile_end[, compare_end]) per group
+        const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
+        float ms = 0;
+        c->stats.ms_pose = c->stats.ms_setup = c->stats.ms_raster = c->stats.ms_compare = c->stats.ms_total = 0;
+        size_t e = 0;
+        for (int base = 0; base < c->last_n; base += c->group) {
+          hipEventElapsedTime(&ms, c->events[e], c->events[e + 1]); c->stats.ms_raster += ms;
+          if (two) { hipEventElapsedTime(&ms, c->events[e + 1], c->events[e + 2]); c->stats.ms_compare += ms; }
+          e += two ? 3 : 2;
+        }
       }
       return RTUF_OK;
     }
@@ -841,7 +885,7 @@ int rtuf_sync(rtuf_context* c)
     const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
     HIP_TRY(c, hipMemsetAsync(c->d_bin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_fbin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->stream));
-    const int rc = enqueue_batch(c, c->last_n, c->last_depth, c->last_masked, c->last_mask, c->last_u16);
+    const int rc = enqueue_batch(c, c->last_n, c->last_depth, c->last_masked, c->last_mask, c->last_u16, true);
     if (rc != RTUF_OK) { c->pending = false; return rc; }
   }
   c->pending = false;
@@ -952,7 +996,7 @@ int rtuf_get_stats(rtuf_context* c, rtuf_stats* out)
 int rtuf_enable_timing(rtuf_context* c, int on)
 {
   if (!c) return RTUF_ERR_INVALID;
-  c->timing = on != 0;
+  c->timing = on < 0 ? 0 : (on > 2 ? 1 : on);
   return RTUF_OK;
 }
 

@@ -150,6 +150,7 @@ struct PoseArgs {
   float* mvp;                // [n_streams][n_draws + 1][16]
   float* bg_z;               // [n_streams]  window z of the background quad
   uint32_t* bg_mode;         // [n_streams]  1 = constant full-screen plane (analytic), 0 = draw it as geometry
+  Counters* counters;        // zeroed by the kernel's first workgroup
   int n_streams, n_draws, n_links;
   float z_far;
   int width, height;

@@ -111,6 +111,12 @@ __global__ void pose_kernel(PoseArgs a)
 {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int per = a.n_draws + 1;
+  // first kernel of a batch that every configuration runs: it also zeroes the batch's counters
+  // (statistics, clip lists, work-list length), which saves a separate fill launch per batch
+  if (blockIdx.x == 0) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(a.counters);
+    for (int i = threadIdx.x; i < (int)(sizeof(Counters) / 4); i += blockDim.x) w[i] = 0u;
+  }
   if (gid >= a.n_streams * per) return;
   const int s = gid / per, d = gid - s * per;
   const Camera& cam = a.cams[s];
