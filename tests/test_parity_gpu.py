@@ -344,6 +344,54 @@ def test_on_device_forward_kinematics():
     ctx.close()
 
 
+def test_staging_next_joint_positions_while_a_batch_is_in_flight():
+    """rtuf_set_joint_positions is double-buffered: the next frame's joint states may be staged between
+    rtuf_filter_batch_device and rtuf_sync without disturbing the batch in flight, including partial
+    (per-stream) updates; every other setter waits for the batch instead."""
+    import torch
+    n, W, H = 4, 320, 240
+    A = WL.pr2_workload(n, W, H, total_triangles=8000, first_state_seed=1000)
+    B = WL.pr2_workload(n, W, H, total_triangles=8000, first_state_seed=2000)
+    ctx = R.Context(W, H, n, 0, params(A.replace_value, A.max_diff))
+    ids = A.load_into(ctx)
+    A.load_kinematics(ctx, ids)
+    depth = A.depth_batch()
+    A.stage_joint_positions(ctx, ids)
+    ref_a = ctx.filter_batch(depth)
+    B.stage_joint_positions(ctx, ids, first_call=False)
+    ref_b = ctx.filter_batch(depth)
+    assert (ref_a[1] != ref_b[1]).sum() > 0            # the two joint states really differ on screen
+
+    dev = torch.device("cuda:0")
+    d_depth = torch.from_numpy(depth).to(dev)
+    d_masked = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+    d_mask = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def run_and(stage_next):
+        ctx.filter_batch_device(n, d_depth.data_ptr(), d_masked.data_ptr(), d_mask.data_ptr())
+        stage_next()                                    # host-side staging while the GPU works
+        ctx.sync()
+        return d_masked.cpu().numpy(), d_mask.cpu().numpy()
+
+    A.stage_joint_positions(ctx, ids, first_call=False)
+    got = run_and(lambda: B.stage_joint_positions(ctx, ids, first_call=False))
+    assert np.array_equal(got[1], ref_a[1]) and bits_equal(got[0], ref_a[0])
+    # B is now staged; while it runs, streams 0..1 go back to A's state (partial update)
+    got = run_and(lambda: ctx.set_joint_positions(0, ids[0], A.joint_q[:2], None, A.camera_frame_index))
+    assert np.array_equal(got[1], ref_b[1]) and bits_equal(got[0], ref_b[0])
+    got = run_and(lambda: None)
+    want_mask = np.concatenate([ref_a[1][:2], ref_b[1][2:]])
+    want_masked = np.concatenate([ref_a[0][:2], ref_b[0][2:]])
+    assert np.array_equal(got[1], want_mask) and bits_equal(got[0], want_masked)
+    # a setter that is not double-buffered waits for the batch in flight: the batch keeps its inputs
+    ctx.filter_batch_device(n, d_depth.data_ptr(), d_masked.data_ptr(), d_mask.data_ptr())
+    ctx.set_cameras(0, A.projection * 1.0, A.offset_inv, None)
+    assert np.array_equal(d_mask.cpu().numpy(), want_mask)
+    ctx.sync()
+    ctx.close()
+
+
 def test_config_c4_720p_pr2_plus_walls():
     """BASELINE config 4 shape: 1280x720, PR2-like robot + two static wall URDFs (full-screen boxes incl.
     quirk Q1: exercises the large-triangle path), several streams."""
