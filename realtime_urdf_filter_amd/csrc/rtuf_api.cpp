@@ -305,7 +305,7 @@ static int alloc_frame_buffers(rtuf_context* c)
   int G = c->params.max_inflight_streams ? (int)c->params.max_inflight_streams : 256;
   G = std::min(G, N);
   uint32_t cap = c->params.bin_capacity;
-  if (!cap) cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->n_tris + 16, 256), 4096);
+  if (!cap) cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->n_tris + 16, 256), 4 * kTileW * kTileH);   // 4 records per tile pixel
   // keep the bins (records + fragments) under ~32 GiB by shrinking the in-flight group
   const size_t budget = (size_t)32 << 30;
   while (G > 1 && (size_t)G * tiles * cap * (sizeof(PackedTri) + 2 * sizeof(Frag)) > budget) G = (G + 1) / 2;
@@ -752,7 +752,7 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
     sa.clip_list = c->d_clip_list; sa.counters = c->d_counters; sa.group_base = base; sa.group_size = gs;
     sa.n_draws = c->n_draws; sa.width = c->width; sa.height = c->height; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
     sa.capacity = c->capacity; sa.clip_capacity = c->clip_capacity; sa.bg_chunk = c->bg_chunk;
-    sa.items = c->d_items; sa.n_chunks = c->n_chunks;
+    sa.items = c->d_items; sa.n_chunks = c->n_chunks; sa.flags = c->params.flags;
     launch_cull(sa, st);
     launch_setup(sa, c->items_hint, st);
     launch_clip(sa, st);

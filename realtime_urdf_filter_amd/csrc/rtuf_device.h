@@ -24,12 +24,12 @@
 namespace rtuf {
 
 #ifndef RTUF_TILE_W
-#define RTUF_TILE_W 32
+#define RTUF_TILE_W 64
 #endif
 #ifndef RTUF_TILE_H
 #define RTUF_TILE_H 32
 #endif
-constexpr int kTileW = RTUF_TILE_W;      // screen tile of one raster workgroup (LDS: 8 B per pixel)
+constexpr int kTileW = RTUF_TILE_W;      // screen tile of one raster workgroup (LDS: 8 B per pixel; 64x32 = 16 KB)
 constexpr int kTileH = RTUF_TILE_H;
 constexpr int kBlock = 256;
 constexpr int kMaxChunkVerts = 256;     // unique vertices per set-up chunk (one per lane; LDS: 24 B each per stream)
@@ -93,11 +93,13 @@ struct Camera {
   double cam_tf[16];
 };
 
-struct ClipItem {
-  uint32_t slot;                // stream slot within the in-flight group
-  uint32_t chunk;
-  uint32_t tri;                 // triangle index within the chunk
-  uint32_t pad;
+struct alignas(16) ClipItem {   // one triangle that crosses a frustum plane; self-contained, so the clip
+  uint32_t slot;                // kernel's loads depend on nothing but the item (stream slot within the group)
+  uint32_t draw;
+  uint32_t vert_begin;          // of the triangle's chunk, into cverts
+  uint32_t packed;              // 3 x 10-bit chunk-local vertex ids
+  uint32_t order;               // draw-order key (0 = background quad)
+  uint32_t pad[3];
 };
 
 // Device-side statistics / overflow detection.  One hot word would serialise every workgroup at
@@ -179,6 +181,7 @@ struct SetupArgs {
   uint32_t capacity;
   uint32_t clip_capacity;        // per shard segment
   uint32_t bg_chunk;             // index of the background-quad chunk
+  uint32_t flags;                // rtuf_params.flags (bits 16.. are timing experiments of the set-up kernel)
 };
 
 struct TileArgs {

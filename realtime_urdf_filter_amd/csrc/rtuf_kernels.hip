@@ -1004,8 +1004,9 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
       if (needs_clip) {
         const uint32_t kk = base + (uint32_t)__popcll(cmk & ((1ull << lane) - 1ull));
         if (kk < a.clip_capacity) {
-          ClipItem it; it.slot = (uint32_t)slot; it.chunk = (uint32_t)chunk_id; it.tri = (uint32_t)tid; it.pad = 0;
-          a.clip_list[(size_t)shard_id * a.clip_capacity + kk] = it;
+          uint4* dst = reinterpret_cast<uint4*>(&a.clip_list[(size_t)shard_id * a.clip_capacity + kk]);
+          dst[0] = make_uint4((uint32_t)slot, ch.draw, ch.vert_begin, packed);
+          dst[1] = make_uint4(is_bg ? 0u : ch.order_base + (uint32_t)tid, 0u, 0u, 0u);
         } else {
           shard.clip_overflow = 1u;
         }
@@ -1038,6 +1039,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
     }
   }
   __syncthreads();
+  if (a.flags & 0x10000u) { __syncthreads(); if (!STRIDED) break; continue; }     // timing experiment
   // phase 3a: dense set-up + binning of the larger survivors as 32-byte records (the tile kernel
   // rebuilds the edge functions, so only orientation, bounding box and z plane are needed here)
   const uint32_t nlist = s_nlist, ntiny = s_ntiny;
@@ -1067,7 +1069,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
         bby = (uint32_t)by0 | ((uint32_t)by1 << 16);
       }
     }
-    if (__ballot(have)) {
+    if (__ballot(have) && !(a.flags & 0x20000u)) {
       entries += emit_record_wave(a, slot, have, bbx, bby, pk);
       binned += have ? 1u : 0u;
     }
@@ -1102,7 +1104,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
           order = is_bg ? 0u : ch.order_base + (uint32_t)t;
         }
       }
-      if (__ballot(mask != 0)) {
+      if (__ballot(mask != 0) && !(a.flags & 0x40000u)) {
         nfrag += cls == 0 ? emit_fragments_wave<true>(a, slot, mask, bx0, by0, a0, dzdx, dzdy, order)
                           : emit_fragments_wave<false>(a, slot, mask, bx0, by0, a0, dzdx, dzdy, order);
         binned += mask ? 1u : 0u;
@@ -1149,7 +1151,7 @@ __device__ __forceinline__ float clipdist(const float* c, int plane)
 }
 
 constexpr int kClipBlock = 128;          // threads per clip workgroup (48 KB of LDS polygon storage)
-constexpr int kClipMaxV = 24;            // clip-space vertices per triangle: 3 + new ones
+constexpr int kClipMaxV = 16;            // clip-space vertices per triangle: 3 + at most 2 new ones per frustum plane (+1 spare)
 constexpr int kClipMaxP = 12;            // polygon vertices (5-bit pool indices packed in one 64-bit register)
 
 // Per-thread polygon clipper.  The vertex pool lives in LDS (thread-interleaved float4s: conflict
@@ -1160,10 +1162,9 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
 {
   const int t = threadIdx.x;
   const int slot = (int)it.slot, stream = a.group_base + slot;
-  const Chunk ch = a.chunks[it.chunk];
-  const float* __restrict__ M = a.mvp + ((size_t)stream * (a.n_draws + 1) + ch.draw) * 16;
-  const uint32_t packed = a.ctris[ch.tri_begin + it.tri];
-  const uint32_t order = it.chunk == a.bg_chunk ? 0u : ch.order_base + it.tri;
+  const float* __restrict__ M = a.mvp + ((size_t)stream * (a.n_draws + 1) + it.draw) * 16;
+  const uint32_t packed = it.packed;
+  const uint32_t order = it.order;
   const float sx = 0.5f * (float)a.width, sy = 0.5f * (float)a.height;
 
   int npool = 3;
@@ -1172,7 +1173,7 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
     const uint32_t vi[3] = {packed & 1023u, (packed >> 10) & 1023u, (packed >> 20) & 1023u};
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      const float4 p = a.cverts[ch.vert_begin + vi[i]];
+      const float4 p = a.cverts[it.vert_begin + vi[i]];
       float c[4];
       vs_position(M, p.x, p.y, p.z, c);
       pool[i][t] = make_float4(c[0], c[1], c[2], c[3]);
@@ -1275,8 +1276,12 @@ __global__ __launch_bounds__(kClipBlock) void clip_kernel(SetupArgs a)
   const ClipItem* list = a.clip_list + (size_t)shard_id * a.clip_capacity;
   for (uint32_t base = (blockIdx.x / kCounterShards) * blockDim.x; base < n; base += per * blockDim.x) {
     const uint32_t i = base + threadIdx.x;          // whole waves stay in the loop (cooperative emission)
-    ClipItem it; it.slot = 0; it.chunk = 0; it.tri = 0; it.pad = 0;
-    if (i < n) it = list[i];
+    ClipItem it; it.slot = 0; it.draw = 0; it.vert_begin = 0; it.packed = 0; it.order = 0;
+    if (i < n) {
+      const uint4* src = reinterpret_cast<const uint4*>(&list[i]);
+      const uint4 w0 = src[0];
+      it.slot = w0.x; it.draw = w0.y; it.vert_begin = w0.z; it.packed = w0.w; it.order = src[1].x;
+    }
     clip_one(a, it, shard_id, s_pool, i < n);
   }
 }
@@ -1383,9 +1388,9 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       const int qx0 = max((int)(q.bbx & 0xffff) - x_base, 0), qx1 = min((int)(q.bbx >> 16) - x_base, kTileW - 1);
       const int qy0 = max((int)(q.bby & 0xffff) - y_base, 0), qy1 = min((int)(q.bby >> 16) - y_base, kTileH - 1);
       const int qw = qx1 - qx0 + 1, qarea = qw * (qy1 - qy0 + 1);
-      const uint32_t inv = (uint32_t)ceilf(65536.0f * __builtin_amdgcn_rcpf((float)qw));
+      const uint32_t inv = (uint32_t)ceilf(1048576.0f * __builtin_amdgcn_rcpf((float)qw));
       for (int idx = lane; idx < qarea; idx += 64) {
-        const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 16);
+        const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
         const int lx = qx0 + idx - __mul24(yy, qw), ly = qy0 + yy;
         const int px = x_base + lx, py = y_base + ly;
         if (inside(q, px, py)) fragment<MODE>(keys, q, px, py, ly * kTileW + lx);
@@ -1413,12 +1418,13 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       const int qy0 = max((int)(q.bby & 0xffff) - y_base, 0), qy1 = min((int)(q.bby >> 16) - y_base, kTileH - 1);
       const int qw = qx1 - qx0 + 1;
       const int qarea = src < 0 ? 0 : qw * (qy1 - qy0 + 1);
-      // idx / qw for idx < 4096, qw <= 64 via an exact reciprocal multiply
-      // (1 ulp of v_rcp_f32 is ~0.004 here, the fractional part of 65536/qw is 0 or >= 1/64)
-      const uint32_t inv = (uint32_t)ceilf(65536.0f * __builtin_amdgcn_rcpf((float)max(qw, 1)));
+      // idx / qw for idx < 4096, qw <= 128 via a reciprocal multiply that is exact in that range:
+      // inv = ceil(2^20 / qw) (+1 at most if v_rcp_f32 is an ulp high), and idx * (inv - 2^20/qw) * qw < 2^20
+      // (checked exhaustively on the CPU, including +-1 ulp of the reciprocal)
+      const uint32_t inv = (uint32_t)ceilf(1048576.0f * __builtin_amdgcn_rcpf((float)max(qw, 1)));
       for (int idx = sub; __ballot(idx < qarea); idx += 16) {
         if (idx < qarea) {
-          const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 16);
+          const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
           const int lx = qx0 + idx - __mul24(yy, qw), ly = qy0 + yy;
           const int px = x_base + lx, py = y_base + ly;
           if (inside(q, px, py)) fragment<MODE>(keys, q, px, py, ly * kTileW + lx);
@@ -1498,19 +1504,24 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
   // The sensor pixels this lane will resolve are requested before anything else so that their HBM
   // latency overlaps the bin-counter round trip and all of the rasterisation.
   constexpr int kLanesPerRow = kTileW / 4, kRowsPerPass = kBlock / kLanesPerRow;
-  static_assert(kRowsPerPass >= kTileH, "one resolve pass per tile expected");
+  constexpr int kPasses = (kTileH + kRowsPerPass - 1) / kRowsPerPass;      // resolve passes per tile (1 for 32x32)
   const bool vec = (a.width & 3) == 0;
-  const int r_ly = tid / kLanesPerRow, r_lx = (tid % kLanesPerRow) * 4;
-  const int r_px = x_base + r_lx, r_py = y_base + r_ly;
-  const bool r_valid = r_ly < kTileH && r_py < a.height && r_px < a.width;
-  const size_t gofs = ((size_t)stream * a.height + r_py) * a.width + r_px;
-  float4 sens = make_float4(0, 0, 0, 0);
-  if (!TWO_KERNEL && r_valid && vec) {
-    if (U16) {
-      const ushort4 q = *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(a.depth) + gofs);
-      sens = make_float4(u16_to_metres(q.x), u16_to_metres(q.y), u16_to_metres(q.z), u16_to_metres(q.w));
-    } else {
-      sens = *reinterpret_cast<const float4*>(a.depth + gofs);
+  const int r_ly0 = tid / kLanesPerRow, r_lx = (tid % kLanesPerRow) * 4;
+  const int r_px = x_base + r_lx;
+  float4 sens_p[kPasses];
+#pragma unroll
+  for (int ps = 0; ps < kPasses; ps++) {
+    const int r_ly = r_ly0 + ps * kRowsPerPass, r_py = y_base + r_ly;
+    const bool r_valid = r_ly < kTileH && r_py < a.height && r_px < a.width;
+    const size_t gofs = ((size_t)stream * a.height + r_py) * a.width + r_px;
+    sens_p[ps] = make_float4(0, 0, 0, 0);
+    if (!TWO_KERNEL && r_valid && vec) {
+      if (U16) {
+        const ushort4 q = *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(a.depth) + gofs);
+        sens_p[ps] = make_float4(u16_to_metres(q.x), u16_to_metres(q.y), u16_to_metres(q.z), u16_to_metres(q.w));
+      } else {
+        sens_p[ps] = *reinterpret_cast<const float4*>(a.depth + gofs);
+      }
     }
   }
   const uint32_t n = min(count, a.capacity), nf = min(fcount, a.fcapacity);
@@ -1546,8 +1557,14 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
     }
   }
 
-  // resolve: kLanesPerRow lanes x 4 pixels per tile row, the whole tile in one pass
-  if (r_valid) {
+  // resolve: kLanesPerRow lanes x 4 pixels per tile row, kRowsPerPass rows per pass
+#pragma unroll
+  for (int ps = 0; ps < kPasses; ps++) {
+    const int r_ly = r_ly0 + ps * kRowsPerPass, r_py = y_base + r_ly;
+    const bool r_valid = r_ly < kTileH && r_py < a.height && r_px < a.width;
+    const size_t gofs = ((size_t)stream * a.height + r_py) * a.width + r_px;
+    const float4 sens = sens_p[ps];
+    if (!r_valid) continue;
     const int ly = r_ly, lx = r_lx, px = r_px, py = r_py;
     float z[4];
     bool frag[4];

@@ -1,0 +1,5 @@
+# timing experiments of the set-up kernel (results are wrong with these flags): see SetupArgs.flags
+for f in 0 0x10000 0x20000 0x40000 0x60000; do
+ echo -n "flags=$f "; python bench.py --steps 20 --warmup 3 --cpu-seconds 0 --check-frames 0 --debug-flags $f 2>&1 | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), d['kernel_ms_per_step']['ms_setup'], d['kernel_ms_per_step']['ms_raster'])"
+done
