@@ -308,11 +308,11 @@ static int alloc_frame_buffers(rtuf_context* c)
   if (!cap) cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->n_tris + 16, 256), 4 * kTileW * kTileH);   // 4 records per tile pixel
   // keep the bins (records + fragments) under ~32 GiB by shrinking the in-flight group
   const size_t budget = (size_t)32 << 30;
-  while (G > 1 && (size_t)G * tiles * cap * (sizeof(PackedTri) + 2 * sizeof(Frag)) > budget) G = (G + 1) / 2;
+  while (G > 1 && (size_t)G * tiles * cap * (sizeof(PackedTri) + 4 * sizeof(Frag)) > budget) G = (G + 1) / 2;
   c->group = G;
   c->capacity = cap;
   c->clip_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 8192 / kCounterShards, 1024), (size_t)1 << 22);   // per shard
-  c->fcapacity = std::max<uint32_t>(2 * cap, 1024);   // 16-byte fragments of all boxes up to 4x4 pixel centres
+  c->fcapacity = std::max<uint32_t>(4 * cap, 1024);   // 8-byte fragments of all boxes up to 4x4 pixel centres
   HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(PackedTri)));
   HIP_TRY(c, hipMalloc(&c->d_bin_count, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(c->d_bin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
@@ -416,6 +416,7 @@ int rtuf_finalize_models(rtuf_context* c)
   c->n_links = link_base;
   c->n_draws = (int)draws.size();
   c->n_tris = tri_seq;
+  if (tri_seq >= (int64_t)kMaxOrder) return c->fail(RTUF_ERR_CAPACITY, "%lld triangles: draw-order keys are limited to %u", (long long)tri_seq, kMaxOrder);
   // background quad as the hidden last draw (used only when a stream's projection does not make
   // it a constant full-screen plane): GL_QUADS -> (0,1,3), (1,2,3); both get order 0
   {

@@ -15,7 +15,7 @@
 //     depth  f32[N][H][W] in, masked f32[N][H][W] + mask u8[N][H][W] out
 //   rasteriser working set, per in-flight stream g and screen tile
 //     bin_count u32[G][tiles], bins PackedTri[G][tiles][capacity]  (triangles, 32 B records)
-//     fbin_count u32[G][tiles], fbins Frag[G][tiles][fcapacity]    (pixels of tiny triangles, 16 B)
+//     fbin_count u32[G][tiles], fbins Frag[G][tiles][fcapacity]    (pixels of small triangles, 8 B)
 //     clip_list ClipItem[], zsurface f32[G][H][W] (two-kernel mode only)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -58,13 +58,15 @@ struct alignas(16) PackedTri {  // 32 B: what a triangle bin stores; the tile ke
 };
 static_assert(sizeof(PackedTri) == 32, "PackedTri must be 32 bytes");
 
-struct alignas(16) Frag {       // 16 B: one covered pixel of a tiny (<= 2x2 px bounding box) triangle
-  uint32_t xy;                  // x | y << 16
-  uint32_t z24;                 // 24-bit depth-test value
-  uint32_t order;               // draw-order sequence number
-  uint32_t zbits;               // float window z (what the fragment shader sees)
-};
-static_assert(sizeof(Frag) == 16, "Frag must be 16 bytes");
+// 8 B: one covered pixel of a small (<= 4x4 pixel centres, single tile) triangle, ready for the depth
+// test:  z24 << 40 | order << kFragPosBits | position in the tile (y * kTileW + x).
+// Fragments carry no z plane, so triangles that may win with window z <= 0.5 (where the float z the
+// shader sees is finer than 24 bits) are never resolved to fragments; they stay records.
+constexpr int kFragPosBits = 11;
+constexpr uint32_t kMaxOrder = (1u << (40 - kFragPosBits)) - 1u;    // draw-order keys must fit 29 bits
+static_assert(kTileW * kTileH <= (1 << kFragPosBits), "tile positions must fit the fragment's position field");
+struct alignas(8) Frag { unsigned long long v; };
+static_assert(sizeof(Frag) == 8, "Frag must be 8 bytes");
 
 struct Chunk {                  // <= 256 consecutive triangles of one draw + their vertex list
   uint32_t tri_begin;           // into ctris

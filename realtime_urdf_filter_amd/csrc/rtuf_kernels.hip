@@ -749,7 +749,8 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
     base = __shfl(base, myleader);
     if (act) {
       uint32_t pos = base + base_in_group;
-      uint4* dst = reinterpret_cast<uint4*>(a.fbins) + (size_t)bin * a.fcapacity;
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.fbins) + (size_t)bin * a.fcapacity;
+      const int lbase = (by0 % kTileH) * kTileW + (bx0 % kTileW);
       uint32_t m = mask;
       while (m) {
         const int k = __ffs((int)m) - 1;
@@ -757,11 +758,8 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
         const int px = bx0 + (k & 3), py = by0 + (k >> 2);
         if (pos < a.fcapacity) {
           const float z = __fmaf_rn(dzdy, (float)py, __fmaf_rn(dzdx, (float)px, a0));
-          uint4 f;
-          f.x = (uint32_t)px | ((uint32_t)py << 16);
-          f.y = z24_of(z);
-          f.z = order;
-          f.w = __float_as_uint(z);
+          const unsigned long long f = ((unsigned long long)z24_of(z) << 40) | ((unsigned long long)order << kFragPosBits) |
+                                       (unsigned long long)(lbase + (k >> 2) * kTileW + (k & 3));
           dst[pos] = f;
         }
         pos++;
@@ -778,12 +776,9 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
       const uint32_t pos = atomicAdd(&a.fbin_count[bin], 1u);
       if (pos < a.fcapacity) {
         const float z = __fmaf_rn(dzdy, (float)py, __fmaf_rn(dzdx, (float)px, a0));
-        uint4 f;
-        f.x = (uint32_t)px | ((uint32_t)py << 16);
-        f.y = z24_of(z);
-        f.z = order;
-        f.w = __float_as_uint(z);
-        reinterpret_cast<uint4*>(a.fbins)[(size_t)bin * a.fcapacity + pos] = f;
+        const unsigned long long f = ((unsigned long long)z24_of(z) << 40) | ((unsigned long long)order << kFragPosBits) |
+                                     (unsigned long long)((py % kTileH) * kTileW + (px % kTileW));
+        reinterpret_cast<unsigned long long*>(a.fbins)[(size_t)bin * a.fcapacity + pos] = f;
       }
     }
   }
@@ -887,8 +882,8 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
   __shared__ float s_win[kStreamsPerBlock][3][kMaxChunkVerts];  // window x, y, z (SoA: 12 B per vertex)
   __shared__ int2 s_snap[kStreamsPerBlock][kMaxChunkVerts];    // snapped x; snapped y << 8 | clip mask
   __shared__ uint32_t s_packed[kBlock];                         // the chunk's triangles
-  __shared__ uint16_t s_list[kStreamsPerBlock * kBlock];        // survivors: stream k << 8 | triangle
-  __shared__ uint16_t s_list2[kStreamsPerBlock * kBlock];       // survivors resolved as 4x4 fragment boxes
+  __shared__ uint16_t s_list[kStreamsPerBlock * kBlock];        // survivors binned as records: stream k << 8 | triangle
+  __shared__ uint16_t s_list2[kStreamsPerBlock * kBlock];       // survivors resolved to fragments: 4x4 boxes from the bottom, 2x2 from the top
   __shared__ uint32_t s_nlist, s_ntiny, s_nsmall;
   __shared__ uint32_t s_stat[3];
   __shared__ float s_mvp[kStreamsPerBlock][16];
@@ -1012,8 +1007,8 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
         }
       }
     }
-    // survivors go to one of two LDS work lists: tiny boxes (<= 2x2 pixel centres: resolved to
-    // fragments) grow from the top of s_list, everything else (binned as records) from the bottom
+    // survivors go to LDS work lists: records into s_list; boxes resolved to fragments into s_list2
+    // (<= 4x4 single-tile boxes from the bottom, <= 2x2 boxes from the top)
     const bool rec = survive && !tiny && !small;
     const unsigned long long sm = __ballot(rec), tm = __ballot(tiny), qm = __ballot(small);
     if (sm) {
@@ -1028,7 +1023,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
       uint32_t base = 0;
       if (lane == leader) base = atomicAdd(&s_ntiny, (uint32_t)__popcll(tm));
       base = __shfl(base, leader);
-      if (tiny) s_list[kStreamsPerBlock * kBlock - 1 - (base + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull)))] = (uint16_t)((k << 8) | tid);
+      if (tiny) s_list2[kStreamsPerBlock * kBlock - 1 - (base + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull)))] = (uint16_t)((k << 8) | tid);
     }
     if (qm) {
       const int leader = __ffsll((long long)qm) - 1;
@@ -1040,9 +1035,61 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
   }
   __syncthreads();
   if (a.flags & 0x10000u) { __syncthreads(); if (!STRIDED) break; continue; }     // timing experiment
-  // phase 3a: dense set-up + binning of the larger survivors as 32-byte records (the tile kernel
+  // phase 3a/3b: tiny (2x2) and small (4x4, single tile) survivors -> coverage of their box positions
+  // -> 8-byte fragments; the z plane (one division) is only evaluated for triangles that actually
+  // cover a pixel centre
+  const uint32_t ntiny = s_ntiny, nsmall = s_nsmall;
+#pragma unroll
+  for (int cls = 0; cls < 2; cls++) {
+    const uint32_t ncls = cls == 0 ? ntiny : nsmall;
+    for (uint32_t base = 0; base < ncls; base += kBlock) {
+      const uint32_t j = base + tid;
+      uint32_t mask = 0;
+      int slot = 0, bx0 = 0, by0 = 0;
+      float a0 = 0, dzdx = 0, dzdy = 0;
+      uint32_t order = 0;
+      bool near = false;
+      uint32_t ent = 0;
+      if (j < ncls) {
+        Win v0, v1, v2;
+        const uint32_t e = s_list2[cls == 0 ? kStreamsPerBlock * kBlock - 1 - j : j];
+        ent = e;
+        const int k = (int)(e >> 8), t = (int)(e & 255u);
+        slot = s_slot[k];
+        const uint32_t p = s_packed[t];
+        const uint32_t j0 = p & 1023u, j1 = (p >> 10) & 1023u, j2 = (p >> 20) & 1023u;
+        v0.x = s_win[k][0][j0]; v0.y = s_win[k][1][j0]; v0.z = s_win[k][2][j0];
+        v1.x = s_win[k][0][j1]; v1.y = s_win[k][1][j1]; v1.z = s_win[k][2][j1];
+        v2.x = s_win[k][0][j2]; v2.y = s_win[k][1][j2]; v2.z = s_win[k][2][j2];
+        mask = cls == 0 ? small_box_coverage<2>(v0, v1, v2, a.width, a.height, bx0, by0)
+                        : small_box_coverage<4>(v0, v1, v2, a.width, a.height, bx0, by0);
+        if (mask) {
+          z_plane(v0, v1, v2, a0, dzdx, dzdy);
+          order = is_bg ? 0u : ch.order_base + (uint32_t)t;
+          // z is monotone along x and along y (also as evaluated in float), so its minimum over the box
+          // is at a corner.  Anything that may reach window z <= 0.5 needs its plane in the tile
+          // kernel (exact float z): it goes out as a record instead (geometry within ~2 x near of the camera).
+          const float xa = (float)bx0, xb = (float)(bx0 + 3), ya = (float)by0, yb = (float)(by0 + 3);
+          const float zaa = __fmaf_rn(dzdy, ya, __fmaf_rn(dzdx, xa, a0)), zba = __fmaf_rn(dzdy, ya, __fmaf_rn(dzdx, xb, a0));
+          const float zab = __fmaf_rn(dzdy, yb, __fmaf_rn(dzdx, xa, a0)), zbb = __fmaf_rn(dzdy, yb, __fmaf_rn(dzdx, xb, a0));
+          near = !(zaa >= 0.51f && zba >= 0.51f && zab >= 0.51f && zbb >= 0.51f);      // (NaN counts as near)
+        }
+      }
+      if (near) {      // rare: hand the triangle to the record pass below (one LDS append)
+        s_list[atomicAdd(&s_nlist, 1u)] = (uint16_t)ent;
+        mask = 0;
+      }
+      if (__ballot(mask != 0) && !(a.flags & 0x40000u)) {
+        nfrag += cls == 0 ? emit_fragments_wave<true>(a, slot, mask, bx0, by0, a0, dzdx, dzdy, order)
+                          : emit_fragments_wave<false>(a, slot, mask, bx0, by0, a0, dzdx, dzdy, order);
+        binned += mask ? 1u : 0u;
+      }
+    }
+  }
+  __syncthreads();        // appends of the fragment pass to the record list
+  // phase 3c: dense set-up + binning of the larger survivors as 32-byte records (the tile kernel
   // rebuilds the edge functions, so only orientation, bounding box and z plane are needed here)
-  const uint32_t nlist = s_nlist, ntiny = s_ntiny;
+  const uint32_t nlist = s_nlist;
   for (uint32_t base = 0; base < nlist; base += kBlock) {
     const uint32_t j = base + tid;
     bool have = false;
@@ -1072,43 +1119,6 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
     if (__ballot(have) && !(a.flags & 0x20000u)) {
       entries += emit_record_wave(a, slot, have, bbx, bby, pk);
       binned += have ? 1u : 0u;
-    }
-  }
-  // phase 3b/3c: tiny (2x2) and small (4x4, single tile) survivors -> coverage of their box positions
-  // -> 16-byte fragments; the z plane (one division) is only evaluated for triangles that actually
-  // cover a pixel centre
-  const uint32_t nsmall = s_nsmall;
-#pragma unroll
-  for (int cls = 0; cls < 2; cls++) {
-    const uint32_t ncls = cls == 0 ? ntiny : nsmall;
-    for (uint32_t base = 0; base < ncls; base += kBlock) {
-      const uint32_t j = base + tid;
-      uint32_t mask = 0;
-      int slot = 0, bx0 = 0, by0 = 0;
-      float a0 = 0, dzdx = 0, dzdy = 0;
-      uint32_t order = 0;
-      if (j < ncls) {
-        const uint32_t e = cls == 0 ? s_list[kStreamsPerBlock * kBlock - 1 - j] : s_list2[j];
-        const int k = (int)(e >> 8), t = (int)(e & 255u);
-        slot = s_slot[k];
-        const uint32_t p = s_packed[t];
-        const uint32_t j0 = p & 1023u, j1 = (p >> 10) & 1023u, j2 = (p >> 20) & 1023u;
-        Win v0, v1, v2;
-        v0.x = s_win[k][0][j0]; v0.y = s_win[k][1][j0]; v0.z = s_win[k][2][j0];
-        v1.x = s_win[k][0][j1]; v1.y = s_win[k][1][j1]; v1.z = s_win[k][2][j1];
-        v2.x = s_win[k][0][j2]; v2.y = s_win[k][1][j2]; v2.z = s_win[k][2][j2];
-        mask = cls == 0 ? small_box_coverage<2>(v0, v1, v2, a.width, a.height, bx0, by0)
-                        : small_box_coverage<4>(v0, v1, v2, a.width, a.height, bx0, by0);
-        if (mask) {
-          z_plane(v0, v1, v2, a0, dzdx, dzdy);
-          order = is_bg ? 0u : ch.order_base + (uint32_t)t;
-        }
-      }
-      if (__ballot(mask != 0) && !(a.flags & 0x40000u)) {
-        nfrag += cls == 0 ? emit_fragments_wave<true>(a, slot, mask, bx0, by0, a0, dzdx, dzdy, order)
-                          : emit_fragments_wave<false>(a, slot, mask, bx0, by0, a0, dzdx, dzdy, order);
-        binned += mask ? 1u : 0u;
-      }
     }
   }
   if (!STRIDED) break;
@@ -1434,17 +1444,15 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
   }
 }
 
-// Fragments of the tiny triangles: 16-byte records, perfectly coalesced, one LDS atomic each.
-template <int MODE>
-__device__ __forceinline__ void raster_frags(unsigned long long* keys, const uint4* frags, uint32_t nf,
-                                             int x_base, int y_base, int tid)
+// Fragments of the small triangles: 8 bytes each, perfectly coalesced, one LDS atomic each.  They never
+// need the exact-float-z pass (the set-up kernel keeps anything with window z near 0.5 or below as a record).
+__device__ __forceinline__ void raster_frags(unsigned long long* keys, const unsigned long long* frags, uint32_t nf, int tid)
 {
   for (uint32_t i = tid; i < nf; i += kBlock) {
-    const uint4 f = frags[i];
-    const int lidx = ((int)(f.x >> 16) - y_base) * kTileW + ((int)(f.x & 0xffff) - x_base);
-    const unsigned long long key = ((unsigned long long)f.y << 32) | f.z;
-    if (MODE == 0) atomicMin(&keys[lidx], key);
-    else if (keys[lidx] == key) keys[lidx] = kResolvedBit | (unsigned long long)f.w;
+    const unsigned long long f = frags[i];
+    const int lidx = (int)((uint32_t)f & ((1u << kFragPosBits) - 1u));
+    const unsigned long long key = ((f >> 40) << 32) | ((f >> kFragPosBits) & (unsigned long long)kMaxOrder);
+    atomicMin(&keys[lidx], key);
   }
 }
 
@@ -1526,7 +1534,7 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
   }
   const uint32_t n = min(count, a.capacity), nf = min(fcount, a.fcapacity);
   const PackedTri* recs = a.bins + (size_t)bin * a.capacity;
-  const uint4* frags = reinterpret_cast<const uint4*>(a.fbins) + (size_t)bin * a.fcapacity;
+  const unsigned long long* frags = reinterpret_cast<const unsigned long long*>(a.fbins) + (size_t)bin * a.fcapacity;
   // flags bits 8.. are timing experiments only (wrong results): 0x100 skip rasterisation, 0x200 skip pixel loops
   const bool empty = (n == 0 && nf == 0) || (a.flags & 0x100u);   // no geometry in this tile: pure streaming compare
   if (!empty) {
@@ -1540,7 +1548,7 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
       if (fcount) atomicMax(&sh.max_fbin_fill, fcount);
     }
     if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, (int)((a.flags >> 12) & 3u));
-    if (!(a.flags & 0x400u)) raster_frags<0>(keys, frags, nf, x_base, y_base, tid);
+    if (!(a.flags & 0x400u)) raster_frags(keys, frags, nf, tid);
     __syncthreads();
 
     // Does any pixel need the exact float z of its winner?  Only when the winning depth is in the
@@ -1552,7 +1560,6 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
     }
     if (__syncthreads_or(need)) {
       raster_bin<1>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height);
-      raster_frags<1>(keys, frags, nf, x_base, y_base, tid);
       __syncthreads();
     }
   }

@@ -291,6 +291,41 @@ def test_two_kernel_zsurface_matches_oracle_z():
     ctx.close()
 
 
+def test_small_triangles_closer_than_twice_the_near_plane():
+    """Window z <= 0.5 (eye distance <= 2nf/(n+f) ~ 0.2 m) is where the float z the shader sees is finer
+    than the 24-bit depth value.  Small triangles are normally resolved to 8-byte fragments that carry
+    no z plane; the ones that may reach that range must keep their plane (records + exact-z pass).
+    Thousands of 1-4 pixel triangles between 0.105 m and 0.35 m: z-surface and outputs are bit-exact."""
+    W, H, n_tris = 160, 120, 5000
+    rng = np.random.default_rng(77)
+    P = S.projection(525.0 * W / 640, 525.0 * W / 640, (W - 1) / 2, (H - 1) / 2, W, H)
+    zc = rng.uniform(0.105, 0.35, n_tris)
+    centre = np.stack([rng.uniform(-0.55, 0.55, n_tris) * zc, rng.uniform(-0.42, 0.42, n_tris) * zc, zc], axis=1)
+    size = rng.uniform(0.004, 0.02, n_tris) * zc
+    verts = (centre[:, None, :] + rng.normal(size=(n_tris, 3, 3)) * size[:, None, None]).reshape(-1, 3).astype(np.float32)
+    tris = np.arange(3 * n_tris, dtype=np.uint32).reshape(-1, 3)
+    depth = S.sensor_depth(W, H, 0.5)
+    depth[::2] = np.float32(0.2)                 # sensor values around the rendered depths: both mask outcomes occur
+    I = S.gl(np.eye(4))
+    draws = [(I, 0, [0.0, 0.0, 0.0], verts, tris)]
+    om, ok, zwin, prim, _ = O.filter_frame(depth, P, draws, I, I, replace_value=5.0, want_debug=True)
+    near = (zwin <= 0.5) & (prim > 0)
+    assert near.sum() > 500 and ((zwin > 0.5) & (prim > 0)).sum() > 500       # the scene straddles z = 0.5
+    for two_kernel in (True, False):
+        ctx = R.Context(W, H, 1, 0, params(5.0, 0.05, two_kernel))
+        m = ctx.add_model()
+        ctx.add_draw(m, ctx.add_link(m), verts, tris, 0, [0.0, 0.0, 0.0])
+        ctx.finalize_models()
+        ctx.set_camera(0, P, I, I)
+        ctx.set_link_poses(0, m, np.stack([I]))
+        masked, mask = ctx.filter_batch(depth[None])
+        assert (ok != mask[0]).sum() == 0 and bits_equal(om, masked[0])
+        if two_kernel:
+            assert bits_equal(ctx.read_zsurface(1)[0], zwin)
+        assert ctx.stats()["fragments_binned"] > 1000
+        ctx.close()
+
+
 def test_cpp_facade_example_matches_reference(tmp_path):
     """examples/example_filter.cpp: the reference's single-camera C++ usage on the facade classes
     (RealtimeURDFFilter::getProjectionMatrix / filter / getMaskedDepth / mask_) reproduces the
