@@ -88,8 +88,10 @@ def main():
         if args.u16:
             host = np.clip(np.rint(np.nan_to_num(host, nan=0.0, posinf=0.0) * 1000.0), 0, 65535).astype(np.uint16).view(np.int16)
         d_depth.append(torch.from_numpy(host).to(dev))
-    d_masked = torch.empty((n, H, W), dtype=torch.int16 if args.u16 else torch.float32, device=dev)
-    d_mask = None if args.no_mask else torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+    # two output sets: with two batches in flight, batch k+1 must not write where batch k's results are still unread
+    d_masked_set = [torch.empty((n, H, W), dtype=torch.int16 if args.u16 else torch.float32, device=dev) for _ in range(2)]
+    d_mask_set = [None if args.no_mask else torch.empty((n, H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_masked, d_mask = d_masked_set[0], d_mask_set[0]
     torch.cuda.synchronize()
 
     def stage(k):
@@ -99,12 +101,19 @@ def main():
         else:
             variants[v].stage_joint_positions(ctx, ids, first_call=(k == 0))      # joint angles in, forward kinematics on the GPU
 
-    def step(k):
-        # one step = one batch through the hot path.  The next batch's joint positions are staged (host
-        # memory only, double-buffered inside the library) while the GPU works on this one.
-        v = k % len(variants)
-        (ctx.filter_batch_device_u16 if args.u16 else ctx.filter_batch_device)(n, d_depth[v].data_ptr(), d_masked.data_ptr(), d_mask.data_ptr() if d_mask is not None else 0)
+    submit = ctx.filter_batch_device_u16 if args.u16 else ctx.filter_batch_device
+    ptrs = [(d_masked_set[i].data_ptr(), d_mask_set[i].data_ptr() if d_mask_set[i] is not None else 0) for i in range(2)]
+    dptr = [d.data_ptr() for d in d_depth]
+
+    def enqueue(k):
+        # one step = one batch through the hot path: enqueue it, then stage the NEXT batch's joint positions
+        # (host memory only) while the GPU works.  The library keeps up to two batches in flight and retires
+        # the oldest when a third arrives, so the host round trip of one step overlaps the next one's kernels.
+        submit(n, dptr[k % len(variants)], ptrs[k % 2][0], ptrs[k % 2][1])
         stage(k + 1)
+
+    def step(k):
+        enqueue(k)
         ctx.sync()
 
     def barrier():
@@ -117,16 +126,17 @@ def main():
     torch.cuda.synchronize()
     barrier()
     acc = {"ms_pose": 0.0, "ms_setup": 0.0, "ms_raster": 0.0, "ms_compare": 0.0, "ms_total": 0.0}
+    ctx.enable_timing(2)       # (re)starts the library's per-batch event sums: tile (and compare) kernel only
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(args.warmup + k)
-        st = ctx.stats()
-        for key in acc:
-            acc[key] += st[key]
+        enqueue(args.warmup + k)
     ctx.sync()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    assert st["timed_batches"] == args.steps, (st["timed_batches"], args.steps)
+    acc["ms_raster"], acc["ms_compare"] = st["sum_ms_raster"], st["sum_ms_compare"]
     # stage-by-stage breakdown: a few extra steps with every stage bracketed by events, outside the timed region
     raster_ms = acc["ms_raster"] / max(args.steps, 1)
     compare_ms = acc["ms_compare"] / max(args.steps, 1)
@@ -203,6 +213,8 @@ def main():
             from realtime_urdf_filter_amd.filter import depth_f32_to_u16, depth_u16_to_f32
             v_last = (args.warmup + args.steps - 1) % len(variants)
             wl = variants[v_last]
+            k_last = args.warmup + args.steps + extra - 1
+            d_masked, d_mask = d_masked_set[k_last % 2], d_mask_set[k_last % 2]
             hm = d_masked.cpu().numpy()
             hk = d_mask.cpu().numpy() if d_mask is not None else None
             hd = d_depth[v_last].cpu().numpy()

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTUF_ABI_VERSION 1
+#define RTUF_ABI_VERSION 2
 
 typedef struct rtuf_context rtuf_context;
 
@@ -167,7 +167,12 @@ int rtuf_debug_read_poses(rtuf_context *ctx, int n_streams, double *link_tf_out,
 int rtuf_filter_batch(rtuf_context *ctx, int n_streams, const float *const *depth_in,
                       float *const *masked_out, uint8_t *const *mask_out);
 /* Same with device-resident planes: depth/masked are [n][H][W] float32, mask [n][H][W] u8 or
- * NULL.  Asynchronous on the context's stream; rtuf_sync() waits. */
+ * NULL.  Asynchronous on the context's stream.  Up to two batches may be in flight: a call made
+ * while two are pending first retires the oldest (as rtuf_sync does for all of them), so a caller
+ * that keeps enqueueing never leaves the GPU idle during the host round trip.  The buffers of a
+ * batch must stay valid and unmodified until it is retired (a bin regrowth runs it again);
+ * rtuf_set_joint_positions may be called at any time (its staging is per batch), every other
+ * setter waits for the batches in flight.  rtuf_sync() retires everything in flight. */
 int rtuf_filter_batch_device(rtuf_context *ctx, int n_streams, const float *d_depth,
                              float *d_masked, uint8_t *d_mask);
 /* 16UC1 variants: depth in / out as uint16 millimetres with the reference's conversions fused into the
@@ -203,6 +208,9 @@ typedef struct {
   uint32_t max_fbin_fill;           /* largest fragment bin of the last batch          */
   uint64_t fragments_binned;        /* covered pixels of tiny (<= 2x2 px) triangles binned as fragments */
   float ms_pose, ms_setup, ms_raster, ms_compare, ms_total;   /* last timed batch       */
+  uint32_t reserved0;
+  uint64_t timed_batches;           /* batches retired since rtuf_enable_timing, and the sums  */
+  double sum_ms_pose, sum_ms_setup, sum_ms_raster, sum_ms_compare, sum_ms_total;   /* of their times */
 } rtuf_stats;
 int rtuf_get_stats(rtuf_context *ctx, rtuf_stats *out);
 /* Per-kernel HIP-event timing (off by default: every event costs a few microseconds of stream

@@ -29,6 +29,8 @@ struct HostDraw {
   std::vector<uint32_t> tris;     // 3 per triangle, local vertex ids
 };
 struct HostLink { std::vector<HostDraw> draws; };
+static constexpr int kMaxInflight = 2;      // device batches that may be in flight at once
+
 struct Kinematics {               // on-device forward kinematics of one model
   int n_frames = 0, camera_frame = -1, max_depth = 0;
   int32_t* d_depth = nullptr;
@@ -36,10 +38,10 @@ struct Kinematics {               // on-device forward kinematics of one model
   bool dirty_q = true, dirty_aux = true;     // joint positions / root poses + enable flags changed on the host
   int32_t* d_parent = nullptr; int32_t* d_type = nullptr; double* d_origin = nullptr; double* d_axis = nullptr;
   int32_t* d_link_frame = nullptr; double* d_link_offset = nullptr;
-  // joint positions are staged in two pinned buffers that the forward-kinematics kernel reads in place
-  // (zero-copy): the batch in flight owns h_q[q_live], rtuf_set_joint_positions writes h_q[q_write], so
-  // the next frame's joint states can be staged while the GPU filters the current one
-  double* h_q[2] = {nullptr, nullptr};                      // [max_streams][n_frames]
+  // joint positions are staged in a ring of pinned buffers that the forward-kinematics kernel reads in
+  // place (zero-copy): every batch in flight owns the buffer it was enqueued with, rtuf_set_joint_positions
+  // writes h_q[q_write], so the next frame's joint states can be staged while the GPU filters
+  double* h_q[kMaxInflight + 1] = {};                      // [max_streams][n_frames]
   int q_live = 0, q_write = 0;
   bool q_carried = true;                                    // h_q[q_write] holds everything h_q[q_live] does
   double* h_root = nullptr; double* d_root = nullptr;       // [max_streams][12]
@@ -80,7 +82,7 @@ struct rtuf_context {
   uint32_t capacity = 0, fcapacity = 0, clip_capacity = 0;
   PackedTri* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr; WorkItem* d_items = nullptr; uint32_t items_hint = 0;
   Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
-  Counters* d_counters = nullptr; Counters* h_counters = nullptr;
+  Counters* d_counters = nullptr;
   float* d_zsurface = nullptr;
 
   // staging for the host-pointer API
@@ -90,10 +92,21 @@ struct rtuf_context {
   // single-stream outputs (masked_depth_ / mask_ of the reference)
   std::vector<float> single_masked; std::vector<uint8_t> single_mask;
 
-  // last device batch (for overflow re-run at sync time)
-  bool pending = false;
-  int last_n = 0; const float* last_depth = nullptr; float* last_masked = nullptr; uint8_t* last_mask = nullptr;
-  bool last_u16 = false;
+  // Batches in flight.  Up to kMaxInflight device batches may be enqueued before the oldest is retired
+  // (rtuf_sync, or the next rtuf_filter_batch_device* call when the ring is full), so the host round
+  // trip of one batch overlaps the GPU work of the next.  A batch keeps what a re-run after a bin
+  // regrowth needs: its buffers and which joint-position staging buffer it read.
+  struct Batch {
+    bool active = false;
+    int n = 0; const float* depth = nullptr; float* masked = nullptr; uint8_t* mask = nullptr; bool u16 = false;
+    Counters* h_counters = nullptr;          // pinned; filled by the copy that ends the batch
+    hipEvent_t done = nullptr;               // recorded after that copy
+    std::vector<hipEvent_t> events;          // stage timing
+    std::vector<int> q_idx;                  // per model: joint-position staging buffer
+  };
+  Batch batch[kMaxInflight];
+  int oldest = 0;                            // ring index of the oldest batch in flight
+  int pending = 0;                           // batches in flight
 
   // host staging areas changed since the last upload?
   bool dirty_cams = true, dirty_link_tf = true, dirty_mask = true;
@@ -101,7 +114,8 @@ struct rtuf_context {
 
   rtuf_stats stats{};
   int timing = 0;            // 0 off, 1 every stage, 2 only around the tile (and compare) kernel
-  std::vector<hipEvent_t> events;
+  double acc_ms[5] = {0, 0, 0, 0, 0};     // sums of ms_pose .. ms_total over the timed batches
+  uint64_t acc_batches = 0;
 
   int fail(int code, const char* fmt, ...)
   {
@@ -183,7 +197,8 @@ static void free_frame_buffers(rtuf_context* c)
   dfree(c->d_cams); dfree(c->d_link_tf); dfree(c->d_model_mask); dfree(c->d_mvp); dfree(c->d_bg_z); dfree(c->d_bg_mode);
   dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_items); dfree(c->d_counters); dfree(c->d_zsurface);
   dfree(c->d_depth); dfree(c->d_masked); dfree(c->d_mask);
-  hfree(c->h_cams); hfree(c->h_link_tf); hfree(c->h_model_mask); hfree(c->h_counters);
+  hfree(c->h_cams); hfree(c->h_link_tf); hfree(c->h_model_mask);
+  for (auto& b : c->batch) hfree(b.h_counters);
   c->staged_streams = 0;
 }
 
@@ -196,15 +211,17 @@ void rtuf_destroy(rtuf_context* c)
     Kinematics& k = m.kin;
     hipFree(k.d_depth); hipFree(k.d_parent); hipFree(k.d_type); hipFree(k.d_origin); hipFree(k.d_axis); hipFree(k.d_link_frame); hipFree(k.d_link_offset);
     hipFree(k.d_root); hipFree(k.d_enabled);
-    if (k.h_q[0]) hipHostFree(k.h_q[0]);
-    if (k.h_q[1]) hipHostFree(k.h_q[1]);
+    for (double* q : k.h_q) if (q) hipHostFree(q);
     if (k.h_root) hipHostFree(k.h_root);
     if (k.h_enabled) hipHostFree(k.h_enabled);
   }
   free_frame_buffers(c);
   auto dfree = [](auto*& p) { if (p) { hipFree(p); p = nullptr; } };
   dfree(c->d_cverts); dfree(c->d_ctris); dfree(c->d_chunks); dfree(c->d_draws);
-  for (hipEvent_t ev : c->events) hipEventDestroy(ev);
+  for (auto& b : c->batch) {
+    for (hipEvent_t ev : b.events) hipEventDestroy(ev);
+    if (b.done) hipEventDestroy(b.done);
+  }
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -283,7 +300,10 @@ static int alloc_frame_buffers(rtuf_context* c)
   HIP_TRY(c, hipHostMalloc(&c->h_cams, sizeof(Camera) * N));
   HIP_TRY(c, hipHostMalloc(&c->h_link_tf, sizeof(double) * 16 * L * N));
   HIP_TRY(c, hipHostMalloc(&c->h_model_mask, sizeof(uint64_t) * N));
-  HIP_TRY(c, hipHostMalloc(&c->h_counters, sizeof(Counters)));
+  for (auto& b : c->batch) {
+    HIP_TRY(c, hipHostMalloc(&b.h_counters, sizeof(Counters)));
+    if (!b.done) HIP_TRY(c, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+  }
   HIP_TRY(c, hipMalloc(&c->d_cams, sizeof(Camera) * N));
   HIP_TRY(c, hipMalloc(&c->d_link_tf, sizeof(double) * 16 * L * N));
   HIP_TRY(c, hipMalloc(&c->d_model_mask, sizeof(uint64_t) * N));
@@ -594,13 +614,11 @@ int rtuf_set_kinematics(rtuf_context* c, int model, int n_frames, const int32_t*
   HIP_TRY(c, hipMalloc(&k.d_link_offset, sizeof(double) * off.size()));
   HIP_TRY(c, hipMalloc(&k.d_root, sizeof(double) * N * 12));
   HIP_TRY(c, hipMalloc(&k.d_enabled, N));
-  HIP_TRY(c, hipHostMalloc(&k.h_q[0], sizeof(double) * N * n_frames));
-  HIP_TRY(c, hipHostMalloc(&k.h_q[1], sizeof(double) * N * n_frames));
+  for (double*& q : k.h_q) HIP_TRY(c, hipHostMalloc(&q, sizeof(double) * N * n_frames));
   HIP_TRY(c, hipHostMalloc(&k.h_root, sizeof(double) * N * 12));
   HIP_TRY(c, hipHostMalloc(&k.h_enabled, N));
   memset(k.h_enabled, 0, N);
-  memset(k.h_q[0], 0, sizeof(double) * N * n_frames);
-  memset(k.h_q[1], 0, sizeof(double) * N * n_frames);
+  for (double* q : k.h_q) memset(q, 0, sizeof(double) * N * n_frames);
   HIP_TRY(c, hipMemcpy(k.d_parent, parent, sizeof(int32_t) * n_frames, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(k.d_type, joint_type, sizeof(int32_t) * n_frames, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(k.d_origin, org.data(), sizeof(double) * org.size(), hipMemcpyHostToDevice));
@@ -668,12 +686,12 @@ int rtuf_debug_read_poses(rtuf_context* c, int n, double* link_tf_out, double* c
 }
 
 // ---- the hot path ---------------------------------------------------------------------
-static hipEvent_t get_event(rtuf_context* c, size_t i)
+static hipEvent_t get_event(rtuf_context::Batch& b, size_t i)
 {
-  while (c->events.size() <= i) {
-    hipEvent_t ev; hipEventCreate(&ev); c->events.push_back(ev);
+  while (b.events.size() <= i) {
+    hipEvent_t ev; hipEventCreate(&ev); b.events.push_back(ev);
   }
-  return c->events[i];
+  return b.events[i];
 }
 
 static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
@@ -698,15 +716,18 @@ static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
   return RTUF_OK;
 }
 
-static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask, bool io_u16, bool rerun = false)
+static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
 {
+  const int n = b.n;
+  const float* d_depth = b.depth; float* d_masked = b.masked; uint8_t* d_mask = b.mask;
+  const bool io_u16 = b.u16;
   const size_t esz = io_u16 ? sizeof(uint16_t) : sizeof(float);
   hipStream_t st = c->stream;
   const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
   const size_t L = (size_t)std::max(c->n_links, 1);
   const size_t plane = (size_t)c->width * c->height;
   size_t ev = 0;
-  if (c->timing == 1) hipEventRecord(get_event(c, ev++), st);
+  if (c->timing == 1) hipEventRecord(get_event(b, ev++), st);
   // only what the host changed since the last batch crosses the bus (with on-device forward
   // kinematics that is just the joint positions below)
   const bool more = n > c->uploaded_streams;
@@ -719,8 +740,18 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
   for (HostModel& m : c->models) {
     Kinematics& k = m.kin;
     if (!k.n_frames || !k.any_enabled) continue;
-    if (k.dirty_q && !rerun) {               // this batch takes the staged joint positions; later writes go to the other buffer
-      k.q_live = k.q_write; k.q_write ^= 1; k.q_carried = false; k.dirty_q = false;
+    const size_t mi = (size_t)(&m - &c->models[0]);
+    if (b.q_idx.size() < c->models.size()) b.q_idx.resize(c->models.size(), 0);
+    if (!rerun) {
+      if (k.dirty_q) {                       // this batch takes the staged joint positions ...
+        k.q_live = k.q_write; k.q_carried = false; k.dirty_q = false;
+        // ... and later writes go to a buffer no batch in flight reads (kMaxInflight + 1 buffers: one is always free)
+        bool used[kMaxInflight + 1] = {};
+        used[k.q_live] = true;
+        for (const auto& o : c->batch) if (o.active && &o != &b && mi < o.q_idx.size()) used[o.q_idx[mi]] = true;
+        for (int i = 0; i <= kMaxInflight; i++) if (!used[i]) { k.q_write = i; break; }
+      }
+      b.q_idx[mi] = k.q_live;
     }
     if (k.dirty_aux || more) {
       HIP_TRY(c, hipMemcpyAsync(k.d_root, k.h_root, sizeof(double) * 12 * (size_t)n, hipMemcpyHostToDevice, st));
@@ -729,7 +760,7 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
     k.dirty_aux = false;
     FkArgs fa{};
     fa.parent = k.d_parent; fa.depth = k.d_depth; fa.max_depth = k.max_depth; fa.joint_type = k.d_type; fa.joint_origin = k.d_origin; fa.joint_axis = k.d_axis;
-    fa.link_frame = k.d_link_frame; fa.link_offset = k.d_link_offset; fa.q = k.h_q[k.q_live]; fa.root_tf = k.d_root;
+    fa.link_frame = k.d_link_frame; fa.link_offset = k.d_link_offset; fa.q = k.h_q[b.q_idx[mi]]; fa.root_tf = k.d_root;
     fa.enabled = k.d_enabled; fa.link_tf = c->d_link_tf; fa.cams = c->d_cams;
     fa.n_streams = n; fa.n_frames = k.n_frames; fa.n_links_model = (int)m.links.size(); fa.link_base = m.link_base;
     fa.n_links_total = (int)L; fa.camera_frame = k.camera_frame;
@@ -741,7 +772,7 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
   pa.n_streams = n; pa.n_draws = c->n_draws; pa.n_links = (int)L; pa.z_far = c->params.far_plane;
   pa.width = c->width; pa.height = c->height;
   launch_pose(pa, st);
-  if (c->timing == 1) hipEventRecord(get_event(c, ev++), st);
+  if (c->timing == 1) hipEventRecord(get_event(b, ev++), st);
   for (int base = 0; base < n; base += c->group) {
     const int gs = std::min(c->group, n - base);
     // clip list is per group
@@ -757,7 +788,7 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
     launch_cull(sa, st);
     launch_setup(sa, c->items_hint, st);
     launch_clip(sa, st);
-    if (c->timing) hipEventRecord(get_event(c, ev++), st);
+    if (c->timing) hipEventRecord(get_event(b, ev++), st);
     TileArgs ta{};
     ta.bins = c->d_bins; ta.bin_count = c->d_bin_count;
     ta.fbins = c->d_fbins; ta.fbin_count = c->d_fbin_count; ta.fcapacity = c->fcapacity; ta.depth = d_depth; ta.masked = d_masked; ta.mask = d_mask;
@@ -768,7 +799,7 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
     ta.max_diff = c->params.depth_distance_threshold; ta.replace_value = c->params.filter_replace_value;
     ta.io_u16 = io_u16 ? 1 : 0;
     launch_tile(ta, two, st);
-    if (c->timing) hipEventRecord(get_event(c, ev++), st);
+    if (c->timing) hipEventRecord(get_event(b, ev++), st);
     if (two) {
       CompareArgs ca{};
       ca.depth = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_depth) + (size_t)base * plane * esz); ca.zsurface = c->d_zsurface;
@@ -778,62 +809,31 @@ static int enqueue_batch(rtuf_context* c, int n, const float* d_depth, float* d_
       ca.z_near = ta.z_near; ca.z_far = ta.z_far; ca.max_diff = ta.max_diff; ca.replace_value = ta.replace_value;
       launch_compare(ca, st);
     }
-    if (c->timing == 1 || (c->timing == 2 && two)) hipEventRecord(get_event(c, ev++), st);
+    if (c->timing == 1 || (c->timing == 2 && two)) hipEventRecord(get_event(b, ev++), st);
   }
-  HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(b.h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipEventRecord(b.done, st));
   HIP_TRY(c, hipGetLastError());
   return RTUF_OK;
 }
 
-int rtuf_filter_batch_device(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask)
+// Retires the oldest batch in flight: waits for it, reads its counters, and if a bin or the clip list
+// overflowed, enlarges them and runs that batch and every later one again (their inputs are intact).
+static int retire_oldest(rtuf_context* c)
 {
-  if (!c) return RTUF_ERR_INVALID;
-  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
-  if (n <= 0 || n > c->max_streams || !d_depth || !d_masked) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
-  hipSetDevice(c->device);
-  if ((c->params.flags & RTUF_FLAG_TWO_KERNEL) && !c->d_zsurface)
-    HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));
-  if (c->pending) { const int rc = rtuf_sync(c); if (rc != RTUF_OK) return rc; }
-  c->last_n = n; c->last_depth = d_depth; c->last_masked = d_masked; c->last_mask = d_mask;
-  c->last_u16 = false;
-  const int rc = enqueue_batch(c, n, d_depth, d_masked, d_mask, false);
-  if (rc == RTUF_OK) c->pending = true;
-  return rc;
-}
-
-int rtuf_filter_batch_device_u16(rtuf_context* c, int n, const uint16_t* d_depth, uint16_t* d_masked, uint8_t* d_mask)
-{
-  if (!c) return RTUF_ERR_INVALID;
-  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
-  if (n <= 0 || n > c->max_streams || !d_depth || !d_masked) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
-  if (c->width & 3) return c->fail(RTUF_ERR_INVALID, "16UC1 path needs a width that is a multiple of 4");
-  hipSetDevice(c->device);
-  if ((c->params.flags & RTUF_FLAG_TWO_KERNEL) && !c->d_zsurface)
-    HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));
-  if (c->pending) { const int rc = rtuf_sync(c); if (rc != RTUF_OK) return rc; }
-  c->last_n = n; c->last_depth = reinterpret_cast<const float*>(d_depth); c->last_masked = reinterpret_cast<float*>(d_masked); c->last_mask = d_mask;
-  c->last_u16 = true;
-  const int rc = enqueue_batch(c, n, c->last_depth, c->last_masked, d_mask, true);
-  if (rc == RTUF_OK) c->pending = true;
-  return rc;
-}
-
-int rtuf_sync(rtuf_context* c)
-{
-  if (!c) return RTUF_ERR_INVALID;
-  hipSetDevice(c->device);
   for (int attempt = 0; attempt < 8; attempt++) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (!c->pending) return RTUF_OK;
+    rtuf_context::Batch& b = c->batch[c->oldest];
+    if (!c->pending || !b.active) { c->pending = 0; return RTUF_OK; }
+    HIP_TRY(c, hipEventSynchronize(b.done));
     struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0; unsigned max_bin_fill = 0, max_fbin_fill = 0, clip_overflow = 0; } k;
-    c->items_hint = c->h_counters->work.n_items;      // sizes the next batch's set-up grid
+    c->items_hint = b.h_counters->work.n_items;      // sizes the next batches' set-up grid
     for (int i = 0; i < kCounterShards; i++) {
-      const CounterShard& sh = c->h_counters->shard[i];
+      const CounterShard& sh = b.h_counters->shard[i];
       k.tris_binned += sh.tris_binned; k.bin_entries += sh.bin_entries; k.clip_count += sh.clip_count;
       k.max_bin_fill = std::max(k.max_bin_fill, sh.max_bin_fill); k.clip_overflow |= sh.clip_overflow;
       k.max_fbin_fill = std::max(k.max_fbin_fill, sh.max_fbin_fill); k.frags += sh.frags;
     }
-    c->stats.triangles_submitted = (uint64_t)c->n_tris * (uint64_t)c->last_n;
+    c->stats.triangles_submitted = (uint64_t)c->n_tris * (uint64_t)b.n;
     c->stats.triangles_binned = k.tris_binned;
     c->stats.bin_entries = k.bin_entries;
     c->stats.triangles_clipped = k.clip_count;
@@ -844,53 +844,105 @@ int rtuf_sync(rtuf_context* c)
     const bool bin_over = k.max_bin_fill > c->capacity || k.max_fbin_fill > c->fcapacity;
     const bool clip_over = k.clip_overflow != 0;
     if (!bin_over && !clip_over) {
-      c->pending = false;
-      if (c->timing == 1 && c->events.size() >= 2) {
+      if (c->timing == 1 && b.events.size() >= 2) {
         // events: [start, pose_end, (setup_end, tile_end, compare_end) per group ...]
         float ms = 0;
         c->stats.ms_pose = c->stats.ms_setup = c->stats.ms_raster = c->stats.ms_compare = 0;
-        hipEventElapsedTime(&ms, c->events[0], c->events[1]); c->stats.ms_pose = ms;
+        hipEventElapsedTime(&ms, b.events[0], b.events[1]); c->stats.ms_pose = ms;
         size_t e = 1;
-        for (int base = 0; base < c->last_n; base += c->group) {
-          hipEventElapsedTime(&ms, c->events[e], c->events[e + 1]); c->stats.ms_setup += ms;
-          hipEventElapsedTime(&ms, c->events[e + 1], c->events[e + 2]); c->stats.ms_raster += ms;
-          hipEventElapsedTime(&ms, c->events[e + 2], c->events[e + 3]); c->stats.ms_compare += ms;
+        for (int base = 0; base < b.n; base += c->group) {
+          hipEventElapsedTime(&ms, b.events[e], b.events[e + 1]); c->stats.ms_setup += ms;
+          hipEventElapsedTime(&ms, b.events[e + 1], b.events[e + 2]); c->stats.ms_raster += ms;
+          hipEventElapsedTime(&ms, b.events[e + 2], b.events[e + 3]); c->stats.ms_compare += ms;
           e += 3;
         }
-        hipEventElapsedTime(&ms, c->events[0], c->events[e]); c->stats.ms_total = ms;
-      } else if (c->timing == 2 && c->events.size() >= 2) {
+        hipEventElapsedTime(&ms, b.events[0], b.events[e]); c->stats.ms_total = ms;
+      } else if (c->timing == 2 && b.events.size() >= 2) {
         // events: (tile_begin, tile_end[, compare_end]) per group
         const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
         float ms = 0;
         c->stats.ms_pose = c->stats.ms_setup = c->stats.ms_raster = c->stats.ms_compare = c->stats.ms_total = 0;
         size_t e = 0;
-        for (int base = 0; base < c->last_n; base += c->group) {
-          hipEventElapsedTime(&ms, c->events[e], c->events[e + 1]); c->stats.ms_raster += ms;
-          if (two) { hipEventElapsedTime(&ms, c->events[e + 1], c->events[e + 2]); c->stats.ms_compare += ms; }
+        for (int base = 0; base < b.n; base += c->group) {
+          hipEventElapsedTime(&ms, b.events[e], b.events[e + 1]); c->stats.ms_raster += ms;
+          if (two) { hipEventElapsedTime(&ms, b.events[e + 1], b.events[e + 2]); c->stats.ms_compare += ms; }
           e += two ? 3 : 2;
         }
       }
+      if (c->timing) {
+        c->acc_ms[0] += c->stats.ms_pose; c->acc_ms[1] += c->stats.ms_setup; c->acc_ms[2] += c->stats.ms_raster;
+        c->acc_ms[3] += c->stats.ms_compare; c->acc_ms[4] += c->stats.ms_total;
+        c->acc_batches++;
+        c->stats.timed_batches = c->acc_batches;
+        c->stats.sum_ms_pose = c->acc_ms[0]; c->stats.sum_ms_setup = c->acc_ms[1]; c->stats.sum_ms_raster = c->acc_ms[2];
+        c->stats.sum_ms_compare = c->acc_ms[3]; c->stats.sum_ms_total = c->acc_ms[4];
+      }
+      b.active = false;
+      c->oldest = (c->oldest + 1) % kMaxInflight;
+      c->pending--;
       return RTUF_OK;
     }
-    // overflow: enlarge and run the batch again (inputs are still resident)
-    if (bin_over) { const int rc = grow_bins(c, k.max_bin_fill, k.max_fbin_fill); if (rc != RTUF_OK) { c->pending = false; return rc; } }
+    // overflow: wait for the later batches too, enlarge, and run everything in flight again in order
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (bin_over) { const int rc = grow_bins(c, k.max_bin_fill, k.max_fbin_fill); if (rc != RTUF_OK) { for (auto& o : c->batch) o.active = false; c->pending = 0; return rc; } }
     if (clip_over) {
       hipFree(c->d_clip_list); c->d_clip_list = nullptr;
       c->clip_capacity *= 4;
       HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
       c->stats.regrowths++;
     }
-    if (c->d_zsurface && (c->params.flags & RTUF_FLAG_TWO_KERNEL)) {
-      // group may have shrunk; the surface is sized for the old (larger) group, still fine
-    }
     const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
     HIP_TRY(c, hipMemsetAsync(c->d_bin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_fbin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->stream));
-    const int rc = enqueue_batch(c, c->last_n, c->last_depth, c->last_masked, c->last_mask, c->last_u16, true);
-    if (rc != RTUF_OK) { c->pending = false; return rc; }
+    for (int i = 0; i < c->pending; i++) {
+      const int rc = enqueue_batch(c, c->batch[(c->oldest + i) % kMaxInflight], true);
+      if (rc != RTUF_OK) { for (auto& o : c->batch) o.active = false; c->pending = 0; return rc; }
+    }
   }
-  c->pending = false;
+  for (auto& o : c->batch) o.active = false;
+  c->pending = 0;
   return c->fail(RTUF_ERR_CAPACITY, "tile bins still overflow after regrowth");
+}
+
+static int submit_batch(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask, bool u16)
+{
+  hipSetDevice(c->device);
+  if ((c->params.flags & RTUF_FLAG_TWO_KERNEL) && !c->d_zsurface)
+    HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));
+  // two-kernel mode keeps one z-surface: its batches do not overlap
+  const int limit = (c->params.flags & RTUF_FLAG_TWO_KERNEL) ? 1 : kMaxInflight;
+  while (c->pending >= limit) { const int rc = retire_oldest(c); if (rc != RTUF_OK) return rc; }
+  rtuf_context::Batch& b = c->batch[(c->oldest + c->pending) % kMaxInflight];
+  b.n = n; b.depth = d_depth; b.masked = d_masked; b.mask = d_mask; b.u16 = u16;
+  const int rc = enqueue_batch(c, b, false);
+  if (rc == RTUF_OK) { b.active = true; c->pending++; }
+  return rc;
+}
+
+int rtuf_filter_batch_device(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (n <= 0 || n > c->max_streams || !d_depth || !d_masked) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
+  return submit_batch(c, n, d_depth, d_masked, d_mask, false);
+}
+
+int rtuf_filter_batch_device_u16(rtuf_context* c, int n, const uint16_t* d_depth, uint16_t* d_masked, uint8_t* d_mask)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (n <= 0 || n > c->max_streams || !d_depth || !d_masked) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
+  if (c->width & 3) return c->fail(RTUF_ERR_INVALID, "16UC1 path needs a width that is a multiple of 4");
+  return submit_batch(c, n, reinterpret_cast<const float*>(d_depth), reinterpret_cast<float*>(d_masked), d_mask, true);
+}
+
+int rtuf_sync(rtuf_context* c)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  hipSetDevice(c->device);
+  while (c->pending) { const int rc = retire_oldest(c); if (rc != RTUF_OK) return rc; }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return RTUF_OK;
 }
 
 void* rtuf_stream(rtuf_context* c) { return c ? (void*)c->stream : nullptr; }
@@ -998,6 +1050,8 @@ int rtuf_enable_timing(rtuf_context* c, int on)
 {
   if (!c) return RTUF_ERR_INVALID;
   c->timing = on < 0 ? 0 : (on > 2 ? 1 : on);
+  for (double& v : c->acc_ms) v = 0;
+  c->acc_batches = 0;
   return RTUF_OK;
 }
 

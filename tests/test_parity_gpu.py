@@ -427,6 +427,46 @@ def test_staging_next_joint_positions_while_a_batch_is_in_flight():
     ctx.close()
 
 
+def test_two_batches_in_flight_and_regrowth_reruns_both():
+    """Two device batches may be enqueued before the first is retired; a third call retires the oldest.
+    With bins that are too small for the scene, the overflow is only seen when the first batch is
+    retired: both batches in flight are run again after the regrowth and still produce the reference
+    result from their own joint positions and buffers."""
+    import torch
+    n, W, H = 4, 320, 240
+    A = WL.pr2_workload(n, W, H, total_triangles=8000, first_state_seed=1000)
+    B = WL.pr2_workload(n, W, H, total_triangles=8000, first_state_seed=2000)
+    depth = A.depth_batch()
+    refs = []
+    ctx = R.Context(W, H, n, 0, params(A.replace_value, A.max_diff))
+    ids = A.load_into(ctx)
+    A.load_kinematics(ctx, ids)
+    for wl in (A, B):
+        wl.stage_joint_positions(ctx, ids, first_call=wl is A)
+        refs.append(ctx.filter_batch(depth))
+    ctx.close()
+
+    dev = torch.device("cuda:0")
+    d_depth = torch.from_numpy(depth).to(dev)
+    outs = [(torch.empty((n, H, W), dtype=torch.float32, device=dev), torch.empty((n, H, W), dtype=torch.uint8, device=dev)) for _ in range(3)]
+    torch.cuda.synchronize()
+    for cap in (0, 16):                      # default capacity, then bins that must grow
+        ctx = R.Context(W, H, n, 0, params(A.replace_value, A.max_diff, bin_capacity=cap))
+        ids = A.load_into(ctx)
+        A.load_kinematics(ctx, ids)
+        order = [A, B, A]
+        for i, wl in enumerate(order):       # three enqueues, no sync in between: the third retires the first
+            wl.stage_joint_positions(ctx, ids, first_call=(i == 0))
+            ctx.filter_batch_device(n, d_depth.data_ptr(), outs[i][0].data_ptr(), outs[i][1].data_ptr())
+        ctx.sync()
+        for i, wl in enumerate(order):
+            want = refs[0] if wl is A else refs[1]
+            assert np.array_equal(outs[i][1].cpu().numpy(), want[1]) and bits_equal(outs[i][0].cpu().numpy(), want[0]), (cap, i)
+        st = ctx.stats()
+        assert (st["regrowths"] > 0) == (cap == 16)
+        ctx.close()
+
+
 def test_config_c4_720p_pr2_plus_walls():
     """BASELINE config 4 shape: 1280x720, PR2-like robot + two static wall URDFs (full-screen boxes incl.
     quirk Q1: exercises the large-triangle path), several streams."""
