@@ -32,6 +32,10 @@ namespace rtuf {
 constexpr int kTileW = RTUF_TILE_W;      // screen tile of one raster workgroup (LDS: 8 B per pixel; 64x32 = 16 KB)
 constexpr int kTileH = RTUF_TILE_H;
 constexpr int kBlock = 256;
+#ifndef RTUF_TILE_THREADS
+#define RTUF_TILE_THREADS 256
+#endif
+constexpr int kTileThreads = RTUF_TILE_THREADS;   // threads of a tile workgroup
 constexpr int kMaxChunkVerts = 256;     // unique vertices per set-up chunk (one per lane; LDS: 24 B each per stream)
 #ifndef RTUF_STREAMS_PER_BLOCK
 #define RTUF_STREAMS_PER_BLOCK 3
@@ -199,6 +203,7 @@ struct TileArgs {
   const float* bg_z;             // [n]
   const uint32_t* bg_mode;       // [n]
   Counters* counters;
+  uint16_t* tile_order;          // [G][tiles]  each stream's tiles, fullest bins first (order_kernel); nullptr = natural order
   int group_base, group_size;
   int width, height, tiles_x, tiles_y;
   uint32_t capacity;
@@ -239,6 +244,7 @@ void launch_cull(const SetupArgs& a, hipStream_t st);
 void launch_setup(const SetupArgs& a, uint32_t items_hint, hipStream_t st);
 void launch_clip(const SetupArgs& a, hipStream_t st);
 void launch_reset_clip(Counters* c, hipStream_t st);
+void launch_order(const TileArgs& a, hipStream_t st);
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st);   // a.io_u16 selects the 16UC1 variant
 void launch_compare(const CompareArgs& a, hipStream_t st);
 

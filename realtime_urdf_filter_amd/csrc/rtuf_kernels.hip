@@ -1348,7 +1348,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
                                            int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, int dbg_skip = 0)
 {
   const int lane = tid & 63;
-  for (uint32_t base = 0; base < n; base += kBlock) {
+  for (uint32_t base = 0; base < n; base += kTileThreads) {
     const uint32_t i = base + tid;
     const bool have = i < n;
     TriRec r;
@@ -1373,15 +1373,29 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     if (dbg_skip == 1 && area <= kSmallArea) area = 0;      // timing experiment: no lane-per-triangle walk
     if (dbg_skip == 2 && area > kSmallArea) area = 0;       // timing experiment: no quarter-wave walk
     const bool small = area > 0 && area <= kSmallArea;
-    // lane-per-triangle: walk the bounding box as one run of `area` candidates
+    // lane-per-triangle: walk the bounding box as one run of `area` candidates.  The three edge values
+    // are stepped incrementally (one add each; a different step at the end of a row), which is the
+    // same integer arithmetic as evaluating A*px + B*py + C at every candidate.
     {
-      int lx = lx0, ly = ly0;
+      const int px0 = x_base + lx0, px1 = x_base + lx1;
+      int px = px0, py = y_base + ly0, lidx = ly0 * kTileW + lx0;
+      int e0 = __mul24(r.A[0], px) + __mul24(r.B[0], py) + r.C[0];
+      int e1 = __mul24(r.A[1], px) + __mul24(r.B[1], py) + r.C[1];
+      int e2 = __mul24(r.A[2], px) + __mul24(r.B[2], py) + r.C[2];
+      const int w1 = lx1 - lx0;                                           // steps per row
+      const int s0 = r.B[0] - __mul24(w1, r.A[0]), s1 = r.B[1] - __mul24(w1, r.A[1]), s2 = r.B[2] - __mul24(w1, r.A[2]);
+      const int row_step = kTileW - w1;
       int todo = small ? area : 0;
       while (__ballot(todo > 0)) {
         if (todo > 0) {
-          const int px = x_base + lx, py = y_base + ly;
-          if (inside(r, px, py)) fragment<MODE>(keys, r, px, py, ly * kTileW + lx);
-          if (++lx > lx1) { lx = lx0; ly++; }
+          if (min(e0, min(e1, e2)) > 0) fragment<MODE>(keys, r, px, py, lidx);
+          const bool wrap = px == px1;
+          e0 += wrap ? s0 : r.A[0];
+          e1 += wrap ? s1 : r.A[1];
+          e2 += wrap ? s2 : r.A[2];
+          lidx += wrap ? row_step : 1;
+          py += wrap ? 1 : 0;
+          px = wrap ? px0 : px + 1;
           todo--;
         }
       }
@@ -1448,7 +1462,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
 // need the exact-float-z pass (the set-up kernel keeps anything with window z near 0.5 or below as a record).
 __device__ __forceinline__ void raster_frags(unsigned long long* keys, const unsigned long long* frags, uint32_t nf, int tid)
 {
-  for (uint32_t i = tid; i < nf; i += kBlock) {
+  for (uint32_t i = tid; i < nf; i += kTileThreads) {
     const unsigned long long f = frags[i];
     const int lidx = (int)((uint32_t)f & ((1u << kFragPosBits) - 1u));
     const unsigned long long key = ((f >> 40) << 32) | ((f >> kFragPosBits) & (unsigned long long)kMaxOrder);
@@ -1490,15 +1504,48 @@ __device__ __forceinline__ float shade(float sensor, float z, const ShadeConsts&
   return filt ? k.replace_value : sensor;
 }
 
+// order_kernel: one workgroup per stream; counting sort of the stream's tiles by how full their bins are
+// (16 classes of log2(records + fragments / 8)), fullest first.  The tile kernel starts all streams'
+// fullest tiles first and the empty ones (most of the frame, pure streaming) last: a workgroup that
+// needs 50 us no longer starts in the final microseconds of a 400 us launch.
+__global__ __launch_bounds__(kBlock) void order_kernel(TileArgs a)
+{
+  __shared__ uint32_t s_hist[16], s_start[16];
+  const int tid = threadIdx.x, slot = blockIdx.x;
+  const int tiles = a.tiles_x * a.tiles_y;
+  if (tid < 16) s_hist[tid] = 0;
+  __syncthreads();
+  auto cls_of = [&](int t) {
+    const uint32_t w = a.bin_count[slot * tiles + t] + (a.fbin_count[slot * tiles + t] >> 3);
+    return 15 - min(15, 32 - (int)__clz((int)w));           // class 0 = fullest
+  };
+  for (int t = tid; t < tiles; t += kBlock) atomicAdd(&s_hist[cls_of(t)], 1u);
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int c = 0; c < 16; c++) { s_start[c] = run; run += s_hist[c]; }
+  }
+  __syncthreads();
+  for (int t = tid; t < tiles; t += kBlock) a.tile_order[(size_t)slot * tiles + atomicAdd(&s_start[cls_of(t)], 1u)] = (uint16_t)t;
+}
+
 template <bool TWO_KERNEL, bool U16>
-__global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
+__global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 {
   __shared__ unsigned long long keys[kTileW * kTileH];
 
   const int tid = threadIdx.x;
   const int tiles = a.tiles_x * a.tiles_y;
-  const int bin = blockIdx.x;
-  const int slot = bin / tiles, tile = bin - slot * tiles;
+  // workgroup -> (rank, stream): rank r of every stream before rank r + 1 of any (see order_kernel)
+  int slot, tile;
+  if (a.tile_order) {
+    const int r = blockIdx.x / a.group_size;
+    slot = blockIdx.x - r * a.group_size;
+    tile = (int)a.tile_order[(size_t)slot * tiles + r];
+  } else {
+    slot = blockIdx.x / tiles; tile = blockIdx.x - slot * tiles;
+  }
+  const int bin = slot * tiles + tile;
   const int stream = a.group_base + slot;
   const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
   const int x_base = txi * kTileW, y_base = tyi * kTileH;
@@ -1511,7 +1558,7 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
   const uint32_t count = a.bin_count[bin], fcount = a.fbin_count[bin];
   // The sensor pixels this lane will resolve are requested before anything else so that their HBM
   // latency overlaps the bin-counter round trip and all of the rasterisation.
-  constexpr int kLanesPerRow = kTileW / 4, kRowsPerPass = kBlock / kLanesPerRow;
+  constexpr int kLanesPerRow = kTileW / 4, kRowsPerPass = kTileThreads / kLanesPerRow;
   constexpr int kPasses = (kTileH + kRowsPerPass - 1) / kRowsPerPass;      // resolve passes per tile (1 for 32x32)
   const bool vec = (a.width & 3) == 0;
   const int r_ly0 = tid / kLanesPerRow, r_lx = (tid % kLanesPerRow) * 4;
@@ -1538,7 +1585,7 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
   // flags bits 8.. are timing experiments only (wrong results): 0x100 skip rasterisation, 0x200 skip pixel loops
   const bool empty = (n == 0 && nf == 0) || (a.flags & 0x100u);   // no geometry in this tile: pure streaming compare
   if (!empty) {
-    for (int i = tid; i < kTileW * kTileH; i += kBlock) keys[i] = bgkey;
+    for (int i = tid; i < kTileW * kTileH; i += kTileThreads) keys[i] = bgkey;
     __syncthreads();
     if (tid == 0) {
       a.bin_count[bin] = 0;                 // ready for the next batch
@@ -1554,7 +1601,7 @@ __global__ __launch_bounds__(kBlock) void tile_kernel(TileArgs a)
     // Does any pixel need the exact float z of its winner?  Only when the winning depth is in the
     // lower half of the depth range (z24 <= 2^23): above it, float z == (z24 + 1) * 2^-24 exactly.
     bool need = false;
-    for (int i = tid; i < kTileW * kTileH; i += kBlock) {
+    for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
       const unsigned long long k = keys[i];
       if (k != bgkey && (uint32_t)(k >> 32) <= 8388608u) need = true;
     }
@@ -1735,12 +1782,16 @@ void launch_clip(const SetupArgs& a, hipStream_t st)
   // the item count lives on the device: fixed grid, grid-stride loop
   hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * 64), dim3(kClipBlock), 0, st, a);
 }
+void launch_order(const TileArgs& a, hipStream_t st)
+{
+  hipLaunchKernelGGL(order_kernel, dim3(a.group_size), dim3(kBlock), 0, st, a);
+}
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st)
 {
   const int blocks = a.group_size * a.tiles_x * a.tiles_y;
-  if (two_kernel) hipLaunchKernelGGL((tile_kernel<true, false>), dim3(blocks), dim3(kBlock), 0, st, a);
-  else if (a.io_u16) hipLaunchKernelGGL((tile_kernel<false, true>), dim3(blocks), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL((tile_kernel<false, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+  if (two_kernel) hipLaunchKernelGGL((tile_kernel<true, false>), dim3(blocks), dim3(kTileThreads), 0, st, a);
+  else if (a.io_u16) hipLaunchKernelGGL((tile_kernel<false, true>), dim3(blocks), dim3(kTileThreads), 0, st, a);
+  else hipLaunchKernelGGL((tile_kernel<false, false>), dim3(blocks), dim3(kTileThreads), 0, st, a);
 }
 void launch_compare(const CompareArgs& a, hipStream_t st)
 {
