@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--triangles", type=int, default=250000, help="triangle budget of the PR2-like model")
     ap.add_argument("--variants", type=int, default=2, help="distinct input batches rotated through the steps")
+    ap.add_argument("--pipelines", type=int, default=1, help="contexts (HIP stream + bins each) per GPU that the batches alternate between: with 2 or 3, one batch's small and low-occupancy kernels overlap another's heavy ones (+8..12 %% frames/s), but kernels then share the GPU and per-launch times (roofline) no longer describe one kernel; default 1")
     ap.add_argument("--two-kernel", action="store_true", help="rasteriser + separate compare kernel")
     ap.add_argument("--host-poses", action="store_true", help="stage explicit link matrices from the host instead of joint positions + on-device forward kinematics")
     ap.add_argument("--u16", action="store_true", help="16UC1 depth in/out (uint16 millimetres) with the conversions fused into the kernels")
@@ -76,11 +77,17 @@ def main():
     if args.two_kernel:
         p.flags |= R.FLAG_TWO_KERNEL
     p.flags |= args.debug_flags
-    ctx = R.Context(W, H, n, local_rank, p)
-    ids = wl0.load_into(ctx)
-    if not args.host_poses:
-        wl0.load_kinematics(ctx, ids)
-    ctx.enable_timing(2)       # HIP events around the dominant kernel only (each event costs stream time)
+    P = max(1, args.pipelines)
+    ctxs, idss = [], []
+    for _ in range(P):
+        c = R.Context(W, H, n, local_rank, p)
+        i = wl0.load_into(c)
+        if not args.host_poses:
+            wl0.load_kinematics(c, i)
+        c.enable_timing(2)       # HIP events around the dominant kernel only (each event costs stream time)
+        ctxs.append(c)
+        idss.append(i)
+    ctx, ids = ctxs[0], idss[0]
 
     d_depth = []
     for v, wl in enumerate(variants):
@@ -88,67 +95,78 @@ def main():
         if args.u16:
             host = np.clip(np.rint(np.nan_to_num(host, nan=0.0, posinf=0.0) * 1000.0), 0, 65535).astype(np.uint16).view(np.int16)
         d_depth.append(torch.from_numpy(host).to(dev))
-    # two output sets: with two batches in flight, batch k+1 must not write where batch k's results are still unread
-    d_masked_set = [torch.empty((n, H, W), dtype=torch.int16 if args.u16 else torch.float32, device=dev) for _ in range(2)]
-    d_mask_set = [None if args.no_mask else torch.empty((n, H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
-    d_masked, d_mask = d_masked_set[0], d_mask_set[0]
+    # two output sets per pipeline: with two batches in flight per context, a batch must not write where an
+    # earlier batch's results are still unread
+    n_sets = 2 * P
+    d_masked_set = [torch.empty((n, H, W), dtype=torch.int16 if args.u16 else torch.float32, device=dev) for _ in range(n_sets)]
+    d_mask_set = [None if args.no_mask else torch.empty((n, H, W), dtype=torch.uint8, device=dev) for _ in range(n_sets)]
     torch.cuda.synchronize()
-
-    def stage(k):
-        v = k % len(variants)
-        if args.host_poses:
-            variants[v].stage(ctx, ids)
-        else:
-            variants[v].stage_joint_positions(ctx, ids, first_call=(k == 0))      # joint angles in, forward kinematics on the GPU
-
-    submit = ctx.filter_batch_device_u16 if args.u16 else ctx.filter_batch_device
-    ptrs = [(d_masked_set[i].data_ptr(), d_mask_set[i].data_ptr() if d_mask_set[i] is not None else 0) for i in range(2)]
+    V = len(variants)
+    staged_once = [False] * P
+    ptrs = [(d_masked_set[i].data_ptr(), d_mask_set[i].data_ptr() if d_mask_set[i] is not None else 0) for i in range(n_sets)]
     dptr = [d.data_ptr() for d in d_depth]
 
-    def enqueue(k):
-        # one step = one batch through the hot path: enqueue it, then stage the NEXT batch's joint positions
-        # (host memory only) while the GPU works.  The library keeps up to two batches in flight and retires
-        # the oldest when a third arrives, so the host round trip of one step overlaps the next one's kernels.
-        submit(n, dptr[k % len(variants)], ptrs[k % 2][0], ptrs[k % 2][1])
-        stage(k + 1)
+    def stage_into(ci, k):
+        if args.host_poses:
+            variants[k % V].stage(ctxs[ci], idss[ci])
+        else:   # joint angles in, forward kinematics on the GPU
+            variants[k % V].stage_joint_positions(ctxs[ci], idss[ci], first_call=not staged_once[ci])
+        staged_once[ci] = True
 
-    def step(k):
-        enqueue(k)
+    def submit(ci, k):
+        c = ctxs[ci]
+        (c.filter_batch_device_u16 if args.u16 else c.filter_batch_device)(n, dptr[k % V], ptrs[k % n_sets][0], ptrs[k % n_sets][1])
+
+    def enqueue(k):
+        # one step = one batch through the hot path: enqueue it on pipeline k mod P, then stage the NEXT batch's
+        # joint positions (host memory only) while the GPU works.  Each context keeps up to two batches in
+        # flight and retires its oldest when a third arrives; nothing in the loop waits for the GPU otherwise.
+        submit(k % P, k)
+        stage_into((k + 1) % P, k + 1)
+
+    def isolated_step(k):
+        stage_into(0, k)
+        submit(0, k)
         ctx.sync()
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    stage(0)
-    for k in range(args.warmup):
-        step(k)
+    k0 = args.warmup * P
+    for k in range(k0):            # every pipeline warms up (first batch: bin sizing) with one batch in flight
+        stage_into(k % P, k)
+        submit(k % P, k)
+        ctxs[k % P].sync()
     torch.cuda.synchronize()
     barrier()
-    acc = {"ms_pose": 0.0, "ms_setup": 0.0, "ms_raster": 0.0, "ms_compare": 0.0, "ms_total": 0.0}
-    ctx.enable_timing(2)       # (re)starts the library's per-batch event sums: tile (and compare) kernel only
+    for c in ctxs:
+        c.enable_timing(2)       # (re)starts the library's per-batch event sums: tile (and compare) kernel only
+    stage_into(k0 % P, k0)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        enqueue(args.warmup + k)
-    ctx.sync()
+    for k in range(k0, k0 + args.steps):
+        enqueue(k)
+    for c in ctxs:
+        c.sync()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    st = ctx.stats()
-    assert st["timed_batches"] == args.steps, (st["timed_batches"], args.steps)
-    acc["ms_raster"], acc["ms_compare"] = st["sum_ms_raster"], st["sum_ms_compare"]
-    # stage-by-stage breakdown: a few extra steps with every stage bracketed by events, outside the timed region
-    raster_ms = acc["ms_raster"] / max(args.steps, 1)
-    compare_ms = acc["ms_compare"] / max(args.steps, 1)
+    sts = [c.stats() for c in ctxs]
+    assert sum(st["timed_batches"] for st in sts) == args.steps, ([st["timed_batches"] for st in sts], args.steps)
+    raster_ms = sum(st["sum_ms_raster"] for st in sts) / max(args.steps, 1)
+    compare_ms = sum(st["sum_ms_compare"] for st in sts) / max(args.steps, 1)
+    # stage-by-stage breakdown: a few extra steps on one pipeline, one batch in flight, every stage bracketed
+    # by events, outside the timed region (kernel times without another batch sharing the GPU)
     ctx.enable_timing(1)
-    extra = 3 * len(variants)       # a multiple of the variant cycle: the last step run is the last timed step's variant (parity below)
-    acc = {key: 0.0 for key in acc}
-    for k in range(extra):
-        step(args.warmup + args.steps + k)
+    extra = 3 * V       # a multiple of the variant cycle: the last step run is the last timed step's variant (parity below)
+    acc = {"ms_pose": 0.0, "ms_setup": 0.0, "ms_raster": 0.0, "ms_compare": 0.0, "ms_total": 0.0}
+    for j in range(extra):
+        isolated_step(k0 + args.steps + j)
         st = ctx.stats()
         for key in acc:
             acc[key] += st[key]
     breakdown = {key: v / extra for key, v in acc.items()}
+    k_last = k0 + args.steps + extra - 1
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -168,9 +186,9 @@ def main():
         #   two-kernel mode   : tile kernel writes the 4 B/pixel z-surface; compare moves 13 B/pixel
         groups = 1
         if two:
-            cands = {"tile_kernel<two_kernel>": (per_timed["ms_raster"], 4 * px * n), "compare_kernel": (per_timed["ms_compare"], (13 if d_mask is not None else 12) * px * n)}
+            cands = {"tile_kernel<two_kernel>": (per_timed["ms_raster"], 4 * px * n), "compare_kernel": (per_timed["ms_compare"], (13 if (not args.no_mask) else 12) * px * n)}
         else:
-            bpp = (4 if args.u16 else 8) + (1 if d_mask is not None else 0)
+            bpp = (4 if args.u16 else 8) + (1 if (not args.no_mask) else 0)
             cands = {"tile_kernel<fused>": (per_timed["ms_raster"], bpp * px * n)}
         cands["setup_kernel+clip_kernel"] = (per["ms_setup"], 12 * wl0.n_vertices() + 16 * wl0.n_triangles())
         dom = max((k for k in cands if not k.startswith("setup")), key=lambda k: cands[k][0])
@@ -183,7 +201,7 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
             if (tj["kernel"] == dom and tj["streams"] == n and tj["width"] == W and tj["height"] == H
-                    and tj["triangles"] == wl0.meta["triangles"] and d_mask is not None and not args.u16):
+                    and tj["triangles"] == wl0.meta["triangles"] and (not args.no_mask) and not args.u16):
                 traffic = tj["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -194,10 +212,10 @@ def main():
             "dtype": "f32", "data": "synthetic", "depth_format": "16UC1" if args.u16 else "32FC1",
             "config": {"workload": "C3: %dx%d depth, synthetic PR2-like URDF (%d links with meshes, %d triangles), batch=%d concurrent streams per GPU, new joint state + camera pose every step"
                                    % (W, H, wl0.meta["links_with_geometry"], wl0.meta["triangles"], n),
-                       "streams_per_gpu": n, "poses": "host matrices" if args.host_poses else "joint positions, forward kinematics on the GPU", "mode": "two-kernel" if two else "fused", "mask_output": d_mask is not None,
-                       "parallelism": "stream-sharded x%d" % world},
+                       "streams_per_gpu": n, "poses": "host matrices" if args.host_poses else "joint positions, forward kinematics on the GPU", "mode": "two-kernel" if two else "fused", "mask_output": (not args.no_mask),
+                       "parallelism": "stream-sharded x%d" % world, "pipelines_per_gpu": P},
             "per_stream_fps": value / (n * world),
-            "kernel_ms_per_step": dict(per, note="stage breakdown from %d extra steps after the timed region (every stage bracketed by HIP events); roofline.avg_launch_ms is measured inside the timed region" % extra),
+            "kernel_ms_per_step": dict(per, note="stage breakdown from %d extra steps after the timed region: one pipeline, one batch in flight, every stage bracketed by HIP events (kernel times without another batch sharing the GPU); roofline.avg_launch_ms is measured inside the timed region, where %d pipelines overlap" % (extra, P)),
             "rasteriser": {"triangles_per_s": wl0.n_triangles() * n / (per["ms_setup"] * 1e-3) if per["ms_setup"] > 0 else None,
                            "binned_triangles_per_s": st["triangles_binned"] / (per["ms_raster"] * 1e-3) if per["ms_raster"] > 0 else None,
                            "triangles_submitted": st["triangles_submitted"], "triangles_binned": st["triangles_binned"],
@@ -205,18 +223,20 @@ def main():
                            "fragments_binned": st["fragments_binned"], "max_bin_fill": st["max_bin_fill"], "max_fragment_bin_fill": st["max_fbin_fill"], "bin_capacity": st["bin_capacity"], "regrowths": st["regrowths"]},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                          "frac": achieved / peak, "traffic": traffic, "launches_per_step": groups,
-                         "avg_launch_ms": dur_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "avg_launch_ms": dur_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "isolated": {"avg_launch_ms": per["ms_compare"] if dom == "compare_kernel" else per["ms_raster"],
+                                      "frac": (alg_bytes / ((per["ms_compare"] if dom == "compare_kernel" else per["ms_raster"]) * 1e-3) / 1e9 / peak) if per["ms_raster"] > 0 else None,
+                                      "note": "same kernel with nothing else on the GPU (extra steps after the timed region)"}},
         }
         # ---- parity spot check + CPU baseline (oracle = checker / reported baseline only) ------
         if world == 1:
             from oracle import bindings as O
             from realtime_urdf_filter_amd.filter import depth_f32_to_u16, depth_u16_to_f32
-            v_last = (args.warmup + args.steps - 1) % len(variants)
+            v_last = k_last % V
             wl = variants[v_last]
-            k_last = args.warmup + args.steps + extra - 1
-            d_masked, d_mask = d_masked_set[k_last % 2], d_mask_set[k_last % 2]
+            d_masked, d_mask = d_masked_set[k_last % n_sets], d_mask_set[k_last % n_sets]
             hm = d_masked.cpu().numpy()
-            hk = d_mask.cpu().numpy() if d_mask is not None else None
+            hk = d_mask.cpu().numpy() if (not args.no_mask) else None
             hd = d_depth[v_last].cpu().numpy()
             if args.u16:
                 hm = hm.view(np.uint16)

@@ -467,6 +467,36 @@ def test_two_batches_in_flight_and_regrowth_reruns_both():
         ctx.close()
 
 
+def test_two_contexts_on_one_gpu_interleaved():
+    """Two contexts (own HIP stream and bins each) on the same GPU, batches alternating between them with
+    nothing retired in between (bench.py --pipelines 2): kernels of the two overlap on the device and
+    both produce the reference result."""
+    import torch
+    n, W, H = 4, 320, 240
+    wls = [WL.pr2_workload(n, W, H, total_triangles=8000, first_state_seed=seed) for seed in (1000, 2000)]
+    depth = wls[0].depth_batch()
+    dev = torch.device("cuda:0")
+    d_depth = torch.from_numpy(depth).to(dev)
+    ctxs, idss, refs = [], [], []
+    for wl in wls:
+        c = R.Context(W, H, n, 0, params(wl.replace_value, wl.max_diff))
+        ids = wl.load_into(c)
+        wl.load_kinematics(c, ids)
+        wl.stage_joint_positions(c, ids)
+        refs.append(c.filter_batch(depth))
+        ctxs.append(c); idss.append(ids)
+    outs = [(torch.empty((n, H, W), dtype=torch.float32, device=dev), torch.empty((n, H, W), dtype=torch.uint8, device=dev)) for _ in range(4)]
+    torch.cuda.synchronize()
+    for k in range(4):                        # A B A B, all in flight together
+        ctxs[k % 2].filter_batch_device(n, d_depth.data_ptr(), outs[k][0].data_ptr(), outs[k][1].data_ptr())
+    for c in ctxs:
+        c.sync()
+    for k in range(4):
+        assert np.array_equal(outs[k][1].cpu().numpy(), refs[k % 2][1]) and bits_equal(outs[k][0].cpu().numpy(), refs[k % 2][0]), k
+    for c in ctxs:
+        c.close()
+
+
 def test_config_c4_720p_pr2_plus_walls():
     """BASELINE config 4 shape: 1280x720, PR2-like robot + two static wall URDFs (full-screen boxes incl.
     quirk Q1: exercises the large-triangle path), several streams."""
