@@ -68,7 +68,7 @@ struct rtuf_context {
   uint32_t bg_chunk = 0;
 
   // static geometry (device)
-  float4* d_cverts = nullptr; uint32_t* d_ctris = nullptr; Chunk* d_chunks = nullptr; Draw* d_draws = nullptr;
+  float4* d_cverts = nullptr; uint32_t* d_ctris = nullptr; uint32_t* d_corder = nullptr; Chunk* d_chunks = nullptr; Draw* d_draws = nullptr;
 
   // per-frame pose staging
   Camera* h_cams = nullptr;            // pinned [max_streams]
@@ -217,7 +217,7 @@ void rtuf_destroy(rtuf_context* c)
   }
   free_frame_buffers(c);
   auto dfree = [](auto*& p) { if (p) { hipFree(p); p = nullptr; } };
-  dfree(c->d_cverts); dfree(c->d_ctris); dfree(c->d_chunks); dfree(c->d_draws);
+  dfree(c->d_cverts); dfree(c->d_ctris); dfree(c->d_corder); dfree(c->d_chunks); dfree(c->d_draws);
   for (auto& b : c->batch) {
     for (hipEvent_t ev : b.events) hipEventDestroy(ev);
     if (b.done) hipEventDestroy(b.done);
@@ -353,26 +353,54 @@ int rtuf_finalize_models(rtuf_context* c)
   if (c->finalized) return c->fail(RTUF_ERR_STATE, "models already finalised");
   hipSetDevice(c->device);
   std::vector<float4> cverts;
-  std::vector<uint32_t> ctris;
+  std::vector<uint32_t> ctris, corder;
   std::vector<Chunk> chunks;
   std::vector<Draw> draws;
   int64_t tri_seq = 0;
   // Splits one draw's triangle list into chunks of <= kBlock triangles / <= kMaxChunkVerts vertices.
-  auto add_chunks = [&](const std::vector<float>& v, const std::vector<uint32_t>& t, uint32_t draw_id, uint32_t model) {
+  // Splits one draw's triangle list into chunks of <= kBlock triangles / <= kMaxChunkVerts vertices.
+  // Triangles are taken in Morton order of their centroids, so a chunk is a compact patch of the surface:
+  // fewer distinct vertices per chunk (each is transformed once per chunk and stream) and a tighter
+  // bounding sphere (more whole-chunk frustum culls) than the file order of a mesh gives.  The depth
+  // test's tie-break is the GL draw order, so every triangle keeps its original sequence number (corder).
+  auto add_chunks = [&](const std::vector<float>& v, const std::vector<uint32_t>& t, uint32_t draw_id, uint32_t model, bool background) {
     const uint32_t nt = (uint32_t)(t.size() / 3);
     std::vector<int32_t> local(v.size() / 3, -1);
     std::vector<uint32_t> touched;
+    std::vector<uint32_t> perm(nt);
+    for (uint32_t i = 0; i < nt; i++) perm[i] = i;
+    if (nt > (uint32_t)kBlock && !(c->params.flags & 0x8000u)) {        // (0x8000: timing experiment, file order)
+      float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+      for (size_t i = 0; i < v.size(); i++) { lo[i % 3] = std::min(lo[i % 3], v[i]); hi[i % 3] = std::max(hi[i % 3], v[i]); }
+      auto spread = [](uint32_t x) {          // 10 bits -> every third bit
+        x &= 1023u; x = (x | (x << 16)) & 0x030000ffu; x = (x | (x << 8)) & 0x0300f00fu;
+        x = (x | (x << 4)) & 0x030c30c3u; x = (x | (x << 2)) & 0x09249249u;
+        return x;
+      };
+      std::vector<uint32_t> code(nt);
+      for (uint32_t i = 0; i < nt; i++) {
+        uint32_t m = 0;
+        for (int k = 0; k < 3; k++) {
+          const float cen = (v[3 * (size_t)t[3 * (size_t)i] + k] + v[3 * (size_t)t[3 * (size_t)i + 1] + k] + v[3 * (size_t)t[3 * (size_t)i + 2] + k]) * (1.0f / 3.0f);
+          const float ext = hi[k] - lo[k];
+          const float u = ext > 0 ? (cen - lo[k]) / ext : 0.0f;
+          m |= spread((uint32_t)std::min(1023.0f, std::max(0.0f, u * 1023.0f))) << k;
+        }
+        code[i] = m;
+      }
+      std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return code[x] < code[y]; });
+    }
     uint32_t done = 0;
     while (done < nt) {
       Chunk ch{};
       ch.tri_begin = (uint32_t)ctris.size();
       ch.vert_begin = (uint32_t)cverts.size();
       ch.draw = draw_id; ch.model = model;
-      ch.order_base = (uint32_t)(tri_seq + 1);
+      ch.order_base = 0;
       touched.clear();
       uint32_t nv = 0, n = 0;
       while (done + n < nt && n < (uint32_t)kBlock) {
-        const uint32_t* ix = &t[3 * (size_t)(done + n)];
+        const uint32_t* ix = &t[3 * (size_t)perm[done + n]];
         uint32_t fresh = 0;
         for (int k = 0; k < 3; k++) {
           bool seen = local[ix[k]] >= 0;
@@ -390,6 +418,7 @@ int rtuf_finalize_models(rtuf_context* c)
           li[k] = (uint32_t)local[ix[k]];
         }
         ctris.push_back(li[0] | (li[1] << 10) | (li[2] << 20));
+        corder.push_back(background ? 0u : (uint32_t)(tri_seq + perm[done + n] + 1));
         n++;
       }
       ch.tri_count = n; ch.vert_count = nv;
@@ -413,8 +442,8 @@ int rtuf_finalize_models(rtuf_context* c)
       chunks.push_back(ch);
       for (uint32_t id : touched) local[id] = -1;
       done += n;
-      tri_seq += n;
     }
+    tri_seq += nt;
   };
   int link_base = 0;
   for (size_t mi = 0; mi < c->models.size(); mi++) {
@@ -429,7 +458,7 @@ int rtuf_finalize_models(rtuf_context* c)
         d.model = (uint32_t)mi;
         const uint32_t draw_id = (uint32_t)draws.size();
         draws.push_back(d);
-        add_chunks(hd.verts, hd.tris, draw_id, (uint32_t)mi);
+        add_chunks(hd.verts, hd.tris, draw_id, (uint32_t)mi, false);
       }
     }
     link_base += (int)m.links.size();
@@ -445,16 +474,18 @@ int rtuf_finalize_models(rtuf_context* c)
     const std::vector<float> bv = {-100.0f, -100.0f, zq, 100.0f, -100.0f, zq, 100.0f, 100.0f, zq, -100.0f, 100.0f, zq};
     const std::vector<uint32_t> bt = {0, 1, 3, 1, 2, 3};
     c->bg_chunk = (uint32_t)chunks.size();
-    add_chunks(bv, bt, (uint32_t)c->n_draws, 0);
+    add_chunks(bv, bt, (uint32_t)c->n_draws, 0, true);
   }
   c->n_chunks = (int)chunks.size();
   if (draws.empty()) draws.push_back(Draw{});
   HIP_TRY(c, hipMalloc(&c->d_cverts, cverts.size() * sizeof(float4)));
   HIP_TRY(c, hipMalloc(&c->d_ctris, ctris.size() * sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc(&c->d_corder, corder.size() * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&c->d_chunks, chunks.size() * sizeof(Chunk)));
   HIP_TRY(c, hipMalloc(&c->d_draws, draws.size() * sizeof(Draw)));
   HIP_TRY(c, hipMemcpy(c->d_cverts, cverts.data(), cverts.size() * sizeof(float4), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_ctris, ctris.data(), ctris.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_corder, corder.data(), corder.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_draws, draws.data(), draws.size() * sizeof(Draw), hipMemcpyHostToDevice));
   const int rc = alloc_frame_buffers(c);
@@ -779,7 +810,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     // clip list is per group
     if (base > 0) launch_reset_clip(c->d_counters, st);
     SetupArgs sa{};
-    sa.cverts = c->d_cverts; sa.ctris = c->d_ctris; sa.chunks = c->d_chunks; sa.mvp = c->d_mvp;
+    sa.cverts = c->d_cverts; sa.ctris = c->d_ctris; sa.corder = c->d_corder; sa.chunks = c->d_chunks; sa.mvp = c->d_mvp;
     sa.model_mask = c->d_model_mask; sa.bg_mode = c->d_bg_mode; sa.bins = c->d_bins; sa.bin_count = c->d_bin_count;
     sa.fbins = c->d_fbins; sa.fbin_count = c->d_fbin_count; sa.fcapacity = c->fcapacity;
     sa.clip_list = c->d_clip_list; sa.counters = c->d_counters; sa.group_base = base; sa.group_size = gs;

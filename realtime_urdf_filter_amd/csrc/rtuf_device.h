@@ -6,7 +6,7 @@
 //                        <= 256 distinct vertices they use                32 B / chunk
 //     cverts float4[Vc]  object-space positions, grouped per chunk        16 B / vertex
 //     ctris  u32[T]      3 x 10-bit chunk-local vertex ids                 4 B / triangle
-//                        (draw-order sequence number = chunk.order_base + index; 0 = background)
+//                        (draw-order sequence numbers in corder, parallel to ctris; 0 = background)
 //     draws  Draw[D]     link id + the glScalef/glTranslatef of the draw
 //   per frame, per stream s (slot within the batch)
 //     cams   Camera[N]   projection / camera_offset_inv / camera_tf as f64
@@ -167,6 +167,7 @@ struct PoseArgs {
 struct SetupArgs {
   const float4* cverts;          // chunk-local vertex lists (object space)
   const uint32_t* ctris;         // 3 x 10-bit chunk-local vertex ids per triangle
+  const uint32_t* corder;        // draw-order sequence number per triangle (>= 1; 0 = background quad), parallel to ctris
   const Chunk* chunks;
   const float* mvp;              // [n_streams][n_draws + 1][16]
   const uint64_t* model_mask;    // [n_streams] bit m set: stream renders model m

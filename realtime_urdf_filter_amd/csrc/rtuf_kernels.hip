@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
         if (kk < a.clip_capacity) {
           uint4* dst = reinterpret_cast<uint4*>(&a.clip_list[(size_t)shard_id * a.clip_capacity + kk]);
           dst[0] = make_uint4((uint32_t)slot, ch.draw, ch.vert_begin, packed);
-          dst[1] = make_uint4(is_bg ? 0u : ch.order_base + (uint32_t)tid, 0u, 0u, 0u);
+          dst[1] = make_uint4(a.corder[ch.tri_begin + tid], 0u, 0u, 0u);
         } else {
           shard.clip_overflow = 1u;
         }
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
                         : small_box_coverage<4>(v0, v1, v2, a.width, a.height, bx0, by0);
         if (mask) {
           z_plane(v0, v1, v2, a0, dzdx, dzdy);
-          order = is_bg ? 0u : ch.order_base + (uint32_t)t;
+          order = a.corder[ch.tri_begin + t];
           // z is monotone along x and along y (also as evaluated in float), so its minimum over the box
           // is at a corner.  Anything that may reach window z <= 0.5 needs its plane in the tile
           // kernel (exact float z): it goes out as a record instead (geometry within ~2 x near of the camera).
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
       if (have) {
         float a0, dzdx, dzdy;
         z_plane(v0, v1, v2, a0, dzdx, dzdy);
-        pk = pack_record(x0, y0, x1, y1, x2, y2, a0, dzdx, dzdy, is_bg ? 0u : ch.order_base + (uint32_t)t);
+        pk = pack_record(x0, y0, x1, y1, x2, y2, a0, dzdx, dzdy, a.corder[ch.tri_begin + t]);
         bbx = (uint32_t)bx0 | ((uint32_t)bx1 << 16);
         bby = (uint32_t)by0 | ((uint32_t)by1 << 16);
       }
