@@ -43,6 +43,7 @@ struct Kinematics {               // on-device forward kinematics of one model
   // writes h_q[q_write], so the next frame's joint states can be staged while the GPU filters
   double* h_q[kMaxInflight + 1] = {};                      // [max_streams][n_frames]
   int q_live = 0, q_write = 0;
+  int aux_uploaded_streams = 0;
   bool q_carried = true;                                    // h_q[q_write] holds everything h_q[q_live] does
   double* h_root = nullptr; double* d_root = nullptr;       // [max_streams][12]
   uint8_t* h_enabled = nullptr; uint8_t* d_enabled = nullptr;
@@ -74,15 +75,13 @@ struct rtuf_context {
   Camera* h_cams = nullptr;            // pinned [max_streams]
   double* h_link_tf = nullptr;         // pinned [max_streams][n_links][16]
   uint64_t* h_model_mask = nullptr;    // pinned [max_streams]
-  Camera* d_cams = nullptr; double* d_link_tf = nullptr; uint64_t* d_model_mask = nullptr;
-  float* d_mvp = nullptr; float* d_bg_z = nullptr; uint32_t* d_bg_mode = nullptr;
+  uint64_t* d_model_mask = nullptr;
 
   // rasteriser working set
   int group = 0;                       // in-flight streams per launch group
   uint32_t capacity = 0, fcapacity = 0, clip_capacity = 0;
-  PackedTri* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr; WorkItem* d_items = nullptr; uint32_t items_hint = 0; uint16_t* d_tile_order = nullptr;
+  PackedTri* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr; uint32_t items_hint = 0; uint16_t* d_tile_order = nullptr;
   Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
-  Counters* d_counters = nullptr;
   float* d_zsurface = nullptr;
 
   // staging for the host-pointer API
@@ -103,14 +102,24 @@ struct rtuf_context {
     hipEvent_t done = nullptr;               // recorded after that copy
     std::vector<hipEvent_t> events;          // stage timing
     std::vector<int> q_idx;                  // per model: joint-position staging buffer
+    // The batch's pose stage (uploads, forward kinematics, matrix stacks, cull) runs on a side stream and
+    // writes only buffers of its own slot, so it overlaps the raster kernels of the batch before it.
+    Camera* d_cams = nullptr; double* d_link_tf = nullptr;
+    float* d_mvp = nullptr; float* d_bg_z = nullptr; uint32_t* d_bg_mode = nullptr;
+    WorkItem* d_items = nullptr; Counters* d_counters = nullptr;
+    bool dirty_cams = true, dirty_link_tf = true;
+    int uploaded_streams = 0;
+    hipEvent_t posed = nullptr;              // recorded on the side stream after the pose stage
   };
   Batch batch[kMaxInflight];
+  hipStream_t side = nullptr;                // pose stages (see Batch)
   int oldest = 0;                            // ring index of the oldest batch in flight
   int pending = 0;                           // batches in flight
 
   // host staging areas changed since the last upload?
-  bool dirty_cams = true, dirty_link_tf = true, dirty_mask = true;
-  int uploaded_streams = 0;
+  bool dirty_mask = true;
+  int mask_uploaded_streams = 0;
+  int last_slot = 0;                         // slot of the most recently enqueued batch (debug read-back)
 
   rtuf_stats stats{};
   int timing = 0;            // 0 off, 1 every stage, 2 only around the tile (and compare) kernel
@@ -180,6 +189,7 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
   if (params) c->params = *params; else rtuf_default_params(&c->params);
   e = hipSetDevice(device_id);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
   if (e != hipSuccess) {
     snprintf(g_create_error, sizeof g_create_error, "hip init failed: %s", hipGetErrorString(e));
     delete c;
@@ -194,8 +204,9 @@ static void free_frame_buffers(rtuf_context* c)
   hipSetDevice(c->device);
   auto dfree = [](auto*& p) { if (p) { hipFree(p); p = nullptr; } };
   auto hfree = [](auto*& p) { if (p) { hipHostFree(p); p = nullptr; } };
-  dfree(c->d_cams); dfree(c->d_link_tf); dfree(c->d_model_mask); dfree(c->d_mvp); dfree(c->d_bg_z); dfree(c->d_bg_mode);
-  dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_items); dfree(c->d_tile_order); dfree(c->d_counters); dfree(c->d_zsurface);
+  dfree(c->d_model_mask);
+  for (auto& b : c->batch) { dfree(b.d_cams); dfree(b.d_link_tf); dfree(b.d_mvp); dfree(b.d_bg_z); dfree(b.d_bg_mode); dfree(b.d_items); dfree(b.d_counters); }
+  dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_tile_order); dfree(c->d_zsurface);
   dfree(c->d_depth); dfree(c->d_masked); dfree(c->d_mask);
   hfree(c->h_cams); hfree(c->h_link_tf); hfree(c->h_model_mask);
   for (auto& b : c->batch) hfree(b.h_counters);
@@ -206,6 +217,7 @@ void rtuf_destroy(rtuf_context* c)
 {
   if (!c) return;
   hipSetDevice(c->device);
+  if (c->side) hipStreamSynchronize(c->side);
   if (c->stream) hipStreamSynchronize(c->stream);
   for (HostModel& m : c->models) {
     Kinematics& k = m.kin;
@@ -221,7 +233,9 @@ void rtuf_destroy(rtuf_context* c)
   for (auto& b : c->batch) {
     for (hipEvent_t ev : b.events) hipEventDestroy(ev);
     if (b.done) hipEventDestroy(b.done);
+    if (b.posed) hipEventDestroy(b.posed);
   }
+  if (c->side) hipStreamDestroy(c->side);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -304,14 +318,19 @@ static int alloc_frame_buffers(rtuf_context* c)
     HIP_TRY(c, hipHostMalloc(&b.h_counters, sizeof(Counters)));
     if (!b.done) HIP_TRY(c, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
   }
-  HIP_TRY(c, hipMalloc(&c->d_cams, sizeof(Camera) * N));
-  HIP_TRY(c, hipMalloc(&c->d_link_tf, sizeof(double) * 16 * L * N));
   HIP_TRY(c, hipMalloc(&c->d_model_mask, sizeof(uint64_t) * N));
-  HIP_TRY(c, hipMalloc(&c->d_mvp, sizeof(float) * 16 * (size_t)(c->n_draws + 1) * N));
-  HIP_TRY(c, hipMalloc(&c->d_bg_z, sizeof(float) * N));
-  HIP_TRY(c, hipMalloc(&c->d_bg_mode, sizeof(uint32_t) * N));
-  HIP_TRY(c, hipMalloc(&c->d_counters, sizeof(Counters)));
-  HIP_TRY(c, hipMemset(c->d_counters, 0, sizeof(Counters)));
+  for (auto& b : c->batch) {
+    HIP_TRY(c, hipMalloc(&b.d_cams, sizeof(Camera) * N));
+    HIP_TRY(c, hipMalloc(&b.d_link_tf, sizeof(double) * 16 * L * N));
+    HIP_TRY(c, hipMalloc(&b.d_mvp, sizeof(float) * 16 * (size_t)(c->n_draws + 1) * N));
+    HIP_TRY(c, hipMalloc(&b.d_bg_z, sizeof(float) * N));
+    HIP_TRY(c, hipMalloc(&b.d_bg_mode, sizeof(uint32_t) * N));
+    HIP_TRY(c, hipMalloc(&b.d_counters, sizeof(Counters)));
+    HIP_TRY(c, hipMemset(b.d_counters, 0, sizeof(Counters)));
+    b.dirty_cams = b.dirty_link_tf = true; b.uploaded_streams = 0;
+    if (!b.posed) HIP_TRY(c, hipEventCreateWithFlags(&b.posed, hipEventDisableTiming));
+  }
+  c->dirty_mask = true; c->mask_uploaded_streams = 0;
   // identity defaults
   static const double I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   for (int s = 0; s < N; s++) {
@@ -340,7 +359,7 @@ static int alloc_frame_buffers(rtuf_context* c)
   HIP_TRY(c, hipMalloc(&c->d_fbin_count, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(c->d_fbin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
-  HIP_TRY(c, hipMalloc(&c->d_items, (size_t)c->n_chunks * ((G + kStreamsPerBlock - 1) / kStreamsPerBlock) * sizeof(WorkItem)));
+  for (auto& b : c->batch) HIP_TRY(c, hipMalloc(&b.d_items, (size_t)c->n_chunks * ((G + kStreamsPerBlock - 1) / kStreamsPerBlock) * sizeof(WorkItem)));
   HIP_TRY(c, hipMalloc(&c->d_tile_order, (size_t)G * tiles * sizeof(uint16_t)));
   if (c->params.flags & RTUF_FLAG_TWO_KERNEL)
     HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)G * c->width * c->height * sizeof(float)));
@@ -526,7 +545,7 @@ int rtuf_set_camera(rtuf_context* c, int stream, const double projection[16], co
   if (projection) memcpy(cam.projection, projection, sizeof cam.projection);
   if (camera_offset_inv) memcpy(cam.offset_inv, camera_offset_inv, sizeof cam.offset_inv);
   if (camera_tf) memcpy(cam.cam_tf, camera_tf, sizeof cam.cam_tf);
-  c->dirty_cams = true;
+  for (auto& b : c->batch) b.dirty_cams = true;
   return RTUF_OK;
 }
 
@@ -558,7 +577,7 @@ int rtuf_set_link_poses(rtuf_context* c, int stream, int model, const double* li
   if (n_links != (int)m.links.size()) return c->fail(RTUF_ERR_INVALID, "model %d has %d links, got %d", model, (int)m.links.size(), n_links);
   memcpy(c->h_link_tf + ((size_t)stream * c->n_links + m.link_base) * 16, link_tf, sizeof(double) * 16 * (size_t)n_links);
   if (m.kin.h_enabled && m.kin.h_enabled[stream]) { c->models[model].kin.h_enabled[stream] = 0; c->models[model].kin.dirty_aux = true; }
-  c->dirty_link_tf = true;
+  for (auto& b : c->batch) b.dirty_link_tf = true;
   return RTUF_OK;
 }
 
@@ -575,7 +594,7 @@ int rtuf_set_cameras(rtuf_context* c, int first, int n, const double* projection
     if (offset_inv) memcpy(cam.offset_inv, offset_inv + 16 * (size_t)s, sizeof cam.offset_inv);
     if (cam_tf) memcpy(cam.cam_tf, cam_tf + 16 * (size_t)s, sizeof cam.cam_tf);
   }
-  c->dirty_cams = true;
+  for (auto& b : c->batch) b.dirty_cams = true;
   return RTUF_OK;
 }
 
@@ -593,7 +612,7 @@ int rtuf_set_link_poses_batch(rtuf_context* c, int first, int n, int model, cons
            sizeof(double) * 16 * (size_t)n_links);
     if (m.kin.h_enabled && m.kin.h_enabled[first + s]) { c->models[model].kin.h_enabled[first + s] = 0; c->models[model].kin.dirty_aux = true; }
   }
-  c->dirty_link_tf = true;
+  for (auto& b : c->batch) b.dirty_link_tf = true;
   return RTUF_OK;
 }
 
@@ -708,10 +727,10 @@ int rtuf_debug_read_poses(rtuf_context* c, int n, double* link_tf_out, double* c
   hipSetDevice(c->device);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const size_t L = (size_t)std::max(c->n_links, 1);
-  if (link_tf_out) HIP_TRY(c, hipMemcpy(link_tf_out, c->d_link_tf, sizeof(double) * 16 * L * n, hipMemcpyDeviceToHost));
+  if (link_tf_out) HIP_TRY(c, hipMemcpy(link_tf_out, c->batch[c->last_slot].d_link_tf, sizeof(double) * 16 * L * n, hipMemcpyDeviceToHost));
   if (cam_tf_out) {
     std::vector<Camera> cams(n);
-    HIP_TRY(c, hipMemcpy(cams.data(), c->d_cams, sizeof(Camera) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(cams.data(), c->batch[c->last_slot].d_cams, sizeof(Camera) * n, hipMemcpyDeviceToHost));
     for (int s = 0; s < n; s++) memcpy(cam_tf_out + 16 * (size_t)s, cams[s].cam_tf, sizeof(double) * 16);
   }
   return RTUF_OK;
@@ -759,15 +778,18 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
   const size_t L = (size_t)std::max(c->n_links, 1);
   const size_t plane = (size_t)c->width * c->height;
   size_t ev = 0;
-  if (c->timing == 1) hipEventRecord(get_event(b, ev++), st);
+  hipStream_t sp = c->side;       // the pose stage of this batch: concurrent with the raster kernels of the batch before it
+  c->last_slot = (int)(&b - &c->batch[0]);
+  if (c->timing == 1) hipEventRecord(get_event(b, ev++), sp);
   // only what the host changed since the last batch crosses the bus (with on-device forward
   // kinematics that is just the joint positions below)
-  const bool more = n > c->uploaded_streams;
-  if (c->dirty_cams || more) HIP_TRY(c, hipMemcpyAsync(c->d_cams, c->h_cams, sizeof(Camera) * n, hipMemcpyHostToDevice, st));
-  if (c->dirty_link_tf || more) HIP_TRY(c, hipMemcpyAsync(c->d_link_tf, c->h_link_tf, sizeof(double) * 16 * L * n, hipMemcpyHostToDevice, st));
-  if (c->dirty_mask || more) HIP_TRY(c, hipMemcpyAsync(c->d_model_mask, c->h_model_mask, sizeof(uint64_t) * n, hipMemcpyHostToDevice, st));
-  c->dirty_cams = c->dirty_link_tf = c->dirty_mask = false;
-  c->uploaded_streams = std::max(c->uploaded_streams, n);
+  const bool more = n > b.uploaded_streams;
+  if (b.dirty_cams || more) HIP_TRY(c, hipMemcpyAsync(b.d_cams, c->h_cams, sizeof(Camera) * n, hipMemcpyHostToDevice, sp));
+  if (b.dirty_link_tf || more) HIP_TRY(c, hipMemcpyAsync(b.d_link_tf, c->h_link_tf, sizeof(double) * 16 * L * n, hipMemcpyHostToDevice, sp));
+  if (c->dirty_mask || n > c->mask_uploaded_streams) HIP_TRY(c, hipMemcpyAsync(c->d_model_mask, c->h_model_mask, sizeof(uint64_t) * n, hipMemcpyHostToDevice, sp));
+  b.dirty_cams = b.dirty_link_tf = c->dirty_mask = false;
+  b.uploaded_streams = std::max(b.uploaded_streams, n);
+  c->mask_uploaded_streams = std::max(c->mask_uploaded_streams, n);
   // on-device forward kinematics overwrites the link matrices (and camera) of the streams that use it
   for (HostModel& m : c->models) {
     Kinematics& k = m.kin;
@@ -785,45 +807,51 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
       }
       b.q_idx[mi] = k.q_live;
     }
-    if (k.dirty_aux || more) {
-      HIP_TRY(c, hipMemcpyAsync(k.d_root, k.h_root, sizeof(double) * 12 * (size_t)n, hipMemcpyHostToDevice, st));
-      HIP_TRY(c, hipMemcpyAsync(k.d_enabled, k.h_enabled, (size_t)n, hipMemcpyHostToDevice, st));
+    if (k.dirty_aux || n > k.aux_uploaded_streams) {
+      HIP_TRY(c, hipMemcpyAsync(k.d_root, k.h_root, sizeof(double) * 12 * (size_t)n, hipMemcpyHostToDevice, sp));
+      HIP_TRY(c, hipMemcpyAsync(k.d_enabled, k.h_enabled, (size_t)n, hipMemcpyHostToDevice, sp));
     }
     k.dirty_aux = false;
+    k.aux_uploaded_streams = std::max(k.aux_uploaded_streams, n);
     FkArgs fa{};
     fa.parent = k.d_parent; fa.depth = k.d_depth; fa.max_depth = k.max_depth; fa.joint_type = k.d_type; fa.joint_origin = k.d_origin; fa.joint_axis = k.d_axis;
     fa.link_frame = k.d_link_frame; fa.link_offset = k.d_link_offset; fa.q = k.h_q[b.q_idx[mi]]; fa.root_tf = k.d_root;
-    fa.enabled = k.d_enabled; fa.link_tf = c->d_link_tf; fa.cams = c->d_cams;
+    fa.enabled = k.d_enabled; fa.link_tf = b.d_link_tf; fa.cams = b.d_cams;
     fa.n_streams = n; fa.n_frames = k.n_frames; fa.n_links_model = (int)m.links.size(); fa.link_base = m.link_base;
     fa.n_links_total = (int)L; fa.camera_frame = k.camera_frame;
-    launch_fk(fa, st);
+    launch_fk(fa, sp);
   }
   PoseArgs pa{};
-  pa.cams = c->d_cams; pa.link_tf = c->d_link_tf; pa.draws = c->d_draws; pa.mvp = c->d_mvp;
-  pa.bg_z = c->d_bg_z; pa.bg_mode = c->d_bg_mode; pa.counters = c->d_counters;
+  pa.cams = b.d_cams; pa.link_tf = b.d_link_tf; pa.draws = c->d_draws; pa.mvp = b.d_mvp;
+  pa.bg_z = b.d_bg_z; pa.bg_mode = b.d_bg_mode; pa.counters = b.d_counters;
   pa.n_streams = n; pa.n_draws = c->n_draws; pa.n_links = (int)L; pa.z_far = c->params.far_plane;
   pa.width = c->width; pa.height = c->height;
-  launch_pose(pa, st);
-  if (c->timing == 1) hipEventRecord(get_event(b, ev++), st);
+  launch_pose(pa, sp);
+  if (c->timing == 1) hipEventRecord(get_event(b, ev++), sp);
   for (int base = 0; base < n; base += c->group) {
     const int gs = std::min(c->group, n - base);
     // clip list is per group
-    if (base > 0) launch_reset_clip(c->d_counters, st);
+    if (base > 0) launch_reset_clip(b.d_counters, st);
     SetupArgs sa{};
-    sa.cverts = c->d_cverts; sa.ctris = c->d_ctris; sa.corder = c->d_corder; sa.chunks = c->d_chunks; sa.mvp = c->d_mvp;
-    sa.model_mask = c->d_model_mask; sa.bg_mode = c->d_bg_mode; sa.bins = c->d_bins; sa.bin_count = c->d_bin_count;
+    sa.cverts = c->d_cverts; sa.ctris = c->d_ctris; sa.corder = c->d_corder; sa.chunks = c->d_chunks; sa.mvp = b.d_mvp;
+    sa.model_mask = c->d_model_mask; sa.bg_mode = b.d_bg_mode; sa.bins = c->d_bins; sa.bin_count = c->d_bin_count;
     sa.fbins = c->d_fbins; sa.fbin_count = c->d_fbin_count; sa.fcapacity = c->fcapacity;
-    sa.clip_list = c->d_clip_list; sa.counters = c->d_counters; sa.group_base = base; sa.group_size = gs;
+    sa.clip_list = c->d_clip_list; sa.counters = b.d_counters; sa.group_base = base; sa.group_size = gs;
     sa.n_draws = c->n_draws; sa.width = c->width; sa.height = c->height; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
     sa.capacity = c->capacity; sa.clip_capacity = c->clip_capacity; sa.bg_chunk = c->bg_chunk;
-    sa.items = c->d_items; sa.n_chunks = c->n_chunks; sa.flags = c->params.flags;
-    launch_cull(sa, st);
+    sa.items = b.d_items; sa.n_chunks = c->n_chunks; sa.flags = c->params.flags;
+    // the first group's cull belongs to the pose stage; the raster kernels wait for that stage here
+    launch_cull(sa, base == 0 ? sp : st);
+    if (base == 0) {
+      HIP_TRY(c, hipEventRecord(b.posed, sp));
+      HIP_TRY(c, hipStreamWaitEvent(st, b.posed, 0));
+    }
     launch_setup(sa, c->items_hint, st);
     launch_clip(sa, st);
     TileArgs ta{};
     ta.bins = c->d_bins; ta.bin_count = c->d_bin_count;
     ta.fbins = c->d_fbins; ta.fbin_count = c->d_fbin_count; ta.fcapacity = c->fcapacity; ta.depth = d_depth; ta.masked = d_masked; ta.mask = d_mask;
-    ta.zsurface = c->d_zsurface; ta.bg_z = c->d_bg_z; ta.bg_mode = c->d_bg_mode; ta.counters = c->d_counters;
+    ta.zsurface = c->d_zsurface; ta.bg_z = b.d_bg_z; ta.bg_mode = b.d_bg_mode; ta.counters = b.d_counters;
     ta.group_base = base; ta.group_size = gs; ta.width = c->width; ta.height = c->height;
     ta.tiles_x = c->tiles_x; ta.tiles_y = c->tiles_y; ta.capacity = c->capacity; ta.flags = c->params.flags;
     ta.z_near = c->params.near_plane; ta.z_far = c->params.far_plane;
@@ -845,7 +873,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     }
     if (c->timing == 1 || (c->timing == 2 && two)) hipEventRecord(get_event(b, ev++), st);
   }
-  HIP_TRY(c, hipMemcpyAsync(b.h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(b.h_counters, b.d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
   HIP_TRY(c, hipEventRecord(b.done, st));
   HIP_TRY(c, hipGetLastError());
   return RTUF_OK;
