@@ -205,6 +205,19 @@ def main():
                 traffic = tj["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
+        # the kernels are VALU-issue-bound: wave64 VALU instructions per launch from the
+        # committed SQ counters of this same command, against the machine's issue peak
+        valu = None
+        try:
+            vj = json.load(open(os.path.join(ROOT, "profiles", "valu_counts.json")))
+            cnt = vj["wave64_valu_instructions_per_launch"].get(dom)
+            if (cnt and vj["streams"] == n and vj["width"] == W and vj["height"] == H and vj["triangles"] == wl0.meta["triangles"]
+                    and (not args.no_mask) and not args.u16 and dur_ms > 0):
+                g = cnt / (dur_ms * 1e-3) / 1e9
+                valu = {"wave64_instructions_per_launch": cnt, "achieved_G_per_s": g, "peak_G_per_s": vj["peak_G_per_s"], "frac": g / vj["peak_G_per_s"],
+                        "note": "instruction count from profiles/valu_counts.json (rocprofv3 SQ_INSTS_VALU), duration live; peak = " + vj["peak_note"]}
+        except Exception:
+            valu = None
         out = {
             "metric": "filtered depth frames/sec (640x480, PR2 URDF)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -224,6 +237,7 @@ def main():
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                          "frac": achieved / peak, "traffic": traffic, "launches_per_step": groups,
                          "avg_launch_ms": dur_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "valu_issue": valu,
                          "isolated": {"avg_launch_ms": per["ms_compare"] if dom == "compare_kernel" else per["ms_raster"],
                                       "frac": (alg_bytes / ((per["ms_compare"] if dom == "compare_kernel" else per["ms_raster"]) * 1e-3) / 1e9 / peak) if per["ms_raster"] > 0 else None,
                                       "note": "same kernel with nothing else on the GPU (extra steps after the timed region)"}},

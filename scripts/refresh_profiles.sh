@@ -46,4 +46,20 @@ json.dump({"kernel": "tile_kernel<fused>", "mode": "fused", "streams": 256, "wid
            "source": "profiles/%s_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, python bench.py --steps 20 --warmup 3)" % sys.argv[3]},
           open(sys.argv[2], "w"), indent=1)
 PY
+bash scripts/pmc_kernels.sh SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES > $out/pmc_sq.body 2>&1
+{ echo "# rocprofv3 --kernel-trace --pmc <4 SQ counters per pass>, command: python bench.py --steps 10 --warmup 2 --cpu-seconds 0 --check-frames 0 (scripts/pmc_kernels.sh)"
+  echo "# values are per launch, averaged over the launches of the run (MI355X, gfx950, ROCm 7.2); SQ_INSTS_* count wave64 instructions"
+  cat $out/pmc_sq.body; } > $out/${tag}_pmc_sq.txt; rm -f $out/pmc_sq.body
+python - "$out/${tag}_pmc_sq.txt" "$out/valu_counts.json" "$tag" <<'PY'
+import json, re, sys
+txt = open(sys.argv[1]).read()
+def grab(kernel):
+    m = re.search(re.escape(kernel) + r"[^\n]*\n(?:\s+SQ_\w+\s+avg [0-9.e+]+[^\n]*\n)*?\s+SQ_INSTS_VALU\s+avg ([0-9.e+]+)", txt)
+    return float(m.group(1)) if m else None
+json.dump({"streams": 256, "width": 640, "height": 480, "triangles": 250388,
+           "wave64_valu_instructions_per_launch": {"tile_kernel<fused>": grab("tile_kernel<false, false>"), "setup_kernel": grab("setup_kernel<false>")},
+           "peak_G_per_s": 614.4, "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
+           "source": "profiles/%s_pmc_sq.txt (rocprofv3 --pmc SQ_INSTS_VALU ..., python bench.py --steps 10 --warmup 2)" % sys.argv[3]},
+          open(sys.argv[2], "w"), indent=1)
+PY
 ls -la $out; tail -c 600 $out/${tag}_bench.json; cat $out/${tag}_kernel_stats.csv | head -12; cat $out/hbm_traffic.json
