@@ -415,7 +415,6 @@ int rtuf_finalize_models(rtuf_context* c)
       ch.tri_begin = (uint32_t)ctris.size();
       ch.vert_begin = (uint32_t)cverts.size();
       ch.draw = draw_id; ch.model = model;
-      ch.order_base = 0;
       touched.clear();
       uint32_t nv = 0, n = 0;
       while (done + n < nt && n < (uint32_t)kBlock) {

@@ -79,7 +79,7 @@ struct Chunk {                  // <= 256 consecutive triangles of one draw + th
   uint32_t vert_count;          // <= kMaxChunkVerts
   uint32_t draw;
   uint32_t model;
-  uint32_t order_base;          // draw-order sequence number of the chunk's first triangle (>= 1)
+  uint32_t reserved;
   uint32_t pad;
   float center[3];              // object-space bounding sphere of the chunk's vertices
   float radius;
@@ -132,7 +132,7 @@ struct alignas(32) WorkItem {
   uint32_t chunk;
   uint32_t tri_begin;           // copies of the chunk's fields: the set-up workgroup needs no Chunk load
   uint32_t vert_begin;
-  uint32_t order_base;
+  uint32_t reserved;
   uint32_t draw;
   uint16_t tri_count, vert_count;
   uint16_t slot[4];

@@ -861,7 +861,7 @@ __global__ __launch_bounds__(kBlock) void cull_kernel(SetupArgs a)
     if ((uint32_t)tid < n_items) {
       WorkItem it;
       it.chunk = (uint32_t)chunk_id;
-      it.tri_begin = ch.tri_begin; it.vert_begin = ch.vert_begin; it.order_base = ch.order_base; it.draw = ch.draw;
+      it.tri_begin = ch.tri_begin; it.vert_begin = ch.vert_begin; it.reserved = 0; it.draw = ch.draw;
       it.tri_count = (uint16_t)ch.tri_count; it.vert_count = (uint16_t)ch.vert_count;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -905,9 +905,8 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
   if (tid == 4) s_ntiny = 0;
   if (tid == 5) s_nsmall = 0;
   // the item carries the chunk's ranges, so the geometry loads depend on it alone
-  struct { uint32_t tri_begin, vert_begin, order_base, draw, tri_count, vert_count; } ch;
+  struct { uint32_t tri_begin, vert_begin, draw, tri_count, vert_count; } ch;
   uint32_t slots01, slots23;
-  int chunk_id;
   {
     const uint4* src = reinterpret_cast<const uint4*>(&a.items[item_id]);
     uint4 w0 = src[0], w1 = src[1];
@@ -917,12 +916,11 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
     w0.z = __builtin_amdgcn_readfirstlane(w0.z); w0.w = __builtin_amdgcn_readfirstlane(w0.w);
     w1.x = __builtin_amdgcn_readfirstlane(w1.x); w1.y = __builtin_amdgcn_readfirstlane(w1.y);
     w1.z = __builtin_amdgcn_readfirstlane(w1.z); w1.w = __builtin_amdgcn_readfirstlane(w1.w);
-    chunk_id = (int)w0.x; ch.tri_begin = w0.y; ch.vert_begin = w0.z; ch.order_base = w0.w;
+    ch.tri_begin = w0.y; ch.vert_begin = w0.z;          // (w0.x: chunk id, not needed here)
     ch.draw = w1.x; ch.tri_count = w1.y & 0xffffu; ch.vert_count = w1.y >> 16;
     slots01 = w1.z; slots23 = w1.w;
   }
   auto item_slot = [&](int k) { return (int)(((k < 2 ? slots01 : slots23) >> (16 * (k & 1))) & 0xffffu); };
-  const bool is_bg = (uint32_t)chunk_id == a.bg_chunk;
 
   float4 pv = make_float4(0, 0, 0, 1);
   const bool have_vert = tid < (int)ch.vert_count;
