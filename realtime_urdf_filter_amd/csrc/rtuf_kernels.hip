@@ -1495,10 +1495,16 @@ __device__ __forceinline__ ShadeConsts shade_consts(float z_near, float z_far, f
   return k;
 }
 
-__device__ __forceinline__ float shade(float sensor, float z, const ShadeConsts& k, bool& filt)
+// sensor > shade_threshold(z)  <=>  should_filter of include/shaders/urdf_filter.frag:22-23
+__device__ __forceinline__ float shade_threshold(float z, const ShadeConsts& k)
 {
   const float virt = __fdiv_rn(k.num, __fsub_rn(z, k.off));
-  filt = sensor > __fsub_rn(virt, k.max_diff);
+  return __fsub_rn(virt, k.max_diff);
+}
+
+__device__ __forceinline__ float shade(float sensor, float z, const ShadeConsts& k, bool& filt)
+{
+  filt = sensor > shade_threshold(z, k);
   return filt ? k.replace_value : sensor;
 }
 
@@ -1552,6 +1558,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
   const float bgz = a.bg_z[stream];
   const unsigned long long bgkey = analytic_bg ? (((unsigned long long)z24_of(bgz) << 32)) : kNoFragment;
   const ShadeConsts sc = shade_consts(a.z_near, a.z_far, a.max_diff, a.replace_value);
+  const float thr_bg = shade_threshold(bgz, sc);
 
   const uint32_t count = a.bin_count[bin], fcount = a.fbin_count[bin];
   // The sensor pixels this lane will resolve are requested before anything else so that their HBM
@@ -1609,68 +1616,82 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
     }
   }
 
-  // resolve: kLanesPerRow lanes x 4 pixels per tile row, kRowsPerPass rows per pass
-#pragma unroll
-  for (int ps = 0; ps < kPasses; ps++) {
-    const int r_ly = r_ly0 + ps * kRowsPerPass, r_py = y_base + r_ly;
-    const bool r_valid = r_ly < kTileH && r_py < a.height && r_px < a.width;
-    const size_t gofs = ((size_t)stream * a.height + r_py) * a.width + r_px;
-    const float4 sens = sens_p[ps];
-    if (!r_valid) continue;
-    const int ly = r_ly, lx = r_lx, px = r_px, py = r_py;
-    float z[4];
-    bool frag[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const unsigned long long k = empty ? bgkey : keys[ly * kTileW + lx + j];
-      frag[j] = true;
-      if (k & kResolvedBit) z[j] = __uint_as_float((uint32_t)k);
-      else if (k == bgkey) { z[j] = bgz; frag[j] = analytic_bg; }
-      else z[j] = __fmul_rn((float)((uint32_t)(k >> 32) + 1u), 5.9604644775390625e-08f);
-    }
+  // resolve: kLanesPerRow lanes x 4 pixels per tile row, kRowsPerPass rows per pass.  `finish` turns four
+  // window depths (or "nothing drawn") and their compare thresholds into the outputs.
+  auto finish = [&](int ps, const float (&z)[4], const float (&thr)[4], const bool (&frag)[4]) {
+    const int r_ly = r_ly0 + ps * kRowsPerPass, py = y_base + r_ly, px = r_px;
+    const size_t gofs = ((size_t)stream * a.height + py) * a.width + px;
     const int nvalid = min(4, a.width - px);
     if (TWO_KERNEL) {
       const size_t zofs = ((size_t)slot * a.height + py) * a.width + px;
       // "no fragment" (only without background quad) is encoded as NaN
+      float zz[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) if (!frag[j]) z[j] = __uint_as_float(0x7fc00000u);
-      if (vec) *reinterpret_cast<float4*>(a.zsurface + zofs) = make_float4(z[0], z[1], z[2], z[3]);
-      else for (int j = 0; j < nvalid; j++) a.zsurface[zofs + j] = z[j];
+      for (int j = 0; j < 4; j++) zz[j] = frag[j] ? z[j] : __uint_as_float(0x7fc00000u);
+      if (vec) *reinterpret_cast<float4*>(a.zsurface + zofs) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+      else for (int j = 0; j < nvalid; j++) a.zsurface[zofs + j] = zz[j];
+      return;
+    }
+    float s[4];
+    if (vec) {
+      s[0] = sens_p[ps].x; s[1] = sens_p[ps].y; s[2] = sens_p[ps].z; s[3] = sens_p[ps].w;
     } else {
-      float s[4];
-      if (vec) {
-        s[0] = sens.x; s[1] = sens.y; s[2] = sens.z; s[3] = sens.w;
-      } else {
-        for (int j = 0; j < 4; j++)
-          s[j] = j < nvalid ? (U16 ? u16_to_metres(reinterpret_cast<const uint16_t*>(a.depth)[gofs + j]) : a.depth[gofs + j]) : 0.0f;
-      }
-      float o[4];
-      uint32_t mbits = 0;
+      for (int j = 0; j < 4; j++)
+        s[j] = j < nvalid ? (U16 ? u16_to_metres(reinterpret_cast<const uint16_t*>(a.depth)[gofs + j]) : a.depth[gofs + j]) : 0.0f;
+    }
+    float o[4];
+    uint32_t mbits = 0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        bool f;
-        o[j] = shade(s[j], z[j], sc, f);
-        if (!frag[j]) { o[j] = 0.0f; f = false; }     // GL clear colour
-        if (f) mbits |= 0xffu << (8 * j);
-      }
-      if (vec) {
-        if (U16) {
-          ushort4 q;
-          q.x = (unsigned short)metres_to_u16(o[0]); q.y = (unsigned short)metres_to_u16(o[1]);
-          q.z = (unsigned short)metres_to_u16(o[2]); q.w = (unsigned short)metres_to_u16(o[3]);
-          *reinterpret_cast<ushort4*>(reinterpret_cast<uint16_t*>(a.masked) + gofs) = q;
-        } else {
-          *reinterpret_cast<float4*>(a.masked + gofs) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-        if (a.mask) *reinterpret_cast<uint32_t*>(a.mask + gofs) = mbits;
+    for (int j = 0; j < 4; j++) {
+      bool f = s[j] > thr[j];
+      o[j] = f ? sc.replace_value : s[j];
+      if (!frag[j]) { o[j] = 0.0f; f = false; }     // GL clear colour
+      if (f) mbits |= 0xffu << (8 * j);
+    }
+    if (vec) {
+      if (U16) {
+        ushort4 q;
+        q.x = (unsigned short)metres_to_u16(o[0]); q.y = (unsigned short)metres_to_u16(o[1]);
+        q.z = (unsigned short)metres_to_u16(o[2]); q.w = (unsigned short)metres_to_u16(o[3]);
+        *reinterpret_cast<ushort4*>(reinterpret_cast<uint16_t*>(a.masked) + gofs) = q;
       } else {
-        for (int j = 0; j < nvalid; j++) {
-          if (U16) reinterpret_cast<uint16_t*>(a.masked)[gofs + j] = (uint16_t)metres_to_u16(o[j]);
-          else a.masked[gofs + j] = o[j];
-          if (a.mask) a.mask[gofs + j] = (uint8_t)(mbits >> (8 * j));
-        }
+        *reinterpret_cast<float4*>(a.masked + gofs) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+      if (a.mask) *reinterpret_cast<uint32_t*>(a.mask + gofs) = mbits;
+    } else {
+      for (int j = 0; j < nvalid; j++) {
+        if (U16) reinterpret_cast<uint16_t*>(a.masked)[gofs + j] = (uint16_t)metres_to_u16(o[j]);
+        else a.masked[gofs + j] = o[j];
+        if (a.mask) a.mask[gofs + j] = (uint8_t)(mbits >> (8 * j));
       }
     }
+  };
+  // Most pixels of a frame see only the background plane, whose depth is one value per stream: its compare
+  // threshold (one IEEE division) is computed once per lane.  Same operations on the same values as per pixel.
+  const float bg_z4[4] = {bgz, bgz, bgz, bgz}, bg_thr4[4] = {thr_bg, thr_bg, thr_bg, thr_bg};
+  const bool bg_frag4[4] = {analytic_bg, analytic_bg, analytic_bg, analytic_bg};
+#pragma unroll
+  for (int ps = 0; ps < kPasses; ps++) {
+    const int r_ly = r_ly0 + ps * kRowsPerPass;
+    if (!(r_ly < kTileH && y_base + r_ly < a.height && r_px < a.width)) continue;
+    if (empty) {                                   // tile without geometry: a streaming compare against the plane
+      finish(ps, bg_z4, bg_thr4, bg_frag4);
+      continue;
+    }
+    float z[4], thr[4];
+    bool frag[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const unsigned long long k = keys[r_ly * kTileW + r_lx + j];
+      frag[j] = true;
+      thr[j] = thr_bg;
+      if (k == bgkey) { z[j] = bgz; frag[j] = analytic_bg; }
+      else {                                        // the per-pixel division only runs where something was drawn
+        z[j] = (k & kResolvedBit) ? __uint_as_float((uint32_t)k) : __fmul_rn((float)((uint32_t)(k >> 32) + 1u), 5.9604644775390625e-08f);
+        if (!TWO_KERNEL) thr[j] = shade_threshold(z[j], sc);
+      }
+    }
+    finish(ps, z, thr, frag);
   }
 }
 
