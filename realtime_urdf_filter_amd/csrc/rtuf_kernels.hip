@@ -424,9 +424,10 @@ __device__ __forceinline__ bool orient_and_bound(Win& v0, Win& v1, const Win& v2
   // vertices of unclipped triangles lie inside the frustum: snapped values are in [-128, 2048*256+128].
   // The (value-preserving) 21-bit sign extension tells the compiler so, which turns the 64-bit
   // products below into full-rate 24-bit multiplies.
-  x0 = sext21(snap(v0.x)); y0 = sext21(snap(v0.y));
-  x1 = sext21(snap(v1.x)); y1 = sext21(snap(v1.y));
-  x2 = sext21(snap(v2.x)); y2 = sext21(snap(v2.y));
+  // x0..y2 come in as the snapped coordinates of phase 1 (s_snap): snap(v.x), snap(v.y)
+  x0 = sext21(x0); y0 = sext21(y0);
+  x1 = sext21(x1); y1 = sext21(y1);
+  x2 = sext21(x2); y2 = sext21(y2);
   const int minx = min(x0, min(x1, x2)), maxx = max(x0, max(x1, x2));
   const int miny = min(y0, min(y1, y2)), maxy = max(y0, max(y1, y2));
   bx0 = max((minx + 255) >> 8, 0); bx1 = min((maxx - 1) >> 8, width - 1);
@@ -650,17 +651,16 @@ __device__ __forceinline__ bool inside(const TriRec& r, int px, int py)
   return (e0 > 0) & (e1 > 0) & (e2 > 0);
 }
 
-// Set-up + coverage of a triangle whose pixel-centre bounding box is at most N x N (N <= 4): returns
+// Set-up + coverage of a triangle (snapped coordinates x0..y2 from phase 1) whose pixel-centre bounding box
+// is at most N x N (N <= 4): returns
 // the covered box positions (bit dy*4+dx, origin bx0,by0) and orients v0/v1 like orient_and_bound.
 // All integer work is done relative to the box origin, where vertex coordinates are within
 // [-256, (N+1)*256] and every product fits 32 bits (full-rate 24-bit multiplies); the values are
 // the same integers the absolute 64-bit form yields.  Straight-line: all N*N candidates per lane.
 template <int N>
-__device__ __forceinline__ uint32_t small_box_coverage(Win& v0, Win& v1, const Win& v2, int width, int height, int& bx0, int& by0)
+__device__ __forceinline__ uint32_t small_box_coverage(Win& v0, Win& v1, const Win& v2, int x0, int y0, int x1, int y1, int x2, int y2,
+                                                       int width, int height, int& bx0, int& by0)
 {
-  int x0 = snap(v0.x), y0 = snap(v0.y);
-  int x1 = snap(v1.x), y1 = snap(v1.y);
-  int x2 = snap(v2.x), y2 = snap(v2.y);
   const int minx = min(x0, min(x1, x2)), maxx = max(x0, max(x1, x2));
   const int miny = min(y0, min(y1, y2)), maxy = max(y0, max(y1, y2));
   bx0 = max((minx + 255) >> 8, 0);
@@ -1059,8 +1059,9 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
         v0.x = s_win[k][0][j0]; v0.y = s_win[k][1][j0]; v0.z = s_win[k][2][j0];
         v1.x = s_win[k][0][j1]; v1.y = s_win[k][1][j1]; v1.z = s_win[k][2][j1];
         v2.x = s_win[k][0][j2]; v2.y = s_win[k][1][j2]; v2.z = s_win[k][2][j2];
-        mask = cls == 0 ? small_box_coverage<2>(v0, v1, v2, a.width, a.height, bx0, by0)
-                        : small_box_coverage<4>(v0, v1, v2, a.width, a.height, bx0, by0);
+        const int2 q0 = s_snap[k][j0], q1 = s_snap[k][j1], q2 = s_snap[k][j2];      // snapped in phase 1 (y << 8 | clip mask)
+        mask = cls == 0 ? small_box_coverage<2>(v0, v1, v2, q0.x, q0.y >> 8, q1.x, q1.y >> 8, q2.x, q2.y >> 8, a.width, a.height, bx0, by0)
+                        : small_box_coverage<4>(v0, v1, v2, q0.x, q0.y >> 8, q1.x, q1.y >> 8, q2.x, q2.y >> 8, a.width, a.height, bx0, by0);
         if (mask) {
           z_plane(v0, v1, v2, a0, dzdx, dzdy);
           order = a.corder[ch.tri_begin + t];
@@ -1104,7 +1105,8 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
       v0.x = s_win[k][0][j0]; v0.y = s_win[k][1][j0]; v0.z = s_win[k][2][j0];
       v1.x = s_win[k][0][j1]; v1.y = s_win[k][1][j1]; v1.z = s_win[k][2][j1];
       v2.x = s_win[k][0][j2]; v2.y = s_win[k][1][j2]; v2.z = s_win[k][2][j2];
-      int x0, y0, x1, y1, x2, y2, bx0, bx1, by0, by1;
+      const int2 q0 = s_snap[k][j0], q1 = s_snap[k][j1], q2 = s_snap[k][j2];        // snapped in phase 1 (y << 8 | clip mask)
+      int x0 = q0.x, y0 = q0.y >> 8, x1 = q1.x, y1 = q1.y >> 8, x2 = q2.x, y2 = q2.y >> 8, bx0, bx1, by0, by1;
       have = orient_and_bound(v0, v1, v2, a.width, a.height, x0, y0, x1, y1, x2, y2, bx0, bx1, by0, by1);
       if (have) {
         float a0, dzdx, dzdy;
