@@ -1320,7 +1320,7 @@ __device__ __forceinline__ void fragment(unsigned long long* keys, const TriRec&
 
 
 #ifndef RTUF_SMALL_AREA
-#define RTUF_SMALL_AREA 32
+#define RTUF_SMALL_AREA 48
 #endif
 #ifndef RTUF_QUARTER_AREA
 #define RTUF_QUARTER_AREA 256
