@@ -56,12 +56,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # RTUF_BENCH_BACKEND=gloo RTUF_BENCH_DEVICE=0: rehearsal of the multi-rank path on a box with one GPU
+    # (all ranks share device 0, collectives over gloo); the real run is one rank per GPU over RCCL
+    backend = os.environ.get("RTUF_BENCH_BACKEND", "nccl")
+    local_rank = int(os.environ.get("RTUF_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
 
     n, W, H = args.streams, args.width, args.height
@@ -168,7 +175,7 @@ def main():
     breakdown = {key: v / extra for key, v in acc.items()}
     k_last = k0 + args.steps + extra - 1
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = ctx.stats()
