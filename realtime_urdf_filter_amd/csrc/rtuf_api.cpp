@@ -110,6 +110,7 @@ struct rtuf_context {
     bool dirty_cams = true, dirty_link_tf = true;
     int uploaded_streams = 0;
     hipEvent_t posed = nullptr;              // recorded on the side stream after the pose stage
+    uint32_t setup_grid = 0xffffffffu;       // work items the set-up launch covered (single-group batches)
   };
   Batch batch[kMaxInflight];
   hipStream_t side = nullptr;                // pose stages (see Batch)
@@ -845,7 +846,12 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
       HIP_TRY(c, hipEventRecord(b.posed, sp));
       HIP_TRY(c, hipStreamWaitEvent(st, b.posed, 0));
     }
-    launch_setup(sa, c->items_hint, st);
+    // a batch of one group reads its work-list length back with the counters: instead of sweeping the
+    // part of the list beyond the (estimated) grid with a second launch, it is run again if the estimate
+    // was too small (retire_oldest); batches of several groups reuse the counter, so they sweep
+    const bool single_group = n <= c->group;
+    const uint32_t grid = launch_setup(sa, c->items_hint, !single_group, st);
+    b.setup_grid = single_group ? grid : 0xffffffffu;
     launch_clip(sa, st);
     TileArgs ta{};
     ta.bins = c->d_bins; ta.bin_count = c->d_bin_count;
@@ -904,7 +910,9 @@ static int retire_oldest(rtuf_context* c)
     c->stats.max_fbin_fill = k.max_fbin_fill;
     const bool bin_over = k.max_bin_fill > c->capacity || k.max_fbin_fill > c->fcapacity;
     const bool clip_over = k.clip_overflow != 0;
-    if (!bin_over && !clip_over) {
+    const bool list_over = b.h_counters->work.n_items > b.setup_grid;     // the set-up grid was sized too small
+    if (list_over) c->stats.regrowths++;
+    if (!bin_over && !clip_over && !list_over) {
       if (c->timing == 1 && b.events.size() >= 2) {
         // events: [start, pose_end, (setup_end, tile_end, compare_end) per group ...]
         float ms = 0;

@@ -242,7 +242,7 @@ struct FkArgs {
 void launch_fk(const FkArgs& a, hipStream_t st);
 void launch_pose(const PoseArgs& a, hipStream_t st);
 void launch_cull(const SetupArgs& a, hipStream_t st);
-void launch_setup(const SetupArgs& a, uint32_t items_hint, hipStream_t st);
+uint32_t launch_setup(const SetupArgs& a, uint32_t items_hint, bool sweep, hipStream_t st);    // returns the main grid size
 void launch_clip(const SetupArgs& a, hipStream_t st);
 void launch_reset_clip(Counters* c, hipStream_t st);
 void launch_order(const TileArgs& a, hipStream_t st);

@@ -1785,18 +1785,20 @@ void launch_cull(const SetupArgs& a, hipStream_t st)
 {
   hipLaunchKernelGGL(cull_kernel, dim3(a.n_chunks), dim3(kBlock), 0, st, a);
 }
-void launch_setup(const SetupArgs& a, uint32_t items_hint, hipStream_t st)
+uint32_t launch_setup(const SetupArgs& a, uint32_t items_hint, bool sweep, hipStream_t st)
 {
   // The work-list length is only known on the device.  The grid is sized from the previous batch's
-  // length (+25 %; robot and camera move little between frames) and the workgroups stride over the
-  // list, so a wrong guess costs time, never correctness.  Without a hint: the worst case (every
-  // chunk visible in every stream).  Neighbouring workgroups take neighbouring items, which share
-  // a chunk's geometry in L2.
+  // length (+25 %; robot and camera move little between frames).  Without a hint: the worst case (every
+  // chunk visible in every stream).  Neighbouring workgroups take neighbouring items, which share a
+  // chunk's geometry in L2.  If the list may be longer than the grid, either a small strided launch of
+  // the same code sweeps the remainder (sweep = true), or the caller compares the returned grid size
+  // with the list length it reads back and runs the batch again (a wrong guess costs time, never pixels).
   const long long worst = (long long)a.n_chunks * ((a.group_size + kStreamsPerBlock - 1) / kStreamsPerBlock);
   long long grid = worst;
   if (items_hint) grid = std::min<long long>(worst, (long long)items_hint + items_hint / 4 + 64);
   hipLaunchKernelGGL(setup_kernel<false>, dim3((unsigned)grid), dim3(kBlock), 0, st, a, 0u);
-  if (grid < worst) hipLaunchKernelGGL(setup_kernel<true>, dim3(256), dim3(kBlock), 0, st, a, (uint32_t)grid);
+  if (grid < worst && sweep) hipLaunchKernelGGL(setup_kernel<true>, dim3(256), dim3(kBlock), 0, st, a, (uint32_t)grid);
+  return (uint32_t)grid;
 }
 void launch_clip(const SetupArgs& a, hipStream_t st)
 {

@@ -497,6 +497,33 @@ def test_two_contexts_on_one_gpu_interleaved():
         c.close()
 
 
+def test_work_list_longer_than_the_estimated_setup_grid():
+    """The set-up grid of a batch is sized from the previous batch's work-list length.  Robot out of view
+    (short list), then in view (a list many times longer than the estimate): the batch is detected as
+    under-covered when its counters are read back, run again, and matches the oracle."""
+    n, W, H = 9, 320, 240
+    wl = WL.pr2_workload(n, W, H, total_triangles=20000)
+    ctx = R.Context(W, H, n, 0, params(wl.replace_value, wl.max_diff))
+    ids = wl.load_into(ctx)
+    depth = wl.depth_batch()
+    wl.stage(ctx, ids)
+    away = wl.cam_tf.copy().reshape(n, 4, 4)
+    away[1:, 3, :3] += np.array([0.0, 0.0, 50.0])         # GL column-major: translation in the last row; 50 m off
+    ctx.set_cameras(0, wl.projection, wl.offset_inv, away.reshape(n, 16))
+    ctx.filter_batch(depth)                                # only stream 0 sees the robot: one work item per visible chunk
+    few = ctx.stats()["triangles_binned"]
+    ctx.set_cameras(0, wl.projection, wl.offset_inv, wl.cam_tf)
+    before = ctx.stats()["regrowths"]
+    masked, mask = ctx.filter_batch(depth)                 # all nine do: three items per chunk
+    st = ctx.stats()
+    assert st["regrowths"] == before + 1 and st["triangles_binned"] > 4 * max(few, 1)
+    for s in range(n):
+        om, ok = O.filter_frame(depth[s], wl.projection[s], wl.oracle_draws(s), wl.offset_inv[s], wl.cam_tf[s],
+                                max_diff=wl.max_diff, replace_value=wl.replace_value)
+        assert (ok != mask[s]).sum() == 0 and bits_equal(om, masked[s])
+    ctx.close()
+
+
 def test_config_c4_720p_pr2_plus_walls():
     """BASELINE config 4 shape: 1280x720, PR2-like robot + two static wall URDFs (full-screen boxes incl.
     quirk Q1: exercises the large-triangle path), several streams."""
