@@ -80,7 +80,7 @@ struct rtuf_context {
   // rasteriser working set
   int group = 0;                       // in-flight streams per launch group
   uint32_t capacity = 0, fcapacity = 0, clip_capacity = 0;
-  PackedTri* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr; uint32_t items_hint = 0; uint16_t* d_tile_order = nullptr;
+  PackedTri* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr; uint32_t items_hint = 0;
   Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
   float* d_zsurface = nullptr;
 
@@ -207,7 +207,7 @@ static void free_frame_buffers(rtuf_context* c)
   auto hfree = [](auto*& p) { if (p) { hipHostFree(p); p = nullptr; } };
   dfree(c->d_model_mask);
   for (auto& b : c->batch) { dfree(b.d_cams); dfree(b.d_link_tf); dfree(b.d_mvp); dfree(b.d_bg_z); dfree(b.d_bg_mode); dfree(b.d_items); dfree(b.d_counters); }
-  dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_tile_order); dfree(c->d_zsurface);
+  dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_zsurface);
   dfree(c->d_depth); dfree(c->d_masked); dfree(c->d_mask);
   hfree(c->h_cams); hfree(c->h_link_tf); hfree(c->h_model_mask);
   for (auto& b : c->batch) hfree(b.h_counters);
@@ -361,7 +361,6 @@ static int alloc_frame_buffers(rtuf_context* c)
   HIP_TRY(c, hipMemset(c->d_fbin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
   for (auto& b : c->batch) HIP_TRY(c, hipMalloc(&b.d_items, (size_t)c->n_chunks * ((G + kStreamsPerBlock - 1) / kStreamsPerBlock) * sizeof(WorkItem)));
-  HIP_TRY(c, hipMalloc(&c->d_tile_order, (size_t)G * tiles * sizeof(uint16_t)));
   if (c->params.flags & RTUF_FLAG_TWO_KERNEL)
     HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)G * c->width * c->height * sizeof(float)));
   return RTUF_OK;
@@ -862,8 +861,6 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     ta.z_near = c->params.near_plane; ta.z_far = c->params.far_plane;
     ta.max_diff = c->params.depth_distance_threshold; ta.replace_value = c->params.filter_replace_value;
     ta.io_u16 = io_u16 ? 1 : 0;
-    ta.tile_order = (c->params.flags & 0x4000u) ? nullptr : c->d_tile_order;      // (0x4000: timing experiment, natural order)
-    if (ta.tile_order) launch_order(ta, st);
     if (c->timing) hipEventRecord(get_event(b, ev++), st);
     launch_tile(ta, two, st);
     if (c->timing) hipEventRecord(get_event(b, ev++), st);

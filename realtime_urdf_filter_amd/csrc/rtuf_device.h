@@ -204,7 +204,6 @@ struct TileArgs {
   const float* bg_z;             // [n]
   const uint32_t* bg_mode;       // [n]
   Counters* counters;
-  uint16_t* tile_order;          // [G][tiles]  each stream's tiles, fullest bins first (order_kernel); nullptr = natural order
   int group_base, group_size;
   int width, height, tiles_x, tiles_y;
   uint32_t capacity;
@@ -245,7 +244,6 @@ void launch_cull(const SetupArgs& a, hipStream_t st);
 uint32_t launch_setup(const SetupArgs& a, uint32_t items_hint, bool sweep, hipStream_t st);    // returns the main grid size
 void launch_clip(const SetupArgs& a, hipStream_t st);
 void launch_reset_clip(Counters* c, hipStream_t st);
-void launch_order(const TileArgs& a, hipStream_t st);
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st);   // a.io_u16 selects the 16UC1 variant
 void launch_compare(const CompareArgs& a, hipStream_t st);
 

@@ -1510,31 +1510,6 @@ __device__ __forceinline__ float shade(float sensor, float z, const ShadeConsts&
   return filt ? k.replace_value : sensor;
 }
 
-// order_kernel: one workgroup per stream; counting sort of the stream's tiles by how full their bins are
-// (16 classes of log2(records + fragments / 8)), fullest first.  The tile kernel starts all streams'
-// fullest tiles first and the empty ones (most of the frame, pure streaming) last: a workgroup that
-// needs 50 us no longer starts in the final microseconds of a 400 us launch.
-__global__ __launch_bounds__(kBlock) void order_kernel(TileArgs a)
-{
-  __shared__ uint32_t s_hist[16], s_start[16];
-  const int tid = threadIdx.x, slot = blockIdx.x;
-  const int tiles = a.tiles_x * a.tiles_y;
-  if (tid < 16) s_hist[tid] = 0;
-  __syncthreads();
-  auto cls_of = [&](int t) {
-    const uint32_t w = a.bin_count[slot * tiles + t] + (a.fbin_count[slot * tiles + t] >> 3);
-    return 15 - min(15, 32 - (int)__clz((int)w));           // class 0 = fullest
-  };
-  for (int t = tid; t < tiles; t += kBlock) atomicAdd(&s_hist[cls_of(t)], 1u);
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t run = 0;
-    for (int c = 0; c < 16; c++) { s_start[c] = run; run += s_hist[c]; }
-  }
-  __syncthreads();
-  for (int t = tid; t < tiles; t += kBlock) a.tile_order[(size_t)slot * tiles + atomicAdd(&s_start[cls_of(t)], 1u)] = (uint16_t)t;
-}
-
 template <bool TWO_KERNEL, bool U16>
 __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 {
@@ -1542,16 +1517,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 
   const int tid = threadIdx.x;
   const int tiles = a.tiles_x * a.tiles_y;
-  // workgroup -> (rank, stream): rank r of every stream before rank r + 1 of any (see order_kernel)
-  int slot, tile;
-  if (a.tile_order) {
-    const int r = blockIdx.x / a.group_size;
-    slot = blockIdx.x - r * a.group_size;
-    tile = (int)a.tile_order[(size_t)slot * tiles + r];
-  } else {
-    slot = blockIdx.x / tiles; tile = blockIdx.x - slot * tiles;
-  }
-  const int bin = slot * tiles + tile;
+  const int bin = blockIdx.x;
+  const int slot = bin / tiles, tile = bin - slot * tiles;
   const int stream = a.group_base + slot;
   const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
   const int x_base = txi * kTileW, y_base = tyi * kTileH;
@@ -1804,10 +1771,6 @@ void launch_clip(const SetupArgs& a, hipStream_t st)
 {
   // the item count lives on the device: fixed grid, grid-stride loop
   hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * 64), dim3(kClipBlock), 0, st, a);
-}
-void launch_order(const TileArgs& a, hipStream_t st)
-{
-  hipLaunchKernelGGL(order_kernel, dim3(a.group_size), dim3(kBlock), 0, st, a);
 }
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st)
 {
