@@ -530,22 +530,29 @@ __device__ __forceinline__ void store_record(PackedTri* dst, const PackedTri& r)
   d[0] = s[0]; d[1] = s[1];
 }
 
-// Appends the record to every tile bin its bounding box touches (one lane, plain atomics):
-// used by the rare clip path.
+// Appends the record to the (at most kCoopTiles = 4) tile bins its bounding box touches: one lane, plain
+// atomics, used by the clip path.  All slot reservations are issued before the first one is waited for
+// (the clip kernel runs at low occupancy, so a serial atomic round trip per tile would be its critical path).
 __device__ __forceinline__ uint32_t emit_record(const SetupArgs& a, int slot, const TriRec& r, const PackedTri& pk)
 {
   const int tx0 = (int)(r.bbx & 0xffff) / kTileW, tx1 = (int)(r.bbx >> 16) / kTileW;
   const int ty0 = (int)(r.bby & 0xffff) / kTileH, ty1 = (int)(r.bby >> 16) / kTileH;
   const int tiles = a.tiles_x * a.tiles_y;
-  uint32_t n = 0;
-  for (int ty = ty0; ty <= ty1; ty++)
-    for (int tx = tx0; tx <= tx1; tx++) {
-      const size_t bin = (size_t)slot * tiles + (size_t)ty * a.tiles_x + tx;
-      const uint32_t pos = atomicAdd(&a.bin_count[bin], 1u);
-      if (pos < a.capacity) store_record(a.bins + bin * a.capacity + pos, pk);
-      n++;
-    }
-  return n;
+  const int tw = tx1 - tx0 + 1, ntile = tw * (ty1 - ty0 + 1);
+  int bin[4];
+  uint32_t pos[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    // t -> (row, column) of the touched tile block without a division: tw is 1..4, ntile <= 4
+    const int row = (tw == 1) ? t : (tw == 2 ? (t >> 1) : 0), col = t - row * tw;
+    bin[t] = slot * tiles + (ty0 + row) * a.tiles_x + tx0 + col;
+    pos[t] = 0xffffffffu;
+    if (t < ntile) pos[t] = atomicAdd(&a.bin_count[bin[t]], 1u);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+    if (t < ntile && pos[t] < a.capacity) store_record(a.bins + (size_t)bin[t] * a.capacity + pos[t], pk);
+  return (uint32_t)ntile;
 }
 
 // Records whose bounding box touches more than kCoopTiles tiles (the robot's own arm in front of
@@ -1192,6 +1199,7 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
   }
   unsigned long long inl = 0ull | (1ull << 5) | (2ull << 10), outl = 0;
   int nv = valid ? 3 : 0;
+  if (a.flags & 0x200000u) nv = 0;      // timing experiment: loads and vertex transform only
   unsigned clipmask = ormask;
   bool bad = false;
   while (clipmask && nv >= 3 && !bad) {
@@ -1241,6 +1249,7 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
     nv = outc;
   }
   if (bad || nv < 3) nv = 0;           // (all lanes stay for the cooperative emission below)
+  if (a.flags & 0x100000u) nv = 0;      // timing experiment: clip only, emit nothing
   // window coordinates: shaded (original) vertices and clipper-made ones go through different
   // viewport arithmetic (viewport_vs / viewport_clip)
   auto window_of = [&](int idx) {
@@ -1266,11 +1275,14 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
       const int tw = (int)(r.bbx >> 16) / kTileW - (int)(r.bbx & 0xffff) / kTileW + 1;
       const int th = (int)(r.bby >> 16) / kTileH - (int)(r.bby & 0xffff) / kTileH + 1;
       big = tw * th > kCoopTiles;
-      if (!big) entries += emit_record(a, slot, r, pk);
+      if (!big && !(a.flags & 0x800000u)) entries += emit_record(a, slot, r, pk);      // (0x800000: timing experiment)
     }
-    if (__ballot(big)) entries += emit_big_records_wave(a, slot, big, r.bbx, r.bby, pk);
+    if (__ballot(big) && !(a.flags & 0x400000u)) entries += emit_big_records_wave(a, slot, big, r.bbx, r.bby, pk);      // (0x400000: timing experiment)
   }
-  if (binned) {
+  // statistics: one atomic pair per wave (per-lane atomics on a shard's counters serialise at one L2
+  // atomic unit -- that alone used to be three quarters of this kernel's time)
+  for (int off = 32; off > 0; off >>= 1) { binned += __shfl_down(binned, off); entries += __shfl_down(entries, off); }
+  if ((threadIdx.x & 63) == 0 && binned) {
     atomicAdd(&a.counters->shard[shard_id].tris_binned, (unsigned long long)binned);
     atomicAdd(&a.counters->shard[shard_id].bin_entries, (unsigned long long)entries);
   }

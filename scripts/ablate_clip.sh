@@ -1,0 +1,6 @@
+export TMPDIR=/tmp
+root=$PWD
+for f in ${FLAGS:-0 0x100000 0x200000}; do
+cd /tmp; rm -rf /tmp/rp; rocprofv3 --kernel-trace --output-format csv -d /tmp/rp -o t -- python $root/bench.py --steps 10 --warmup 2 --cpu-seconds 0 --check-frames 0 --debug-flags $f > /dev/null 2>&1
+cd $root; echo -n "flags $f: "; python scripts/prof_summary.py $(find /tmp/rp -name '*kernel_trace.csv' | head -1) | grep clip_kernel
+done
