@@ -111,7 +111,10 @@ struct alignas(16) ClipItem {   // one triangle that crosses a frustum plane; se
 // Device-side statistics / overflow detection.  One hot word would serialise every workgroup at
 // a single L2 atomic unit (~12 ns per atomic), so everything is sharded over kCounterShards
 // cache-line-sized slots that the host sums after the batch.
-constexpr int kCounterShards = 64;
+#ifndef RTUF_COUNTER_SHARDS
+#define RTUF_COUNTER_SHARDS 64
+#endif
+constexpr int kCounterShards = RTUF_COUNTER_SHARDS;
 struct alignas(128) CounterShard {
   unsigned long long tris_binned;
   unsigned long long bin_entries;

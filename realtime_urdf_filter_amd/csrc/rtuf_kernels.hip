@@ -530,31 +530,6 @@ __device__ __forceinline__ void store_record(PackedTri* dst, const PackedTri& r)
   d[0] = s[0]; d[1] = s[1];
 }
 
-// Appends the record to the (at most kCoopTiles = 4) tile bins its bounding box touches: one lane, plain
-// atomics, used by the clip path.  All slot reservations are issued before the first one is waited for
-// (the clip kernel runs at low occupancy, so a serial atomic round trip per tile would be its critical path).
-__device__ __forceinline__ uint32_t emit_record(const SetupArgs& a, int slot, const TriRec& r, const PackedTri& pk)
-{
-  const int tx0 = (int)(r.bbx & 0xffff) / kTileW, tx1 = (int)(r.bbx >> 16) / kTileW;
-  const int ty0 = (int)(r.bby & 0xffff) / kTileH, ty1 = (int)(r.bby >> 16) / kTileH;
-  const int tiles = a.tiles_x * a.tiles_y;
-  const int tw = tx1 - tx0 + 1, ntile = tw * (ty1 - ty0 + 1);
-  int bin[4];
-  uint32_t pos[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    // t -> (row, column) of the touched tile block without a division: tw is 1..4, ntile <= 4
-    const int row = (tw == 1) ? t : (tw == 2 ? (t >> 1) : 0), col = t - row * tw;
-    bin[t] = slot * tiles + (ty0 + row) * a.tiles_x + tx0 + col;
-    pos[t] = 0xffffffffu;
-    if (t < ntile) pos[t] = atomicAdd(&a.bin_count[bin[t]], 1u);
-  }
-#pragma unroll
-  for (int t = 0; t < 4; t++)
-    if (t < ntile && pos[t] < a.capacity) store_record(a.bins + (size_t)bin[t] * a.capacity + pos[t], pk);
-  return (uint32_t)ntile;
-}
-
 // Records whose bounding box touches more than kCoopTiles tiles (the robot's own arm in front of
 // the camera, clipped near-plane triangles) are appended cooperatively: one triangle at a time is
 // broadcast to the wave and the 64 lanes take one tile each, so a 7x7-tile triangle costs one
@@ -1260,24 +1235,21 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
   Win w0, wprev;
   if (nv) { w0 = window_of(list_get(inl, 0)); wprev = window_of(list_get(inl, 1)); }
   uint32_t binned = 0, entries = 0;
+  // the polygon as a fan (v[i-1], v[i], v[0]); the wave appends its records together (emit_record_wave):
+  // the clipped triangles of a stream pile up in the few tiles along the frustum planes, and one
+  // reservation per wave and bin instead of one per lane keeps the atomics off each other's cache lines
   for (int i = 2; __ballot(i < nv); i++) {
     bool have = false;
     TriRec r;
     PackedTri pk;
+    r.bbx = r.bby = 0;
     if (i < nv) {
       const Win wi = window_of(list_get(inl, i));
       have = make_record(wprev, wi, w0, order, a.width, a.height, r, pk);
       wprev = wi;
     }
-    bool big = false;
-    if (have) {
-      binned++;
-      const int tw = (int)(r.bbx >> 16) / kTileW - (int)(r.bbx & 0xffff) / kTileW + 1;
-      const int th = (int)(r.bby >> 16) / kTileH - (int)(r.bby & 0xffff) / kTileH + 1;
-      big = tw * th > kCoopTiles;
-      if (!big && !(a.flags & 0x800000u)) entries += emit_record(a, slot, r, pk);      // (0x800000: timing experiment)
-    }
-    if (__ballot(big) && !(a.flags & 0x400000u)) entries += emit_big_records_wave(a, slot, big, r.bbx, r.bby, pk);      // (0x400000: timing experiment)
+    binned += have ? 1u : 0u;
+    if (__ballot(have) && !(a.flags & 0x800000u)) entries += emit_record_wave(a, slot, have, r.bbx, r.bby, pk);      // (0x800000: timing experiment)
   }
   // statistics: one atomic pair per wave (per-lane atomics on a shard's counters serialise at one L2
   // atomic unit -- that alone used to be three quarters of this kernel's time)
@@ -1735,7 +1707,7 @@ __global__ __launch_bounds__(kBlock) void compare_kernel(CompareArgs a)
 // earlier groups stays in the statistics through clip_total)
 __global__ void reset_clip_kernel(Counters* c)
 {
-  const int i = threadIdx.x;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < kCounterShards) c->shard[i].clip_count = 0;
   if (i == kCounterShards) c->work.n_items = 0;
 }
@@ -1743,7 +1715,7 @@ __global__ void reset_clip_kernel(Counters* c)
 // host-callable launchers ---------------------------------------------------------------
 void launch_reset_clip(Counters* c, hipStream_t st)
 {
-  hipLaunchKernelGGL(reset_clip_kernel, dim3(1), dim3(2 * kCounterShards), 0, st, c);
+  hipLaunchKernelGGL(reset_clip_kernel, dim3(2), dim3(kCounterShards), 0, st, c);
 }
 void launch_fk(const FkArgs& a, hipStream_t st)
 {
@@ -1782,7 +1754,7 @@ uint32_t launch_setup(const SetupArgs& a, uint32_t items_hint, bool sweep, hipSt
 void launch_clip(const SetupArgs& a, hipStream_t st)
 {
   // the item count lives on the device: fixed grid, grid-stride loop
-  hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * 64), dim3(kClipBlock), 0, st, a);
+  hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * (4096 / kCounterShards > 0 ? 4096 / kCounterShards : 1)), dim3(kClipBlock), 0, st, a);
 }
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st)
 {
