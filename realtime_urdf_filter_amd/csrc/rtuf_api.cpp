@@ -875,7 +875,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     }
     if (c->timing == 1 || (c->timing == 2 && two)) hipEventRecord(get_event(b, ev++), st);
   }
-  HIP_TRY(c, hipMemcpyAsync(b.h_counters, b.d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  launch_publish_counters(b.d_counters, b.h_counters, st);
   HIP_TRY(c, hipEventRecord(b.done, st));
   HIP_TRY(c, hipGetLastError());
   return RTUF_OK;

@@ -247,6 +247,7 @@ void launch_cull(const SetupArgs& a, hipStream_t st);
 uint32_t launch_setup(const SetupArgs& a, uint32_t items_hint, bool sweep, hipStream_t st);    // returns the main grid size
 void launch_clip(const SetupArgs& a, hipStream_t st);
 void launch_reset_clip(Counters* c, hipStream_t st);
+void launch_publish_counters(const Counters* src, Counters* host_dst, hipStream_t st);
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st);   // a.io_u16 selects the 16UC1 variant
 void launch_compare(const CompareArgs& a, hipStream_t st);
 

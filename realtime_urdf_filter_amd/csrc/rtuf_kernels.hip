@@ -1705,6 +1705,15 @@ __global__ __launch_bounds__(kBlock) void compare_kernel(CompareArgs a)
 
 // clip-list counters are per in-flight group: reset between groups of one batch (clip_count of
 // earlier groups stays in the statistics through clip_total)
+// The batch's counters go to pinned host memory with plain stores from a one-workgroup kernel: a
+// hipMemcpyAsync of 8 KB costs a blit launch plus ~10 us of copy-engine set-up on the stream.
+__global__ void publish_counters_kernel(const Counters* __restrict__ src, Counters* __restrict__ host_dst)
+{
+  const uint4* s = reinterpret_cast<const uint4*>(src);
+  uint4* d = reinterpret_cast<uint4*>(host_dst);
+  for (int i = threadIdx.x; i < (int)(sizeof(Counters) / 16); i += blockDim.x) d[i] = s[i];
+}
+
 __global__ void reset_clip_kernel(Counters* c)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1713,6 +1722,10 @@ __global__ void reset_clip_kernel(Counters* c)
 }
 
 // host-callable launchers ---------------------------------------------------------------
+void launch_publish_counters(const Counters* src, Counters* host_dst, hipStream_t st)
+{
+  hipLaunchKernelGGL(publish_counters_kernel, dim3(1), dim3(256), 0, st, src, host_dst);
+}
 void launch_reset_clip(Counters* c, hipStream_t st)
 {
   hipLaunchKernelGGL(reset_clip_kernel, dim3(2), dim3(kCounterShards), 0, st, c);
