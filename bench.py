@@ -148,7 +148,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     for c in ctxs:
-        c.enable_timing(2)       # (re)starts the library's per-batch event sums: tile (and compare) kernel only
+        c.enable_timing(3)       # (re)starts the library's event sums: tile (and compare) kernel, every fourth batch (an event costs ~5 us of stream time)
     stage_into(k0 % P, k0)
     t0 = time.perf_counter()
     for k in range(k0, k0 + args.steps):
@@ -159,9 +159,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     sts = [c.stats() for c in ctxs]
-    assert sum(st["timed_batches"] for st in sts) == args.steps, ([st["timed_batches"] for st in sts], args.steps)
-    raster_ms = sum(st["sum_ms_raster"] for st in sts) / max(args.steps, 1)
-    compare_ms = sum(st["sum_ms_compare"] for st in sts) / max(args.steps, 1)
+    timed = sum(st["timed_batches"] for st in sts)
+    assert timed >= 1 and timed >= args.steps // 4, ([st["timed_batches"] for st in sts], args.steps)
+    raster_ms = sum(st["sum_ms_raster"] for st in sts) / timed
+    compare_ms = sum(st["sum_ms_compare"] for st in sts) / timed
     # stage-by-stage breakdown: a few extra steps on one pipeline, one batch in flight, every stage bracketed
     # by events, outside the timed region (kernel times without another batch sharing the GPU)
     ctx.enable_timing(1)
@@ -243,7 +244,7 @@ def main():
                            "fragments_binned": st["fragments_binned"], "max_bin_fill": st["max_bin_fill"], "max_fragment_bin_fill": st["max_fbin_fill"], "bin_capacity": st["bin_capacity"], "regrowths": st["regrowths"]},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                          "frac": achieved / peak, "traffic": traffic, "launches_per_step": groups,
-                         "avg_launch_ms": dur_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": dur_ms, "timed_launches": timed, "algorithmic_bytes_per_launch": alg_bytes,
                          "valu_issue": valu,
                          "isolated": {"avg_launch_ms": per["ms_compare"] if dom == "compare_kernel" else per["ms_raster"],
                                       "frac": (alg_bytes / ((per["ms_compare"] if dom == "compare_kernel" else per["ms_raster"]) * 1e-3) / 1e9 / peak) if per["ms_raster"] > 0 else None,

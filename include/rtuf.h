@@ -215,7 +215,8 @@ typedef struct {
 int rtuf_get_stats(rtuf_context *ctx, rtuf_stats *out);
 /* Per-kernel HIP-event timing (off by default: every event costs a few microseconds of stream
  * time).  on = 1: every stage (ms_pose, ms_setup, ms_raster, ms_compare, ms_total);  on = 2: only
- * around the tile kernel (and the compare kernel in two-kernel mode): ms_raster / ms_compare. */
+ * around the tile kernel (and the compare kernel in two-kernel mode): ms_raster / ms_compare;
+ * on = 3: as 2, but only every fourth batch is timed (timed_batches and the sums count those). */
 int rtuf_enable_timing(rtuf_context *ctx, int on);
 
 /* Debug / test access: copy the z-surface of the last batch (float window z of the winning

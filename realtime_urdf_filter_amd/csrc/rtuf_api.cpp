@@ -111,6 +111,7 @@ struct rtuf_context {
     int uploaded_streams = 0;
     hipEvent_t posed = nullptr;              // recorded on the side stream after the pose stage
     uint32_t setup_grid = 0xffffffffu;       // work items the set-up launch covered (single-group batches)
+    int timing = 0;                          // event timing of this batch: 0 none, 1 every stage, 2 tile/compare kernel only
   };
   Batch batch[kMaxInflight];
   hipStream_t side = nullptr;                // pose stages (see Batch)
@@ -123,7 +124,8 @@ struct rtuf_context {
   int last_slot = 0;                         // slot of the most recently enqueued batch (debug read-back)
 
   rtuf_stats stats{};
-  int timing = 0;            // 0 off, 1 every stage, 2 only around the tile (and compare) kernel
+  int timing = 0;            // 0 off, 1 every stage, 2 only around the tile (and compare) kernel, 3 = 2 on every fourth batch
+  uint32_t timing_seq = 0;
   double acc_ms[5] = {0, 0, 0, 0, 0};     // sums of ms_pose .. ms_total over the timed batches
   uint64_t acc_batches = 0;
 
@@ -777,9 +779,13 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
   const size_t L = (size_t)std::max(c->n_links, 1);
   const size_t plane = (size_t)c->width * c->height;
   size_t ev = 0;
+  if (!rerun) {
+    // mode 3 = mode 2 on every fourth batch only (each event costs ~5 us of stream time)
+    b.timing = c->timing == 3 ? ((c->timing_seq++ & 3u) == 0 ? 2 : 0) : c->timing;
+  }
   hipStream_t sp = c->side;       // the pose stage of this batch: concurrent with the raster kernels of the batch before it
   c->last_slot = (int)(&b - &c->batch[0]);
-  if (c->timing == 1) hipEventRecord(get_event(b, ev++), sp);
+  if (b.timing == 1) hipEventRecord(get_event(b, ev++), sp);
   // only what the host changed since the last batch crosses the bus (with on-device forward
   // kinematics that is just the joint positions below)
   const bool more = n > b.uploaded_streams;
@@ -826,7 +832,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
   pa.n_streams = n; pa.n_draws = c->n_draws; pa.n_links = (int)L; pa.z_far = c->params.far_plane;
   pa.width = c->width; pa.height = c->height;
   launch_pose(pa, sp);
-  if (c->timing == 1) hipEventRecord(get_event(b, ev++), sp);
+  if (b.timing == 1) hipEventRecord(get_event(b, ev++), sp);
   for (int base = 0; base < n; base += c->group) {
     const int gs = std::min(c->group, n - base);
     // clip list is per group
@@ -861,9 +867,9 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     ta.z_near = c->params.near_plane; ta.z_far = c->params.far_plane;
     ta.max_diff = c->params.depth_distance_threshold; ta.replace_value = c->params.filter_replace_value;
     ta.io_u16 = io_u16 ? 1 : 0;
-    if (c->timing) hipEventRecord(get_event(b, ev++), st);
+    if (b.timing) hipEventRecord(get_event(b, ev++), st);
     launch_tile(ta, two, st);
-    if (c->timing) hipEventRecord(get_event(b, ev++), st);
+    if (b.timing) hipEventRecord(get_event(b, ev++), st);
     if (two) {
       CompareArgs ca{};
       ca.depth = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_depth) + (size_t)base * plane * esz); ca.zsurface = c->d_zsurface;
@@ -873,7 +879,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
       ca.z_near = ta.z_near; ca.z_far = ta.z_far; ca.max_diff = ta.max_diff; ca.replace_value = ta.replace_value;
       launch_compare(ca, st);
     }
-    if (c->timing == 1 || (c->timing == 2 && two)) hipEventRecord(get_event(b, ev++), st);
+    if (b.timing == 1 || (b.timing == 2 && two)) hipEventRecord(get_event(b, ev++), st);
   }
   launch_publish_counters(b.d_counters, b.h_counters, st);
   HIP_TRY(c, hipEventRecord(b.done, st));
@@ -910,7 +916,7 @@ static int retire_oldest(rtuf_context* c)
     const bool list_over = b.h_counters->work.n_items > b.setup_grid;     // the set-up grid was sized too small
     if (list_over) c->stats.regrowths++;
     if (!bin_over && !clip_over && !list_over) {
-      if (c->timing == 1 && b.events.size() >= 2) {
+      if (b.timing == 1 && b.events.size() >= 2) {
         // events: [start, pose_end, (setup_end, tile_end, compare_end) per group ...]
         float ms = 0;
         c->stats.ms_pose = c->stats.ms_setup = c->stats.ms_raster = c->stats.ms_compare = 0;
@@ -923,7 +929,7 @@ static int retire_oldest(rtuf_context* c)
           e += 3;
         }
         hipEventElapsedTime(&ms, b.events[0], b.events[e]); c->stats.ms_total = ms;
-      } else if (c->timing == 2 && b.events.size() >= 2) {
+      } else if (b.timing == 2 && b.events.size() >= 2) {
         // events: (tile_begin, tile_end[, compare_end]) per group
         const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
         float ms = 0;
@@ -935,7 +941,7 @@ static int retire_oldest(rtuf_context* c)
           e += two ? 3 : 2;
         }
       }
-      if (c->timing) {
+      if (b.timing) {
         c->acc_ms[0] += c->stats.ms_pose; c->acc_ms[1] += c->stats.ms_setup; c->acc_ms[2] += c->stats.ms_raster;
         c->acc_ms[3] += c->stats.ms_compare; c->acc_ms[4] += c->stats.ms_total;
         c->acc_batches++;
@@ -1115,7 +1121,8 @@ int rtuf_get_stats(rtuf_context* c, rtuf_stats* out)
 int rtuf_enable_timing(rtuf_context* c, int on)
 {
   if (!c) return RTUF_ERR_INVALID;
-  c->timing = on < 0 ? 0 : (on > 2 ? 1 : on);
+  c->timing = on < 0 ? 0 : (on > 3 ? 1 : on);
+  c->timing_seq = 0;
   for (double& v : c->acc_ms) v = 0;
   c->acc_batches = 0;
   return RTUF_OK;
