@@ -356,8 +356,8 @@ static int alloc_frame_buffers(rtuf_context* c)
   c->clip_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 8192 / kCounterShards, 1024), (size_t)1 << 22);   // per shard
   c->fcapacity = std::max<uint32_t>(4 * cap, 1024);   // 8-byte fragments of all boxes up to 4x4 pixel centres
   HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(PackedTri)));
-  HIP_TRY(c, hipMalloc(&c->d_bin_count, (size_t)G * tiles * sizeof(uint32_t)));
-  HIP_TRY(c, hipMemset(c->d_bin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc(&c->d_bin_count, (size_t)G * tiles * 2 * sizeof(uint32_t)));      // (front, back) fill per bin
+  HIP_TRY(c, hipMemset(c->d_bin_count, 0, (size_t)G * tiles * 2 * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&c->d_fbins, (size_t)G * tiles * c->fcapacity * sizeof(Frag)));
   HIP_TRY(c, hipMalloc(&c->d_fbin_count, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(c->d_fbin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
@@ -964,7 +964,7 @@ static int retire_oldest(rtuf_context* c)
       c->stats.regrowths++;
     }
     const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
-    HIP_TRY(c, hipMemsetAsync(c->d_bin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_bin_count, 0, (size_t)c->group * tiles * 2 * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_fbin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->stream));
     for (int i = 0; i < c->pending; i++) {
       const int rc = enqueue_batch(c, c->batch[(c->oldest + i) % kMaxInflight], true);

@@ -176,7 +176,7 @@ struct SetupArgs {
   const uint64_t* model_mask;    // [n_streams] bit m set: stream renders model m
   const uint32_t* bg_mode;       // [n_streams]
   PackedTri* bins;               // [G][tiles][capacity]   triangles with a bounding box > 2x2 px
-  uint32_t* bin_count;           // [G][tiles]
+  uint32_t* bin_count;           // [G][tiles][2]  records binned from the front (small boxes) and from the back of the bin
   Frag* fbins;                   // [G][tiles][fcapacity]  covered pixels of the tiny triangles
   uint32_t* fbin_count;          // [G][tiles]
   uint32_t fcapacity;
@@ -196,7 +196,7 @@ struct SetupArgs {
 
 struct TileArgs {
   const PackedTri* bins;
-  uint32_t* bin_count;           // reset to 0 by this kernel after use
+  uint32_t* bin_count;           // [G][tiles][2], reset to 0 by this kernel after use
   const Frag* fbins;
   uint32_t* fbin_count;          // reset to 0 by this kernel after use
   uint32_t fcapacity;

@@ -535,6 +535,10 @@ __device__ __forceinline__ void store_record(PackedTri* dst, const PackedTri& r)
 // broadcast to the wave and the 64 lanes take one tile each, so a 7x7-tile triangle costs one
 // atomic round trip instead of 49 serial ones in a single lane.
 constexpr int kCoopTiles = 4;
+#ifndef RTUF_FRONT_AREA
+#define RTUF_FRONT_AREA 16
+#endif
+constexpr int kFrontArea = RTUF_FRONT_AREA;      // boxes up to this many pixel centres are binned from the front of a bin
 __device__ __forceinline__ uint32_t emit_big_records_wave(const SetupArgs& a, int slot, bool big, uint32_t bbx, uint32_t bby,
                                                           const PackedTri& pk)
 {
@@ -560,8 +564,8 @@ __device__ __forceinline__ uint32_t emit_big_records_wave(const SetupArgs& a, in
     for (int k = lane; k < ntile; k += 64) {
       const int row = k / tw, tx = tx0 + k - row * tw;
       const int bin = __mul24(qslot, tiles) + __mul24(ty0 + row, a.tiles_x) + tx;
-      const uint32_t pos = atomicAdd(&a.bin_count[bin], 1u);
-      if (pos < a.capacity) store_record(a.bins + (size_t)bin * a.capacity + pos, q);
+      const uint32_t pos = atomicAdd(&a.bin_count[2 * bin + 1], 1u);          // many-tile records are large: back of the bin
+      if (pos < a.capacity) store_record(a.bins + (size_t)bin * a.capacity + (a.capacity - 1u - pos), q);
     }
     if (lane == src) n += (uint32_t)ntile;
   }
@@ -583,6 +587,10 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slo
   }
   const int tiles = a.tiles_x * a.tiles_y;
   uint32_t n = 0;
+  // Two size classes per bin: records with a box of at most kFrontArea pixel centres fill the bin from
+  // the front, larger ones from the back, so the tile kernel's waves get boxes of similar size (its
+  // lane-per-triangle walk runs as long as the largest box in the wave).
+  const int cls = ((int)(bbx >> 16) - (int)(bbx & 0xffff) + 1) * ((int)(bby >> 16) - (int)(bby & 0xffff) + 1) > kFrontArea ? 1 : 0;
   const bool big = have && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kCoopTiles;
   if (__ballot(big)) n += emit_big_records_wave(a, slot, big, bbx, bby, pk);
   have = have && !big;
@@ -591,7 +599,7 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slo
     const bool act = have && ty <= ty1;
     unsigned long long pending = __ballot(act);
     if (!pending) break;
-    const int bin = act ? __mul24(slot, tiles) + __mul24(ty, a.tiles_x) + tx : -1;
+    const int bin = act ? 2 * (__mul24(slot, tiles) + __mul24(ty, a.tiles_x) + tx) + cls : -1;      // (bin, class) = one counter
     if (++tx > tx1) { tx = tx0; ty++; }
     unsigned long long mymask = 0;
     int myleader = lane;
@@ -607,7 +615,7 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slo
     base = __shfl(base, myleader);
     if (act) {
       const uint32_t pos = base + (uint32_t)__popcll(mymask & ((1ull << lane) - 1ull));
-      if (pos < a.capacity) store_record(a.bins + (size_t)bin * a.capacity + pos, pk);
+      if (pos < a.capacity) store_record(a.bins + (size_t)(bin >> 1) * a.capacity + (cls ? a.capacity - 1u - pos : pos), pk);
       n++;
     }
   }
@@ -1329,17 +1337,18 @@ __device__ __forceinline__ TriRec broadcast_record(const TriRec& r, int src_lane
 // 8x8 stamps for anything larger.
 template <int MODE>
 __device__ __forceinline__ void raster_bin(unsigned long long* keys, const PackedTri* recs, uint32_t n,
-                                           int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, int dbg_skip = 0)
+                                           int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, uint32_t n_front, uint32_t capacity, int dbg_skip = 0)
 {
   const int lane = tid & 63;
   for (uint32_t base = 0; base < n; base += kTileThreads) {
     const uint32_t i = base + tid;
     const bool have = i < n;
+    const uint32_t ri = i < n_front ? i : capacity - 1u - (i - n_front);      // small boxes from the front, larger ones from the back
     TriRec r;
     int lx0 = 0, lx1 = -1, ly0 = 0, ly1 = -1;
     if (have) {
       PackedTri pk;
-      const uint4* src = reinterpret_cast<const uint4*>(recs + i);
+      const uint4* src = reinterpret_cast<const uint4*>(recs + ri);
       uint4* dst = reinterpret_cast<uint4*>(&pk);
       dst[0] = src[0]; dst[1] = src[1];
       r = unpack_record(pk, width, height);
@@ -1513,7 +1522,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
   const ShadeConsts sc = shade_consts(a.z_near, a.z_far, a.max_diff, a.replace_value);
   const float thr_bg = shade_threshold(bgz, sc);
 
-  const uint32_t count = a.bin_count[bin], fcount = a.fbin_count[bin];
+  const uint32_t count_front = a.bin_count[2 * bin], count_back = a.bin_count[2 * bin + 1], fcount = a.fbin_count[bin];
+  const uint32_t count = count_front + count_back;
   // The sensor pixels this lane will resolve are requested before anything else so that their HBM
   // latency overlaps the bin-counter round trip and all of the rasterisation.
   constexpr int kLanesPerRow = kTileW / 4, kRowsPerPass = kTileThreads / kLanesPerRow;
@@ -1537,7 +1547,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
       }
     }
   }
-  const uint32_t n = min(count, a.capacity), nf = min(fcount, a.fcapacity);
+  // (an over-full bin is detected from the counters and the batch run again; until then stay inside the array)
+  const uint32_t n_front = min(count_front, a.capacity), n = n_front + min(count_back, a.capacity - n_front), nf = min(fcount, a.fcapacity);
   const PackedTri* recs = a.bins + (size_t)bin * a.capacity;
   const unsigned long long* frags = reinterpret_cast<const unsigned long long*>(a.fbins) + (size_t)bin * a.fcapacity;
   // flags bits 8.. are timing experiments only (wrong results): 0x100 skip rasterisation, 0x200 skip pixel loops
@@ -1546,13 +1557,14 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
     for (int i = tid; i < kTileW * kTileH; i += kTileThreads) keys[i] = bgkey;
     __syncthreads();
     if (tid == 0) {
-      a.bin_count[bin] = 0;                 // ready for the next batch
+      a.bin_count[2 * bin] = 0;             // ready for the next batch
+      a.bin_count[2 * bin + 1] = 0;
       a.fbin_count[bin] = 0;
       CounterShard& sh = a.counters->shard[bin % kCounterShards];
       if (count) atomicMax(&sh.max_bin_fill, count);
       if (fcount) atomicMax(&sh.max_fbin_fill, fcount);
     }
-    if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, (int)((a.flags >> 12) & 3u));
+    if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, (int)((a.flags >> 12) & 3u));
     if (!(a.flags & 0x400u)) raster_frags(keys, frags, nf, tid);
     __syncthreads();
 
@@ -1564,7 +1576,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
       if (k != bgkey && (uint32_t)(k >> 32) <= 8388608u) need = true;
     }
     if (__syncthreads_or(need)) {
-      raster_bin<1>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height);
+      raster_bin<1>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity);
       __syncthreads();
     }
   }
