@@ -1510,10 +1510,10 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 
   const int tid = threadIdx.x;
   const int tiles = a.tiles_x * a.tiles_y;
-  const int bin = blockIdx.x;
-  const int slot = bin / tiles, tile = bin - slot * tiles;
+  // grid = (tiles_x, tiles_y, streams of the group): no integer divisions to find the tile
+  const int txi = blockIdx.x, tyi = blockIdx.y, slot = blockIdx.z;
+  const int bin = slot * tiles + tyi * a.tiles_x + txi;
   const int stream = a.group_base + slot;
-  const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
   const int x_base = txi * kTileW, y_base = tyi * kTileH;
 
   const bool analytic_bg = a.bg_mode[stream] != 0;
@@ -1783,10 +1783,10 @@ void launch_clip(const SetupArgs& a, hipStream_t st)
 }
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st)
 {
-  const int blocks = a.group_size * a.tiles_x * a.tiles_y;
-  if (two_kernel) hipLaunchKernelGGL((tile_kernel<true, false>), dim3(blocks), dim3(kTileThreads), 0, st, a);
-  else if (a.io_u16) hipLaunchKernelGGL((tile_kernel<false, true>), dim3(blocks), dim3(kTileThreads), 0, st, a);
-  else hipLaunchKernelGGL((tile_kernel<false, false>), dim3(blocks), dim3(kTileThreads), 0, st, a);
+  const dim3 grid(a.tiles_x, a.tiles_y, a.group_size);
+  if (two_kernel) hipLaunchKernelGGL((tile_kernel<true, false>), grid, dim3(kTileThreads), 0, st, a);
+  else if (a.io_u16) hipLaunchKernelGGL((tile_kernel<false, true>), grid, dim3(kTileThreads), 0, st, a);
+  else hipLaunchKernelGGL((tile_kernel<false, false>), grid, dim3(kTileThreads), 0, st, a);
 }
 void launch_compare(const CompareArgs& a, hipStream_t st)
 {
