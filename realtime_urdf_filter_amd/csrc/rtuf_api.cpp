@@ -105,7 +105,7 @@ struct rtuf_context {
     // The batch's pose stage (uploads, forward kinematics, matrix stacks, cull) runs on a side stream and
     // writes only buffers of its own slot, so it overlaps the raster kernels of the batch before it.
     Camera* d_cams = nullptr; double* d_link_tf = nullptr;
-    float* d_mvp = nullptr; float* d_bg_z = nullptr; uint32_t* d_bg_mode = nullptr;
+    float* d_mvp = nullptr; BgInfo* d_bg = nullptr;
     WorkItem* d_items = nullptr; Counters* d_counters = nullptr;
     bool dirty_cams = true, dirty_link_tf = true;
     int uploaded_streams = 0;
@@ -208,7 +208,7 @@ static void free_frame_buffers(rtuf_context* c)
   auto dfree = [](auto*& p) { if (p) { hipFree(p); p = nullptr; } };
   auto hfree = [](auto*& p) { if (p) { hipHostFree(p); p = nullptr; } };
   dfree(c->d_model_mask);
-  for (auto& b : c->batch) { dfree(b.d_cams); dfree(b.d_link_tf); dfree(b.d_mvp); dfree(b.d_bg_z); dfree(b.d_bg_mode); dfree(b.d_items); dfree(b.d_counters); }
+  for (auto& b : c->batch) { dfree(b.d_cams); dfree(b.d_link_tf); dfree(b.d_mvp); dfree(b.d_bg); dfree(b.d_items); dfree(b.d_counters); }
   dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_zsurface);
   dfree(c->d_depth); dfree(c->d_masked); dfree(c->d_mask);
   hfree(c->h_cams); hfree(c->h_link_tf); hfree(c->h_model_mask);
@@ -326,8 +326,7 @@ static int alloc_frame_buffers(rtuf_context* c)
     HIP_TRY(c, hipMalloc(&b.d_cams, sizeof(Camera) * N));
     HIP_TRY(c, hipMalloc(&b.d_link_tf, sizeof(double) * 16 * L * N));
     HIP_TRY(c, hipMalloc(&b.d_mvp, sizeof(float) * 16 * (size_t)(c->n_draws + 1) * N));
-    HIP_TRY(c, hipMalloc(&b.d_bg_z, sizeof(float) * N));
-    HIP_TRY(c, hipMalloc(&b.d_bg_mode, sizeof(uint32_t) * N));
+    HIP_TRY(c, hipMalloc(&b.d_bg, sizeof(BgInfo) * N));
     HIP_TRY(c, hipMalloc(&b.d_counters, sizeof(Counters)));
     HIP_TRY(c, hipMemset(b.d_counters, 0, sizeof(Counters)));
     b.dirty_cams = b.dirty_link_tf = true; b.uploaded_streams = 0;
@@ -828,7 +827,11 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
   }
   PoseArgs pa{};
   pa.cams = b.d_cams; pa.link_tf = b.d_link_tf; pa.draws = c->d_draws; pa.mvp = b.d_mvp;
-  pa.bg_z = b.d_bg_z; pa.bg_mode = b.d_bg_mode; pa.counters = b.d_counters;
+  // to_linear_depth's constants exactly as the shader evaluates them (include/shaders/urdf_filter.frag:14-17), in float
+  const float zn = c->params.near_plane, zf = c->params.far_plane;
+  const float sc_num = (zn * zf) / (zn - zf), sc_off = zf / (zf - zn);
+  pa.bg = b.d_bg; pa.counters = b.d_counters;
+  pa.sc_num = sc_num; pa.sc_off = sc_off; pa.max_diff = c->params.depth_distance_threshold;
   pa.n_streams = n; pa.n_draws = c->n_draws; pa.n_links = (int)L; pa.z_far = c->params.far_plane;
   pa.width = c->width; pa.height = c->height;
   launch_pose(pa, sp);
@@ -839,7 +842,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     if (base > 0) launch_reset_clip(b.d_counters, st);
     SetupArgs sa{};
     sa.cverts = c->d_cverts; sa.ctris = c->d_ctris; sa.corder = c->d_corder; sa.chunks = c->d_chunks; sa.mvp = b.d_mvp;
-    sa.model_mask = c->d_model_mask; sa.bg_mode = b.d_bg_mode; sa.bins = c->d_bins; sa.bin_count = c->d_bin_count;
+    sa.model_mask = c->d_model_mask; sa.bg = b.d_bg; sa.bins = c->d_bins; sa.bin_count = c->d_bin_count;
     sa.fbins = c->d_fbins; sa.fbin_count = c->d_fbin_count; sa.fcapacity = c->fcapacity;
     sa.clip_list = c->d_clip_list; sa.counters = b.d_counters; sa.group_base = base; sa.group_size = gs;
     sa.n_draws = c->n_draws; sa.width = c->width; sa.height = c->height; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
@@ -861,11 +864,12 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     TileArgs ta{};
     ta.bins = c->d_bins; ta.bin_count = c->d_bin_count;
     ta.fbins = c->d_fbins; ta.fbin_count = c->d_fbin_count; ta.fcapacity = c->fcapacity; ta.depth = d_depth; ta.masked = d_masked; ta.mask = d_mask;
-    ta.zsurface = c->d_zsurface; ta.bg_z = b.d_bg_z; ta.bg_mode = b.d_bg_mode; ta.counters = b.d_counters;
+    ta.zsurface = c->d_zsurface; ta.bg = b.d_bg; ta.counters = b.d_counters;
     ta.group_base = base; ta.group_size = gs; ta.width = c->width; ta.height = c->height;
     ta.tiles_x = c->tiles_x; ta.tiles_y = c->tiles_y; ta.capacity = c->capacity; ta.flags = c->params.flags;
     ta.z_near = c->params.near_plane; ta.z_far = c->params.far_plane;
     ta.max_diff = c->params.depth_distance_threshold; ta.replace_value = c->params.filter_replace_value;
+    ta.sc_num = sc_num; ta.sc_off = sc_off;
     ta.io_u16 = io_u16 ? 1 : 0;
     if (b.timing) hipEventRecord(get_event(b, ev++), st);
     launch_tile(ta, two, st);
@@ -877,6 +881,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
       ca.io_u16 = io_u16 ? 1 : 0; ca.mask = d_mask ? d_mask + (size_t)base * plane : nullptr;
       ca.n_pixels = (size_t)gs * plane;
       ca.z_near = ta.z_near; ca.z_far = ta.z_far; ca.max_diff = ta.max_diff; ca.replace_value = ta.replace_value;
+      ca.sc_num = sc_num; ca.sc_off = sc_off;
       launch_compare(ca, st);
     }
     if (b.timing == 1 || (b.timing == 2 && two)) hipEventRecord(get_event(b, ev++), st);

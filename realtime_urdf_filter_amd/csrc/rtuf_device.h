@@ -153,14 +153,23 @@ struct FrameConsts {
 };
 
 
+// Per stream: what the background quad (src/urdf_filter.cpp:589-597) amounts to, computed once per batch
+// by pose_kernel so that the tile kernel's workgroups do no per-stream arithmetic of their own.
+struct alignas(16) BgInfo {
+  float z;                      // window z of the quad when it is a constant full-screen plane
+  uint32_t mode;                // 1 = constant full-screen plane (analytic), 0 = draw it as geometry
+  float thr;                    // compare threshold of that depth: sensor > thr <=> filtered
+  uint32_t z24;                 // its 24-bit depth-buffer value
+};
+
 // kernel argument blocks (passed by value) and host-callable launchers (rtuf_kernels.hip)
 struct PoseArgs {
   const Camera* cams;        // [n_streams]
   const double* link_tf;     // [n_streams][n_links][16]
   const Draw* draws;         // [n_draws]
   float* mvp;                // [n_streams][n_draws + 1][16]
-  float* bg_z;               // [n_streams]  window z of the background quad
-  uint32_t* bg_mode;         // [n_streams]  1 = constant full-screen plane (analytic), 0 = draw it as geometry
+  BgInfo* bg;                // [n_streams]
+  float sc_num, sc_off, max_diff;   // to_linear_depth constants (host-computed, see shade_consts) and the threshold
   Counters* counters;        // zeroed by the kernel's first workgroup
   int n_streams, n_draws, n_links;
   float z_far;
@@ -174,7 +183,7 @@ struct SetupArgs {
   const Chunk* chunks;
   const float* mvp;              // [n_streams][n_draws + 1][16]
   const uint64_t* model_mask;    // [n_streams] bit m set: stream renders model m
-  const uint32_t* bg_mode;       // [n_streams]
+  const BgInfo* bg;              // [n_streams]
   PackedTri* bins;               // [G][tiles][capacity]   triangles with a bounding box > 2x2 px
   uint32_t* bin_count;           // [G][tiles][2]  records binned from the front (small boxes) and from the back of the bin
   Frag* fbins;                   // [G][tiles][fcapacity]  covered pixels of the tiny triangles
@@ -204,14 +213,14 @@ struct TileArgs {
   float* masked;                 // [n][H][W]   same element type as depth
   uint8_t* mask;                 // [n][H][W] or nullptr
   float* zsurface;               // [G][H][W]  (two-kernel mode)
-  const float* bg_z;             // [n]
-  const uint32_t* bg_mode;       // [n]
+  const BgInfo* bg;              // [n]
   Counters* counters;
   int group_base, group_size;
   int width, height, tiles_x, tiles_y;
   uint32_t capacity;
   uint32_t flags;
   float z_near, z_far, max_diff, replace_value;
+  float sc_num, sc_off;          // z_near*z_far/(z_near-z_far) and z_far/(z_far-z_near) in float, as the shader computes them
   int io_u16;                    // 16UC1 in/out fused into the kernel (src/urdf_filter.cpp:287-288, :309-312)
 };
 
@@ -222,6 +231,7 @@ struct CompareArgs {
   uint8_t* mask;          // may be nullptr
   size_t n_pixels;        // multiple of 4 handled vectorised, tail scalar
   float z_near, z_far, max_diff, replace_value;
+  float sc_num, sc_off;
   int io_u16;
 };
 

@@ -172,8 +172,12 @@ __global__ void pose_kernel(PoseArgs a)
     const bool ok = constant && covers && quadrants && andm == 0;
     // constant plane: every clipped vertex keeps z_clip and w, so its window z is (z/w)*0.5+0.5
     const float zw = __fadd_rn(__fmul_rn(__fmul_rn(c0[2], __fdiv_rn(1.0f, c0[3])), 0.5f), 0.5f);
-    a.bg_z[s] = zw;
-    a.bg_mode[s] = ok ? 1u : 0u;
+    BgInfo bi;
+    bi.z = zw;
+    bi.mode = ok ? 1u : 0u;
+    bi.thr = __fsub_rn(__fdiv_rn(a.sc_num, __fsub_rn(zw, a.sc_off)), a.max_diff);                  // shade_threshold(zw)
+    bi.z24 = (uint32_t)__float2int_rn(__fmul_rn(fminf(fmaxf(zw, 0.0f), 1.0f), 16777215.0f));       // z24_of(zw)
+    a.bg[s] = bi;
     return;
   }
   const Draw dr = a.draws[d];
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(kBlock) void cull_kernel(SetupArgs a)
     bool vis = false;
     if (slot < a.group_size) {
       const int stream = a.group_base + slot;
-      vis = is_bg ? (a.bg_mode[stream] == 0u) : (((a.model_mask[stream] >> ch.model) & 1ull) != 0ull);
+      vis = is_bg ? (a.bg[stream].mode == 0u) : (((a.model_mask[stream] >> ch.model) & 1ull) != 0ull);
       if (vis) {
         float M[16];
         const float4* src = reinterpret_cast<const float4*>(a.mvp + ((size_t)stream * (a.n_draws + 1) + ch.draw) * 16);
@@ -1478,17 +1482,9 @@ __device__ __forceinline__ uint32_t metres_to_u16(float m)
 
 // urdf_filter.frag:14-35.  num = z_near*z_far/(z_near-z_far) and off = z_far/(z_far-z_near)
 // depend on uniforms only and are evaluated once per thread (same float operations).
+// num = z_near*z_far/(z_near-z_far), off = z_far/(z_far-z_near): evaluated once per batch on the host, in float,
+// exactly as the shader's to_linear_depth does (rtuf_api.cpp, enqueue_batch)
 struct ShadeConsts { float num, off, max_diff, replace_value; };
-
-__device__ __forceinline__ ShadeConsts shade_consts(float z_near, float z_far, float max_diff, float replace_value)
-{
-  ShadeConsts k;
-  k.num = __fdiv_rn(__fmul_rn(z_near, z_far), __fsub_rn(z_near, z_far));
-  k.off = __fdiv_rn(z_far, __fsub_rn(z_far, z_near));
-  k.max_diff = max_diff;
-  k.replace_value = replace_value;
-  return k;
-}
 
 // sensor > shade_threshold(z)  <=>  should_filter of include/shaders/urdf_filter.frag:22-23
 __device__ __forceinline__ float shade_threshold(float z, const ShadeConsts& k)
@@ -1516,11 +1512,12 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
   const int stream = a.group_base + slot;
   const int x_base = txi * kTileW, y_base = tyi * kTileH;
 
-  const bool analytic_bg = a.bg_mode[stream] != 0;
-  const float bgz = a.bg_z[stream];
-  const unsigned long long bgkey = analytic_bg ? (((unsigned long long)z24_of(bgz) << 32)) : kNoFragment;
-  const ShadeConsts sc = shade_consts(a.z_near, a.z_far, a.max_diff, a.replace_value);
-  const float thr_bg = shade_threshold(bgz, sc);
+  const BgInfo bi = a.bg[stream];
+  const bool analytic_bg = bi.mode != 0;
+  const float bgz = bi.z, thr_bg = bi.thr;
+  const unsigned long long bgkey = analytic_bg ? ((unsigned long long)bi.z24 << 32) : kNoFragment;
+  ShadeConsts sc;
+  sc.num = a.sc_num; sc.off = a.sc_off; sc.max_diff = a.max_diff; sc.replace_value = a.replace_value;
 
   const uint32_t count_front = a.bin_count[2 * bin], count_back = a.bin_count[2 * bin + 1], fcount = a.fbin_count[bin];
   const uint32_t count = count_front + count_back;
@@ -1667,7 +1664,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 template <bool U16>
 __global__ __launch_bounds__(kBlock) void compare_kernel(CompareArgs a)
 {
-  const ShadeConsts sc = shade_consts(a.z_near, a.z_far, a.max_diff, a.replace_value);
+  ShadeConsts sc;
+  sc.num = a.sc_num; sc.off = a.sc_off; sc.max_diff = a.max_diff; sc.replace_value = a.replace_value;
   const size_t n4 = a.n_pixels >> 2;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const uint16_t* in16 = reinterpret_cast<const uint16_t*>(a.depth);
