@@ -1533,7 +1533,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
   for (int ps = 0; ps < kPasses; ps++) {
     const int r_ly = r_ly0 + ps * kRowsPerPass, r_py = y_base + r_ly;
     const bool r_valid = r_ly < kTileH && r_py < a.height && r_px < a.width;
-    const size_t gofs = ((size_t)stream * a.height + r_py) * a.width + r_px;
+    // 64-bit part uniform (scalar), per-lane part 24-bit (W, H <= 2048)
+    const size_t gofs = (size_t)stream * ((size_t)a.height * a.width) + (uint32_t)(__mul24(r_py, a.width) + r_px);
     sens_p[ps] = make_float4(0, 0, 0, 0);
     if (!TWO_KERNEL && r_valid && vec) {
       if (U16) {
@@ -1582,10 +1583,10 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
   // window depths (or "nothing drawn") and their compare thresholds into the outputs.
   auto finish = [&](int ps, const float (&z)[4], const float (&thr)[4], const bool (&frag)[4]) {
     const int r_ly = r_ly0 + ps * kRowsPerPass, py = y_base + r_ly, px = r_px;
-    const size_t gofs = ((size_t)stream * a.height + py) * a.width + px;
+    const size_t gofs = (size_t)stream * ((size_t)a.height * a.width) + (uint32_t)(__mul24(py, a.width) + px);
     const int nvalid = min(4, a.width - px);
     if (TWO_KERNEL) {
-      const size_t zofs = ((size_t)slot * a.height + py) * a.width + px;
+      const size_t zofs = (size_t)slot * ((size_t)a.height * a.width) + (uint32_t)(__mul24(py, a.width) + px);
       // "no fragment" (only without background quad) is encoded as NaN
       float zz[4];
 #pragma unroll
