@@ -1062,10 +1062,10 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
           // z is monotone along x and along y (also as evaluated in float), so its minimum over the box
           // is at a corner.  Anything that may reach window z <= 0.5 needs its plane in the tile
           // kernel (exact float z): it goes out as a record instead (geometry within ~2 x near of the camera).
-          const float xa = (float)bx0, xb = (float)(bx0 + 3), ya = (float)by0, yb = (float)(by0 + 3);
-          const float zaa = __fmaf_rn(dzdy, ya, __fmaf_rn(dzdx, xa, a0)), zba = __fmaf_rn(dzdy, ya, __fmaf_rn(dzdx, xb, a0));
-          const float zab = __fmaf_rn(dzdy, yb, __fmaf_rn(dzdx, xa, a0)), zbb = __fmaf_rn(dzdy, yb, __fmaf_rn(dzdx, xb, a0));
-          near = !(zaa >= 0.51f && zba >= 0.51f && zab >= 0.51f && zbb >= 0.51f);      // (NaN counts as near)
+          // (monotone along each axis: the minimum is at the corner the two slopes point away from)
+          const float xm = (float)(dzdx < 0.0f ? bx0 + 3 : bx0), ym = (float)(dzdy < 0.0f ? by0 + 3 : by0);
+          const float zmin = __fmaf_rn(dzdy, ym, __fmaf_rn(dzdx, xm, a0));
+          near = !(zmin >= 0.51f);      // (a NaN anywhere in the plane makes zmin NaN: counts as near)
         }
       }
       if (near) {      // rare: hand the triangle to the record pass below (one LDS append)
