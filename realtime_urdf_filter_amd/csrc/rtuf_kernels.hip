@@ -609,7 +609,7 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slo
     int myleader = lane;
     while (pending) {
       const int leader = __ffsll((long long)pending) - 1;
-      const int lbin = __shfl(bin, leader);
+      const int lbin = __builtin_amdgcn_readlane(bin, leader);      // leader is wave-uniform: no LDS crossbar round trip
       const unsigned long long m = __ballot(act && bin == lbin);
       if (act && bin == lbin) { mymask = m; myleader = leader; }
       pending &= ~m;
@@ -727,7 +727,7 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
     int myleader = lane;
     while (pending) {
       const int leader = __ffsll((long long)pending) - 1;
-      const int lbin = __shfl(bin, leader);
+      const int lbin = __builtin_amdgcn_readlane(bin, leader);      // leader is wave-uniform: no LDS crossbar round trip
       const bool mine = act && bin == lbin;
       const unsigned long long m = __ballot(mine);
       if (mine) {
