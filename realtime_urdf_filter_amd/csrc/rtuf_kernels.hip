@@ -987,7 +987,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
       const int leader = __ffsll((long long)cmk) - 1;
       uint32_t base = 0;
       if (lane == leader) base = atomicAdd(&shard.clip_count, (uint32_t)__popcll(cmk));
-      base = __shfl(base, leader);
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
       if (needs_clip) {
         const uint32_t kk = base + (uint32_t)__popcll(cmk & ((1ull << lane) - 1ull));
         if (kk < a.clip_capacity) {
@@ -1007,21 +1007,21 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
       const int leader = __ffsll((long long)sm) - 1;
       uint32_t base = 0;
       if (lane == leader) base = atomicAdd(&s_nlist, (uint32_t)__popcll(sm));
-      base = __shfl(base, leader);
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
       if (rec) s_list[base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = (uint16_t)((k << 8) | tid);
     }
     if (tm) {
       const int leader = __ffsll((long long)tm) - 1;
       uint32_t base = 0;
       if (lane == leader) base = atomicAdd(&s_ntiny, (uint32_t)__popcll(tm));
-      base = __shfl(base, leader);
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
       if (tiny) s_list2[kStreamsPerBlock * kBlock - 1 - (base + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull)))] = (uint16_t)((k << 8) | tid);
     }
     if (qm) {
       const int leader = __ffsll((long long)qm) - 1;
       uint32_t base = 0;
       if (lane == leader) base = atomicAdd(&s_nsmall, (uint32_t)__popcll(qm));
-      base = __shfl(base, leader);
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
       if (small) s_list2[base + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull))] = (uint16_t)((k << 8) | tid);
     }
   }
