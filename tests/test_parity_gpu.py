@@ -524,6 +524,50 @@ def test_work_list_longer_than_the_estimated_setup_grid():
     ctx.close()
 
 
+def test_largest_frame_and_model_without_triangles():
+    """Edge sizes: the largest frame the ABI accepts (2048 x 2048, 20-bit snapped coordinates at their limit)
+    with a triangle soup, and a context whose model has no geometry at all (every pixel sees only the
+    background quad: everything with a finite positive sensor value closer than 0.99 * far - threshold
+    survives, the rest follows the quirks Q2 / Q9)."""
+    W = H = 2048
+    rng = np.random.default_rng(5)
+    P = S.projection(525.0 * W / 640, 525.0 * W / 640, (W - 1) / 2, (H - 1) / 2, W, H)
+    geo = S.soup_geometry(rng, n_links=3, tris_per_link=40)
+    tfs = S.random_link_poses(rng, len(geo), near=True)
+    offinv, camtf = S.random_camera(rng, small=True)
+    depth = S.sensor_depth(W, H, 0.7)
+    ctx = R.Context(W, H, 1, 0, params(5.0, 0.05))
+    m = ctx.add_model()
+    for pre, op, v, t in geo:
+        ctx.add_draw(m, ctx.add_link(m), v, t, pre, op)
+    ctx.finalize_models()
+    ctx.set_camera(0, P, offinv, camtf)
+    ctx.set_link_poses(0, m, np.stack(tfs))
+    masked, mask = ctx.filter_batch(depth[None])
+    om, ok = O.filter_frame(depth, P, [(tfs[i],) + geo[i] for i in range(len(geo))], offinv, camtf, replace_value=5.0)
+    assert (ok != mask[0]).sum() == 0 and bits_equal(om, masked[0])
+    ctx.close()
+    with pytest.raises(Exception):
+        R.Context(2049, 16, 1, 0, params())                      # beyond the coordinate range: refused, not clamped
+
+    W, H = 64, 48
+    depth = S.sensor_depth(W, H, 0.1)
+    P = S.projection(52.5, 52.5, 31.5, 23.5, W, H)
+    ctx = R.Context(W, H, 2, 0, params(5.0, 0.05))
+    m = ctx.add_model()
+    ctx.add_link(m)
+    ctx.finalize_models()
+    I = S.gl(np.eye(4))
+    for s in range(2):
+        ctx.set_camera(s, P, I, I)
+    masked, mask = ctx.filter_batch(np.stack([depth, depth]))
+    om, ok = O.filter_frame(depth, P, [], I, I, replace_value=5.0)
+    for s in range(2):
+        assert (ok != mask[s]).sum() == 0 and bits_equal(om, masked[s])
+    assert ctx.stats()["triangles_binned"] == 0
+    ctx.close()
+
+
 def test_config_c4_720p_pr2_plus_walls():
     """BASELINE config 4 shape: 1280x720, PR2-like robot + two static wall URDFs (full-screen boxes incl.
     quirk Q1: exercises the large-triangle path), several streams."""
