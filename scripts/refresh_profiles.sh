@@ -7,14 +7,14 @@ export TMPDIR=/tmp
 root=$PWD
 out=$root/gpurun_out/profiles
 rm -rf $out; mkdir -p $out
-B="python $root/bench.py --warmup 3"
-$B --steps 30 --cpu-seconds 20 > $out/${tag}_bench.json 2> $out/bench.err
-$B --steps 30 --cpu-seconds 0 --two-kernel > $out/${tag}_bench_two_kernel.json 2>> $out/bench.err
-$B --steps 30 --cpu-seconds 0 --u16 > $out/${tag}_bench_u16.json 2>> $out/bench.err
+B="python $root/bench.py"
+$B --cpu-seconds 20 > $out/${tag}_bench.json 2> $out/bench.err
+$B --cpu-seconds 0 --two-kernel > $out/${tag}_bench_two_kernel.json 2>> $out/bench.err
+$B --cpu-seconds 0 --u16 > $out/${tag}_bench_u16.json 2>> $out/bench.err
 $B --steps 200 --cpu-seconds 0 --streams 1 > $out/${tag}_bench_batch1.json 2>> $out/bench.err
-$B --steps 30 --cpu-seconds 0 --host-poses > $out/${tag}_bench_host_poses.json 2>> $out/bench.err
-$B --steps 60 --cpu-seconds 0 --pipelines 2 > $out/${tag}_bench_pipelines2.json 2>> $out/bench.err
-$B --steps 60 --cpu-seconds 0 --pipelines 3 > $out/${tag}_bench_pipelines3.json 2>> $out/bench.err
+$B --cpu-seconds 0 --host-poses > $out/${tag}_bench_host_poses.json 2>> $out/bench.err
+$B --cpu-seconds 0 --pipelines 2 > $out/${tag}_bench_pipelines2.json 2>> $out/bench.err
+$B --cpu-seconds 0 --pipelines 3 > $out/${tag}_bench_pipelines3.json 2>> $out/bench.err
 cd /tmp
 for mode in "" "--two-kernel"; do
   suffix=${mode:+_two_kernel}
