@@ -450,7 +450,11 @@ int rtuf_finalize_models(rtuf_context* c)
           for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], pp[k]); hi[k] = std::max(hi[k], pp[k]); }
         }
         double r2 = 0;
-        for (int k = 0; k < 3; k++) ch.center[k] = 0.5f * (lo[k] + hi[k]);
+        for (int k = 0; k < 3; k++) {
+          ch.center[k] = 0.5f * (lo[k] + hi[k]);
+          // half extent about the rounded centre, rounded up (the cull test must stay conservative)
+          ch.half[k] = std::nextafter(std::max(hi[k] - ch.center[k], ch.center[k] - lo[k]), INFINITY) * 1.0001f + 1e-7f;
+        }
         for (uint32_t q = 0; q < nv; q++) {
           const float4& p = cverts[ch.vert_begin + q];
           const double dx = (double)p.x - ch.center[0], dy = (double)p.y - ch.center[1], dz = (double)p.z - ch.center[2];

@@ -81,8 +81,10 @@ struct Chunk {                  // <= 256 consecutive triangles of one draw + th
   uint32_t model;
   uint32_t reserved;
   uint32_t pad;
-  float center[3];              // object-space bounding sphere of the chunk's vertices
-  float radius;
+  float center[3];              // object-space bounding box of the chunk's vertices: centre ...
+  float radius;                 // (radius of the enclosing sphere: unused by the kernels, kept for diagnostics)
+  float half[3];                // ... and half extents
+  uint32_t pad2;
 };
 
 struct Draw {

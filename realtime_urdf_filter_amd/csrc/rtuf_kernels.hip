@@ -779,7 +779,7 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
   return cnt;
 }
 
-// True when the chunk's bounding sphere lies completely outside frustum plane `plane` (0..5 =
+// True when the chunk's bounding box lies completely outside frustum plane `plane` (0..5 =
 // +x,-x,+y,-y,near,far): then all its vertices carry that plane's clip bit and every triangle
 // would be rejected by the per-triangle test anyway (same result, decided once per chunk).
 // Margins keep the test conservative.
@@ -792,8 +792,9 @@ __device__ __forceinline__ bool chunk_outside_plane(const float* M, const Chunk&
   const float ck = M[k] * cx + M[4 + k] * cy + M[8 + k] * cz + M[12 + k];
   const float nx = M[3] + sg * M[k], ny = M[7] + sg * M[4 + k], nz = M[11] + sg * M[8 + k];
   const float d = cw + sg * ck;
-  const float nn = sqrtf(nx * nx + ny * ny + nz * nz);
-  const float slack = ch.radius * nn * 1.001f + 1e-5f * (fabsf(cw) + fabsf(ck)) + 1e-30f;
+  // the corner of the box farthest along the plane normal is sum |n_i| * half_i above the centre
+  const float reach = fabsf(nx) * ch.half[0] + fabsf(ny) * ch.half[1] + fabsf(nz) * ch.half[2];
+  const float slack = reach * 1.001f + 1e-5f * (fabsf(cw) + fabsf(ck)) + 1e-30f;
   return d < -slack;
 }
 
@@ -808,7 +809,7 @@ __device__ __forceinline__ bool chunk_outside_plane(const float* M, const Chunk&
 //   once:        phase 3  the work list of all streams is processed by DENSE waves: full
 //                         set-up (edge functions, z plane) and binning
 // cull_kernel: one workgroup per chunk, one thread per stream slot of the in-flight group.  Tests
-// the chunk's bounding sphere against the six frustum planes of every stream (plus model selection /
+// the chunk's bounding box against the six frustum planes of every stream (plus model selection /
 // background mode) and appends the visible streams, kStreamsPerBlock at a time, to the work list
 // the set-up kernel runs from.  The test is conservative, so it never changes the image; it only
 // keeps ~70 % of the (chunk, stream) pairs of a robot that is partly in view from ever starting a
