@@ -1371,28 +1371,31 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     if (dbg_skip == 1 && area <= kSmallArea) area = 0;      // timing experiment: no lane-per-triangle walk
     if (dbg_skip == 2 && area > kSmallArea) area = 0;       // timing experiment: no quarter-wave walk
     const bool small = area > 0 && area <= kSmallArea;
-    // lane-per-triangle: walk the bounding box as one run of `area` candidates.  The three edge values
-    // are stepped incrementally (one add each; a different step at the end of a row), which is the
-    // same integer arithmetic as evaluating A*px + B*py + C at every candidate.
+    // lane-per-triangle: walk the bounding box as one run of candidate PAIRS (a pixel and the one below it),
+    // row pair by row pair.  The three edge values of the upper pixel are stepped incrementally (one add
+    // each, a different step at the end of a row pair), the lower pixel's are those plus B -- the same
+    // integer arithmetic as evaluating A*px + B*py + C at every candidate, at about two thirds of the
+    // instructions per candidate and half the loop trips.
     {
-      const int px0 = x_base + lx0, px1 = x_base + lx1;
+      const int px0 = x_base + lx0, px1 = x_base + lx1, py_last = y_base + ly1;
       int px = px0, py = y_base + ly0, lidx = ly0 * kTileW + lx0;
       int e0 = __mul24(r.A[0], px) + __mul24(r.B[0], py) + r.C[0];
       int e1 = __mul24(r.A[1], px) + __mul24(r.B[1], py) + r.C[1];
       int e2 = __mul24(r.A[2], px) + __mul24(r.B[2], py) + r.C[2];
       const int w1 = lx1 - lx0;                                           // steps per row
-      const int s0 = r.B[0] - __mul24(w1, r.A[0]), s1 = r.B[1] - __mul24(w1, r.A[1]), s2 = r.B[2] - __mul24(w1, r.A[2]);
-      const int row_step = kTileW - w1;
-      int todo = small ? area : 0;
+      const int s0 = 2 * r.B[0] - __mul24(w1, r.A[0]), s1 = 2 * r.B[1] - __mul24(w1, r.A[1]), s2 = 2 * r.B[2] - __mul24(w1, r.A[2]);
+      const int row_step = 2 * kTileW - w1;
+      int todo = small ? __mul24(w1 + 1, (ly1 - ly0 + 2) >> 1) : 0;
       while (__ballot(todo > 0)) {
         if (todo > 0) {
           if (min(e0, min(e1, e2)) > 0) fragment<MODE>(keys, r, px, py, lidx);
+          if (min(e0 + r.B[0], min(e1 + r.B[1], e2 + r.B[2])) > 0 && py < py_last) fragment<MODE>(keys, r, px, py + 1, lidx + kTileW);
           const bool wrap = px == px1;
           e0 += wrap ? s0 : r.A[0];
           e1 += wrap ? s1 : r.A[1];
           e2 += wrap ? s2 : r.A[2];
           lidx += wrap ? row_step : 1;
-          py += wrap ? 1 : 0;
+          py += wrap ? 2 : 0;
           px = wrap ? px0 : px + 1;
           todo--;
         }
