@@ -1371,32 +1371,39 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     if (dbg_skip == 1 && area <= kSmallArea) area = 0;      // timing experiment: no lane-per-triangle walk
     if (dbg_skip == 2 && area > kSmallArea) area = 0;       // timing experiment: no quarter-wave walk
     const bool small = area > 0 && area <= kSmallArea;
-    // lane-per-triangle: walk the bounding box as one run of candidate PAIRS (a pixel and the one below it),
-    // row pair by row pair.  The three edge values of the upper pixel are stepped incrementally (one add
-    // each, a different step at the end of a row pair), the lower pixel's are those plus B -- the same
-    // integer arithmetic as evaluating A*px + B*py + C at every candidate, at about two thirds of the
-    // instructions per candidate and half the loop trips.
+    // lane-per-triangle: walk the bounding box as one run of 2x2 candidate QUADS, quad row by quad row.
+    // The three edge values of a quad's upper left pixel are stepped incrementally (one add each, a
+    // different step at the end of a quad row); the other three pixels' are those plus A, B, A + B -- the
+    // same integer arithmetic as evaluating A*px + B*py + C at every candidate, at about half the
+    // instructions per candidate and a quarter of the loop trips.
     {
       const int px0 = x_base + lx0, px1 = x_base + lx1, py_last = y_base + ly1;
       int px = px0, py = y_base + ly0, lidx = ly0 * kTileW + lx0;
       int e0 = __mul24(r.A[0], px) + __mul24(r.B[0], py) + r.C[0];
       int e1 = __mul24(r.A[1], px) + __mul24(r.B[1], py) + r.C[1];
       int e2 = __mul24(r.A[2], px) + __mul24(r.B[2], py) + r.C[2];
-      const int w1 = lx1 - lx0;                                           // steps per row
-      const int s0 = 2 * r.B[0] - __mul24(w1, r.A[0]), s1 = 2 * r.B[1] - __mul24(w1, r.A[1]), s2 = 2 * r.B[2] - __mul24(w1, r.A[2]);
-      const int row_step = 2 * kTileW - w1;
-      int todo = small ? __mul24(w1 + 1, (ly1 - ly0 + 2) >> 1) : 0;
+      const int qcols = (lx1 - lx0 + 2) >> 1;                              // quads per quad row
+      const int back = 2 * (qcols - 1);                                    // x distance from the last quad of a row to the first
+      const int s0 = 2 * r.B[0] - __mul24(back, r.A[0]), s1 = 2 * r.B[1] - __mul24(back, r.A[1]), s2 = 2 * r.B[2] - __mul24(back, r.A[2]);
+      const int a0x2 = 2 * r.A[0], a1x2 = 2 * r.A[1], a2x2 = 2 * r.A[2];
+      const int row_step = 2 * kTileW - back;
+      const int px_lastq = px0 + back;
+      int todo = small ? __mul24(qcols, (ly1 - ly0 + 2) >> 1) : 0;
       while (__ballot(todo > 0)) {
         if (todo > 0) {
+          const bool right = px < px1, below = py < py_last;
+          const int f0 = e0 + r.B[0], f1 = e1 + r.B[1], f2 = e2 + r.B[2];
           if (min(e0, min(e1, e2)) > 0) fragment<MODE>(keys, r, px, py, lidx);
-          if (min(e0 + r.B[0], min(e1 + r.B[1], e2 + r.B[2])) > 0 && py < py_last) fragment<MODE>(keys, r, px, py + 1, lidx + kTileW);
-          const bool wrap = px == px1;
-          e0 += wrap ? s0 : r.A[0];
-          e1 += wrap ? s1 : r.A[1];
-          e2 += wrap ? s2 : r.A[2];
-          lidx += wrap ? row_step : 1;
+          if (min(e0 + r.A[0], min(e1 + r.A[1], e2 + r.A[2])) > 0 && right) fragment<MODE>(keys, r, px + 1, py, lidx + 1);
+          if (min(f0, min(f1, f2)) > 0 && below) fragment<MODE>(keys, r, px, py + 1, lidx + kTileW);
+          if (min(f0 + r.A[0], min(f1 + r.A[1], f2 + r.A[2])) > 0 && right && below) fragment<MODE>(keys, r, px + 1, py + 1, lidx + kTileW + 1);
+          const bool wrap = px == px_lastq;
+          e0 += wrap ? s0 : a0x2;
+          e1 += wrap ? s1 : a1x2;
+          e2 += wrap ? s2 : a2x2;
+          lidx += wrap ? row_step : 2;
           py += wrap ? 2 : 0;
-          px = wrap ? px0 : px + 1;
+          px = wrap ? px0 : px + 2;
           todo--;
         }
       }
