@@ -1317,7 +1317,7 @@ __device__ __forceinline__ void fragment(unsigned long long* keys, const TriRec&
 
 
 #ifndef RTUF_SMALL_AREA
-#define RTUF_SMALL_AREA 48
+#define RTUF_SMALL_AREA 96
 #endif
 #ifndef RTUF_QUARTER_AREA
 #define RTUF_QUARTER_AREA 256
