@@ -1337,6 +1337,21 @@ __device__ __forceinline__ TriRec broadcast_record(const TriRec& r, int src_lane
   return q;
 }
 
+// One lane's step of the cooperative paths: pixel (lx, ly) of the tile and the one below it (limited to the
+// box, qy1 inclusive).  Neighbouring lanes take neighbouring columns, so each of the two LDS atomics of a
+// step is conflict-free across the wave; the lower pixel's edge values are the upper one's plus B.
+template <int MODE>
+__device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriRec& q, int x_base, int y_base, int lx, int ly, int qy1)
+{
+  const int px = x_base + lx, py = y_base + ly;
+  const int e0 = __mul24(q.A[0], px) + __mul24(q.B[0], py) + q.C[0];
+  const int e1 = __mul24(q.A[1], px) + __mul24(q.B[1], py) + q.C[1];
+  const int e2 = __mul24(q.A[2], px) + __mul24(q.B[2], py) + q.C[2];
+  const int lidx = ly * kTileW + lx;
+  if (min(e0, min(e1, e2)) > 0) fragment<MODE>(keys, q, px, py, lidx);
+  if (min(e0 + q.B[0], min(e1 + q.B[1], e2 + q.B[2])) > 0 && ly < qy1) fragment<MODE>(keys, q, px, py + 1, lidx + kTileW);
+}
+
 // Rasterises the bin's records into the LDS key tile.  Every wave works on its own records
 // (no workgroup barrier inside): lane-per-triangle for tiny bounding boxes, the whole wave in
 // 8x8 stamps for anything larger.
@@ -1408,10 +1423,10 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
         }
       }
     }
-    // quarter-wave cooperative: four triangles at a time, 16 lanes each, one candidate pixel per
-    // lane and step (the bounding box is walked as a linear run, so slivers waste nothing)
+    // quarter-wave cooperative: four triangles at a time, 16 lanes each, one vertical candidate pair per
+    // lane and step (the bounding box is walked as a linear run of pairs, so slivers waste little)
     // whole-wave cooperative: triangles that cover a large part of the tile, one at a time with the
-    // record in scalar registers (v_readlane), 64 candidate pixels per step
+    // record in scalar registers (v_readlane), 64 candidate pairs per step
     unsigned long long huge = __ballot(area > kQuarterArea);
     while (huge) {
       const int src = __ffsll((long long)huge) - 1;
@@ -1419,13 +1434,12 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       const TriRec q = broadcast_record(r, src);
       const int qx0 = max((int)(q.bbx & 0xffff) - x_base, 0), qx1 = min((int)(q.bbx >> 16) - x_base, kTileW - 1);
       const int qy0 = max((int)(q.bby & 0xffff) - y_base, 0), qy1 = min((int)(q.bby >> 16) - y_base, kTileH - 1);
-      const int qw = qx1 - qx0 + 1, qarea = qw * (qy1 - qy0 + 1);
+      // the box as a linear run of vertical pixel pairs, one pair per lane and step
+      const int qw = qx1 - qx0 + 1, npair = qw * ((qy1 - qy0 + 2) >> 1);
       const uint32_t inv = (uint32_t)ceilf(1048576.0f * __builtin_amdgcn_rcpf((float)qw));
-      for (int idx = lane; idx < qarea; idx += 64) {
+      for (int idx = lane; idx < npair; idx += 64) {
         const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
-        const int lx = qx0 + idx - __mul24(yy, qw), ly = qy0 + yy;
-        const int px = x_base + lx, py = y_base + ly;
-        if (inside(q, px, py)) fragment<MODE>(keys, q, px, py, ly * kTileW + lx);
+        raster_pair<MODE>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1);
       }
     }
     unsigned long long big = __ballot(area > kSmallArea && area <= kQuarterArea);
@@ -1449,17 +1463,15 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       const int qx0 = max((int)(q.bbx & 0xffff) - x_base, 0), qx1 = min((int)(q.bbx >> 16) - x_base, kTileW - 1);
       const int qy0 = max((int)(q.bby & 0xffff) - y_base, 0), qy1 = min((int)(q.bby >> 16) - y_base, kTileH - 1);
       const int qw = qx1 - qx0 + 1;
-      const int qarea = src < 0 ? 0 : qw * (qy1 - qy0 + 1);
+      const int npair = src < 0 ? 0 : qw * ((qy1 - qy0 + 2) >> 1);
       // idx / qw for idx < 4096, qw <= 128 via a reciprocal multiply that is exact in that range:
       // inv = ceil(2^20 / qw) (+1 at most if v_rcp_f32 is an ulp high), and idx * (inv - 2^20/qw) * qw < 2^20
       // (checked exhaustively on the CPU, including +-1 ulp of the reciprocal)
       const uint32_t inv = (uint32_t)ceilf(1048576.0f * __builtin_amdgcn_rcpf((float)max(qw, 1)));
-      for (int idx = sub; __ballot(idx < qarea); idx += 16) {
-        if (idx < qarea) {
+      for (int idx = sub; __ballot(idx < npair); idx += 16) {
+        if (idx < npair) {
           const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
-          const int lx = qx0 + idx - __mul24(yy, qw), ly = qy0 + yy;
-          const int px = x_base + lx, py = y_base + ly;
-          if (inside(q, px, py)) fragment<MODE>(keys, q, px, py, ly * kTileW + lx);
+          raster_pair<MODE>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1);
         }
       }
     }
