@@ -636,15 +636,6 @@ __device__ __forceinline__ uint32_t z24_of(float z)
   return (uint32_t)__float2int_rn(__fmul_rn(zc, 16777215.0f));
 }
 
-__device__ __forceinline__ bool inside(const TriRec& r, int px, int py)
-{
-  // |A|, |B| < 2^20 and px, py < 2^11: 24-bit multiplies (full rate) are exact
-  const int e0 = __mul24(r.A[0], px) + __mul24(r.B[0], py) + r.C[0];
-  const int e1 = __mul24(r.A[1], px) + __mul24(r.B[1], py) + r.C[1];
-  const int e2 = __mul24(r.A[2], px) + __mul24(r.B[2], py) + r.C[2];
-  return (e0 > 0) & (e1 > 0) & (e2 > 0);
-}
-
 // Set-up + coverage of a triangle (snapped coordinates x0..y2 from phase 1) whose pixel-centre bounding box
 // is at most N x N (N <= 4): returns
 // the covered box positions (bit dy*4+dx, origin bx0,by0) and orients v0/v1 like orient_and_bound.
