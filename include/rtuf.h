@@ -206,7 +206,7 @@ typedef struct {
   uint32_t bin_capacity;
   uint32_t regrowths;               /* times the bins were enlarged and a batch re-run */
   uint32_t max_fbin_fill;           /* largest fragment bin of the last batch          */
-  uint64_t fragments_binned;        /* covered pixels of tiny (<= 2x2 px) triangles binned as fragments */
+  uint64_t fragments_binned;        /* covered pixels of small (<= 4x4 px box) triangles binned as fragments */
   float ms_pose, ms_setup, ms_raster, ms_compare, ms_total;   /* last timed batch       */
   uint32_t reserved0;
   uint64_t timed_batches;           /* batches retired since rtuf_enable_timing, and the sums  */

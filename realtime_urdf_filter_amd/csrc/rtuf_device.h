@@ -2,19 +2,19 @@
 //
 // HBM layout (all arrays owned by one rtuf_context, one GPU):
 //   static geometry, uploaded once by rtuf_finalize_models()
-//     chunks Chunk[C]    <= 256 consecutive triangles of ONE draw call + the list of the
-//                        <= 256 distinct vertices they use                32 B / chunk
+//     chunks Chunk[C]    <= 256 triangles of ONE draw call (a compact patch: Morton order of the
+//                        centroids) + the <= 256 distinct vertices they use + bounding box   64 B / chunk
 //     cverts float4[Vc]  object-space positions, grouped per chunk        16 B / vertex
 //     ctris  u32[T]      3 x 10-bit chunk-local vertex ids                 4 B / triangle
 //                        (draw-order sequence numbers in corder, parallel to ctris; 0 = background)
 //     draws  Draw[D]     link id + the glScalef/glTranslatef of the draw
 //   per frame, per stream s (slot within the batch)
 //     cams   Camera[N]   projection / camera_offset_inv / camera_tf as f64
-//     link_tf f64[N][L][16]
-//     mvp    f32[N][D][16]  written by pose_kernel
+//     link_tf f64[N][L][16]                                         (two slots: one per batch in flight)
+//     mvp    f32[N][D][16]  written by pose_kernel;  bg BgInfo[N];  items WorkItem[] written by cull_kernel
 //     depth  f32[N][H][W] in, masked f32[N][H][W] + mask u8[N][H][W] out
 //   rasteriser working set, per in-flight stream g and screen tile
-//     bin_count u32[G][tiles], bins PackedTri[G][tiles][capacity]  (triangles, 32 B records)
+//     bin_count u32[G][tiles][2], bins PackedTri[G][tiles][capacity]  (32 B records: small boxes from the front, larger from the back)
 //     fbin_count u32[G][tiles], fbins Frag[G][tiles][fcapacity]    (pixels of small triangles, 8 B)
 //     clip_list ClipItem[], zsurface f32[G][H][W] (two-kernel mode only)
 #pragma once
@@ -186,9 +186,9 @@ struct SetupArgs {
   const float* mvp;              // [n_streams][n_draws + 1][16]
   const uint64_t* model_mask;    // [n_streams] bit m set: stream renders model m
   const BgInfo* bg;              // [n_streams]
-  PackedTri* bins;               // [G][tiles][capacity]   triangles with a bounding box > 2x2 px
+  PackedTri* bins;               // [G][tiles][capacity]   triangles that are not resolved to fragments
   uint32_t* bin_count;           // [G][tiles][2]  records binned from the front (small boxes) and from the back of the bin
-  Frag* fbins;                   // [G][tiles][fcapacity]  covered pixels of the tiny triangles
+  Frag* fbins;                   // [G][tiles][fcapacity]  covered pixels of the small (<= 4x4, single-tile) boxes
   uint32_t* fbin_count;          // [G][tiles]
   uint32_t fcapacity;
   ClipItem* clip_list;

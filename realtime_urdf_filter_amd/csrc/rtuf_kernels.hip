@@ -1,18 +1,22 @@
 // rtuf_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the depth self-filter.
 //
-// Pipeline per batch of camera streams (all on one HIP stream):
-//   pose_kernel     float32 OpenGL matrix stack per (stream, draw)      replaces urdf_filter.cpp:576-614,
-//                                                                       renderable.cpp:59-68, :95, :128, :427
-//   setup_kernel    one lane per triangle: vertex transform, clip test,  replaces urdf_filter.vert + the GL
-//                   viewport, 1/256-px snap, integer edge functions,     driver's primitive assembly / set-up
-//                   z plane, tile binning (64-B records)
-//   clip_kernel     the few triangles that cross a frustum plane:        (GL driver clipper)
+// Pipeline per batch of camera streams (pose stage on a side stream, raster stage on the main stream):
+//   fk_tree_kernel  joint positions -> link matrices + camera transform   replaces urdf_renderer.cpp:173-190 (TF lookups)
+//   pose_kernel     float32 OpenGL matrix stack per (stream, draw);       replaces urdf_filter.cpp:576-614,
+//                   per-stream background plane; zeroes the counters      renderable.cpp:59-68, :95, :128, :427
+//   cull_kernel     chunk bounding boxes vs every stream's frustum ->     (none: GL draws everything)
+//                   compact work list of (chunk, 3 streams) items
+//   setup_kernel    per item: vertex transform once per chunk vertex,     replaces urdf_filter.vert + the GL
+//                   clip test, viewport, 1/256-px snap, sub-pixel cull,   driver's primitive assembly / set-up
+//                   z plane; small boxes -> 8-B fragments, others ->
+//                   32-B records, binned per 64x32 tile
+//   clip_kernel     the few triangles that cross a frustum plane:         (GL driver clipper)
 //                   Sutherland-Hodgman in clip space, fan, same set-up
-//   tile_kernel     one workgroup per (stream, 64x64 tile): the tile's   replaces GL rasterisation + 24-bit
-//                   depth keys live in LDS, fragments resolve with       GL_LESS depth test + urdf_filter.frag
-//                   64-bit LDS atomicMin, then the per-pixel compare     + glGetTexImage conversions
+//   tile_kernel     one workgroup per (stream, 64x32 tile): the tile's    replaces GL rasterisation + 24-bit
+//                   depth keys live in LDS, fragments resolve with        GL_LESS depth test + urdf_filter.frag
+//                   64-bit LDS atomicMin, then the per-pixel compare      + glGetTexImage conversions
 //                   is done in place (fused) or the z-surface is written
-//   compare_kernel  two-kernel mode only: z-surface + sensor -> outputs  replaces urdf_filter.frag:19-36
+//   compare_kernel  two-kernel mode only: z-surface + sensor -> outputs   replaces urdf_filter.frag:19-36
 //
 // Exactness: results must equal the reference's GLSL running on Mesa llvmpipe bit for bit
 // (see oracle/rtuf_oracle.c for what that pins).  Every float operation whose rounding matters
@@ -580,7 +584,7 @@ __device__ __forceinline__ uint32_t emit_big_records_wave(const SetupArgs& a, in
 // target the same bin are grouped with ballots (ALU only), then every group leader issues its
 // atomicAdd in the SAME instruction, so a wave pays one atomic round trip per tile index
 // instead of one per distinct bin; group members get consecutive slots, which makes the
-// 64-byte record stores of neighbouring mesh triangles contiguous.
+// 32-byte record stores of neighbouring mesh triangles contiguous.
 __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slot, bool have, uint32_t bbx, uint32_t bby, const PackedTri& pk)
 {
   const int lane = threadIdx.x & 63;
@@ -687,7 +691,7 @@ __device__ __forceinline__ uint32_t small_box_coverage(Win& v0, Win& v1, const W
   return out & cols & rows;
 }
 
-// Wave-cooperative emission of the covered pixels of small triangles as 16-byte fragments.  `mask`
+// Wave-cooperative emission of the covered pixels of small triangles as 8-byte fragments.  `mask`
 // holds the coverage of the box positions (bit dy*4+dx, box origin bx0,by0).  Lanes are grouped by bin
 // with ballots, the group leaders reserve popcount(mask) slots each in ONE atomic round trip and
 // every lane writes its fragments to consecutive slots.  With MAY_STRADDLE a box whose covered
@@ -1538,7 +1542,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
   // The sensor pixels this lane will resolve are requested before anything else so that their HBM
   // latency overlaps the bin-counter round trip and all of the rasterisation.
   constexpr int kLanesPerRow = kTileW / 4, kRowsPerPass = kTileThreads / kLanesPerRow;
-  constexpr int kPasses = (kTileH + kRowsPerPass - 1) / kRowsPerPass;      // resolve passes per tile (1 for 32x32)
+  constexpr int kPasses = (kTileH + kRowsPerPass - 1) / kRowsPerPass;      // resolve passes per tile (2 for 64x32)
   const bool vec = (a.width & 3) == 0;
   const int r_ly0 = tid / kLanesPerRow, r_lx = (tid % kLanesPerRow) * 4;
   const int r_px = x_base + r_lx;
