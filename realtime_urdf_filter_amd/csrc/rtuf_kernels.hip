@@ -630,10 +630,7 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slo
   return n;
 }
 
-// setup_kernel: one workgroup per (chunk, group of kStreamsPerBlock streams).  A chunk is <= 256
-// consecutive triangles of one draw call with its own <= kMaxChunkVerts vertex list, so each
-// vertex is transformed once per stream (into LDS) instead of once per incident triangle, and
-// the chunk's geometry is loaded once for all streams of the group.
+// 24-bit depth-buffer value of a window z: round(clamp(z, 0, 1) * (2^24 - 1)), half to even (llvmpipe Z24)
 __device__ __forceinline__ uint32_t z24_of(float z)
 {
   const float zc = fminf(fmaxf(z, 0.0f), 1.0f);
@@ -866,6 +863,10 @@ __global__ __launch_bounds__(kBlock) void cull_kernel(SetupArgs a)
   }
 }
 
+// setup_kernel: one workgroup per work item = (chunk, up to kStreamsPerBlock streams that see it).  A chunk is
+// <= 256 triangles of one draw call with its own <= kMaxChunkVerts vertex list, so each vertex is transformed
+// once per stream (into LDS) instead of once per incident triangle, and the chunk's geometry is loaded
+// once for all streams of the item.
 template <bool STRIDED>
 __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t item_base)
 {
