@@ -378,7 +378,6 @@ int rtuf_finalize_models(rtuf_context* c)
   std::vector<Draw> draws;
   int64_t tri_seq = 0;
   // Splits one draw's triangle list into chunks of <= kBlock triangles / <= kMaxChunkVerts vertices.
-  // Splits one draw's triangle list into chunks of <= kBlock triangles / <= kMaxChunkVerts vertices.
   // Triangles are taken in Morton order of their centroids, so a chunk is a compact patch of the surface:
   // fewer distinct vertices per chunk (each is transformed once per chunk and stream) and a tighter
   // bounding sphere (more whole-chunk frustum culls) than the file order of a mesh gives.  The depth

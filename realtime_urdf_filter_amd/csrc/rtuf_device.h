@@ -36,7 +36,10 @@ constexpr int kBlock = 256;
 #define RTUF_TILE_THREADS 256
 #endif
 constexpr int kTileThreads = RTUF_TILE_THREADS;   // threads of a tile workgroup
-constexpr int kMaxChunkVerts = 256;     // unique vertices per set-up chunk (one per lane; LDS: 24 B each per stream)
+#ifndef RTUF_MAX_CHUNK_VERTS
+#define RTUF_MAX_CHUNK_VERTS 256
+#endif
+constexpr int kMaxChunkVerts = RTUF_MAX_CHUNK_VERTS;     // unique vertices per set-up chunk (one per lane; LDS: 24 B each per stream)
 #ifndef RTUF_STREAMS_PER_BLOCK
 #define RTUF_STREAMS_PER_BLOCK 3
 #endif
