@@ -57,6 +57,7 @@ enum {
   RTUF_FLAG_TWO_KERNEL      = 1u << 1,  /* rasteriser writes the z-surface to HBM and a separate compare kernel consumes it
                                            (default: compare fused into the tile kernel, the z-surface never leaves LDS)        */
   RTUF_FLAG_DEFAULT = RTUF_FLAG_BACKGROUND_QUAD
+  /* bits 8..23 are timing experiments of the kernels (scripts/ablate_*.sh): they skip work, the images are wrong */
 };
 
 /* Replaces the constructor's rosparam parsing (src/urdf_filter.cpp:43-118) and the
