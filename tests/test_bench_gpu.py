@@ -45,3 +45,11 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     d = last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["streams_per_gpu"] == 8
     assert abs(d["value"] - 2 * 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+
+
+def test_fuzz_parity_sample():
+    """A sample of scripts/fuzz_parity.py (random resolutions, intrinsics, soups from sub-pixel dust to
+    screen-filling triangles, near-plane crossings, both modes, forced bin regrowth) against the oracle."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "80", "777"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "streams with mismatches 0" in r.stdout
