@@ -466,8 +466,20 @@ void rgo_end_frame(float *masked_depth, unsigned char *mask)
   p_glBindTexture(GL_TEXTURE_RECTANGLE, g_color[1]);
   p_glGetTexImage(GL_TEXTURE_RECTANGLE, 0, GL_RED, GL_FLOAT, masked_depth);
   if (mask) {
+    /* The reference reads the mask with the default GL_PACK_ALIGNMENT of 4 into a width*height buffer
+     * (src/urdf_filter.cpp:733-735): for widths that are not a multiple of 4 GL pads every row and the
+     * reference overruns mask_.  The harness reads into a row-padded scratch buffer and hands back the
+     * dense width*height image the texture holds. */
+    const int stride = (g_w + 3) & ~3;
     p_glBindTexture(GL_TEXTURE_RECTANGLE, g_color[3]);
-    p_glGetTexImage(GL_TEXTURE_RECTANGLE, 0, GL_RED, GL_UNSIGNED_BYTE, mask);
+    if (stride == g_w) {
+      p_glGetTexImage(GL_TEXTURE_RECTANGLE, 0, GL_RED, GL_UNSIGNED_BYTE, mask);
+    } else {
+      unsigned char *tmp = (unsigned char *)malloc((size_t)stride * g_h);
+      p_glGetTexImage(GL_TEXTURE_RECTANGLE, 0, GL_RED, GL_UNSIGNED_BYTE, tmp);
+      for (int y = 0; y < g_h; y++) memcpy(mask + (size_t)y * g_w, tmp + (size_t)y * stride, (size_t)g_w);
+      free(tmp);
+    }
   }
 }
 
