@@ -1570,6 +1570,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
   const unsigned long long* frags = reinterpret_cast<const unsigned long long*>(a.fbins) + (size_t)bin * a.fcapacity;
   // flags bits 8.. are timing experiments only (wrong results): 0x100 skip rasterisation, 0x200 skip pixel loops
   const bool empty = (n == 0 && nf == 0) || (a.flags & 0x100u);   // no geometry in this tile: pure streaming compare
+  if (empty && (a.flags & 0x1000000u)) return;                     // timing experiment: raster tiles only
   if (!empty) {
     for (int i = tid; i < kTileW * kTileH; i += kTileThreads) keys[i] = bgkey;
     __syncthreads();
