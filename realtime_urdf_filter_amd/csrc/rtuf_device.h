@@ -45,6 +45,11 @@ constexpr int kMaxChunkVerts = RTUF_MAX_CHUNK_VERTS;     // unique vertices per 
 #endif
 constexpr int kStreamsPerBlock = RTUF_STREAMS_PER_BLOCK;     // streams a set-up workgroup loops over per chunk
 
+// Bias of the 20-bit snapped coordinates in a PackedTri.  In-frustum vertices snap to [-128, W*256 + 128]; the
+// clipper's interpolation is rounded, so its vertices may land a few units outside (seen: -129): 1024 leaves room
+// on both sides (2048*256 + 128 + 2*1024 < 2^20).
+constexpr int kCoordBias = 1024;
+
 struct alignas(16) TriRec {     // 64 B: one rasterisable triangle inside one tile bin
   int32_t A[3];                 // edge i is inside  <=>  A[i]*px + B[i]*py + C[i] > 0
   int32_t B[3];
@@ -58,8 +63,8 @@ struct alignas(16) TriRec {     // 64 B: one rasterisable triangle inside one ti
 static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
 
 struct alignas(16) PackedTri {  // 32 B: what a triangle bin stores; the tile kernel rebuilds TriRec from it
-  unsigned long long v01;       // (x0+128) | (y0+128) << 20 | (x1+128) << 40   snapped 1/256-px coordinates,
-  unsigned long long v12;       // (y1+128) | (x2+128) << 20 | (y2+128) << 40   already oriented (area > 0)
+  unsigned long long v01;       // (x0+bias) | (y0+bias) << 20 | (x1+bias) << 40   snapped 1/256-px coordinates,
+  unsigned long long v12;       // (y1+bias) | (x2+bias) << 20 | (y2+bias) << 40   already oriented (area > 0)
   float a0, dzdx, dzdy;         // z plane
   uint32_t order;
 };

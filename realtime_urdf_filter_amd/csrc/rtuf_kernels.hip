@@ -429,7 +429,8 @@ __device__ __forceinline__ bool orient_and_bound(Win& v0, Win& v1, const Win& v2
                                                  int& x0, int& y0, int& x1, int& y1, int& x2, int& y2,
                                                  int& bx0, int& bx1, int& by0, int& by1)
 {
-  // vertices of unclipped triangles lie inside the frustum: snapped values are in [-128, 2048*256+128].
+  // vertices of unclipped triangles lie inside the frustum: snapped values are in [-128, 2048*256+128]
+  // (clipper-made vertices, a few units more, never come here).
   // The (value-preserving) 21-bit sign extension tells the compiler so, which turns the 64-bit
   // products below into full-rate 24-bit multiplies.
   // x0..y2 come in as the snapped coordinates of phase 1 (s_snap): snap(v.x), snap(v.y)
@@ -469,10 +470,11 @@ __device__ __forceinline__ void z_plane(const Win& v0, const Win& v1, const Win&
 __device__ __forceinline__ PackedTri pack_record(int x0, int y0, int x1, int y1, int x2, int y2, float a0, float dzdx,
                                                  float dzdy, uint32_t order)
 {
-  // snapped coordinates of in-frustum vertices lie in [-128, 2048*256]: 20 bits after the +128 bias
+  // snapped coordinates of in-frustum vertices lie in [-128, 2048*256 + 128]; vertices made by the clipper can be a
+  // few 1/256 px outside that (their interpolation is rounded): 20 bits after the bias of kCoordBias
   PackedTri pk;
-  pk.v01 = (unsigned long long)(uint32_t)(x0 + 128) | ((unsigned long long)(uint32_t)(y0 + 128) << 20) | ((unsigned long long)(uint32_t)(x1 + 128) << 40);
-  pk.v12 = (unsigned long long)(uint32_t)(y1 + 128) | ((unsigned long long)(uint32_t)(x2 + 128) << 20) | ((unsigned long long)(uint32_t)(y2 + 128) << 40);
+  pk.v01 = (unsigned long long)(uint32_t)(x0 + kCoordBias) | ((unsigned long long)(uint32_t)(y0 + kCoordBias) << 20) | ((unsigned long long)(uint32_t)(x1 + kCoordBias) << 40);
+  pk.v12 = (unsigned long long)(uint32_t)(y1 + kCoordBias) | ((unsigned long long)(uint32_t)(x2 + kCoordBias) << 20) | ((unsigned long long)(uint32_t)(y2 + kCoordBias) << 40);
   pk.a0 = a0; pk.dzdx = dzdx; pk.dzdy = dzdy; pk.order = order;
   return pk;
 }
@@ -514,9 +516,10 @@ __device__ __forceinline__ bool make_record(Win v0, Win v1, Win v2, uint32_t ord
   r.a0 = __fsub_rn(v0.z, __fadd_rn(__fmul_rn(r.dzdx, x0c), __fmul_rn(r.dzdy, y0c)));
   r.order = order;
   r.pad = 0;
-  // snapped coordinates of in-frustum vertices lie in [-128, 2048*256]: 20 bits after the +128 bias
-  pk.v01 = (unsigned long long)(uint32_t)(x0 + 128) | ((unsigned long long)(uint32_t)(y0 + 128) << 20) | ((unsigned long long)(uint32_t)(x1 + 128) << 40);
-  pk.v12 = (unsigned long long)(uint32_t)(y1 + 128) | ((unsigned long long)(uint32_t)(x2 + 128) << 20) | ((unsigned long long)(uint32_t)(y2 + 128) << 40);
+  // snapped coordinates of in-frustum vertices lie in [-128, 2048*256 + 128]; vertices made by the clipper can be a
+  // few 1/256 px outside that (their interpolation is rounded): 20 bits after the bias of kCoordBias
+  pk.v01 = (unsigned long long)(uint32_t)(x0 + kCoordBias) | ((unsigned long long)(uint32_t)(y0 + kCoordBias) << 20) | ((unsigned long long)(uint32_t)(x1 + kCoordBias) << 40);
+  pk.v12 = (unsigned long long)(uint32_t)(y1 + kCoordBias) | ((unsigned long long)(uint32_t)(x2 + kCoordBias) << 20) | ((unsigned long long)(uint32_t)(y2 + kCoordBias) << 40);
   pk.a0 = r.a0; pk.dzdx = r.dzdx; pk.dzdy = r.dzdy; pk.order = order;
   return true;
 }
@@ -524,8 +527,8 @@ __device__ __forceinline__ bool make_record(Win v0, Win v1, Win v2, uint32_t ord
 __device__ __forceinline__ TriRec unpack_record(const PackedTri& pk, int width, int height)
 {
   TriRec r;
-  const int x0 = (int)(pk.v01 & 0xfffffu) - 128, y0 = (int)((pk.v01 >> 20) & 0xfffffu) - 128, x1 = (int)((pk.v01 >> 40) & 0xfffffu) - 128;
-  const int y1 = (int)(pk.v12 & 0xfffffu) - 128, x2 = (int)((pk.v12 >> 20) & 0xfffffu) - 128, y2 = (int)((pk.v12 >> 40) & 0xfffffu) - 128;
+  const int x0 = (int)(pk.v01 & 0xfffffu) - kCoordBias, y0 = (int)((pk.v01 >> 20) & 0xfffffu) - kCoordBias, x1 = (int)((pk.v01 >> 40) & 0xfffffu) - kCoordBias;
+  const int y1 = (int)(pk.v12 & 0xfffffu) - kCoordBias, x2 = (int)((pk.v12 >> 20) & 0xfffffu) - kCoordBias, y2 = (int)((pk.v12 >> 40) & 0xfffffu) - kCoordBias;
   edges_from_snapped(x0, y0, x1, y1, x2, y2, width, height, r);
   r.a0 = pk.a0; r.dzdx = pk.dzdx; r.dzdy = pk.dzdy; r.order = pk.order; r.pad = 0;
   return r;

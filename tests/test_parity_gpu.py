@@ -568,6 +568,37 @@ def test_largest_frame_and_model_without_triangles():
     ctx.close()
 
 
+def test_clipper_vertex_just_outside_the_frustum():
+    """Found by scripts/fuzz_parity.py (scene seed 100008): a screen-filling triangle that crosses four frustum
+    planes.  The clipper's interpolation is rounded, so one of its vertices lands at window x = -0.0022, which
+    snaps to -129/256 px -- one unit below what an in-frustum vertex can reach.  The packed bin records used to
+    assume >= -128 and lost the two sub-triangles that use the vertex (83,882 wrong pixels)."""
+    W, H = 1000, 700
+    P = [-1.8051159391028662, 0.0, 0.0, 0.0, 0.0, 2.507749909440404, 0.0, 0.0, 0.01473850902399576, 0.0036142699082903906, -1.0253164556962024, -1.0, 0.0, 0.0, -0.20253164556962025, 0.0]
+    tf = [-0.612386267094772, 0.7155033584275173, -0.3362112489978207, 0.0, -0.32698724997434814, 0.1579548107057661, 0.9317347348516738, 0.0, 0.7197655161425449, 0.6805183479185917, 0.13723111862185855, 0.0, -1.3332428308938, 0.1446924454905245, 1.8375672740901197, 1.0]
+    offinv = [1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.04031177960767986, 0.048556481330739414, -0.02706193609240065, 1.0]
+    camtf = [0.9993483173213057, 0.0, -0.03609626943431724, 0.0, 0.0, 1.0, 0.0, 0.0, 0.03609626943431724, 0.0, 0.9993483173213057, 0.0, -0.12102787878760611, -0.10111147367741508, 0.06291488458101735, 1.0]
+    v = np.array([[-1.829869031906128, -6.280371189117432, -2.3235292434692383], [-4.480249404907227, 1.0303295850753784, 7.6488237380981445],
+                  [4.771854877471924, 1.2539631128311157, -1.0451332330703735]], np.float32)
+    t = np.array([[0, 1, 2]], np.uint32)
+    op = [0.09092016518115997, -0.024322213605046272, 0.14942046999931335]
+    depth = S.sensor_depth(W, H, 8.0)
+    om, ok, zwin, prim, dbg = O.filter_frame(depth, P, [(tf, 2, op, v, t)], offinv, camtf, max_diff=0.05, replace_value=5.0, want_debug=True)
+    assert (prim >= 0).sum() > 300000                      # the triangle covers half the frame
+    for two_kernel in (False, True):
+        ctx = R.Context(W, H, 1, 0, params(5.0, 0.05, two_kernel))
+        m = ctx.add_model()
+        ctx.add_draw(m, ctx.add_link(m), v, t, 2, op)
+        ctx.finalize_models()
+        ctx.set_camera(0, P, offinv, camtf)
+        ctx.set_link_poses(0, m, np.stack([np.array(tf)]))
+        masked, mask = ctx.filter_batch(depth[None])
+        assert (ok != mask[0]).sum() == 0 and bits_equal(om, masked[0])
+        if two_kernel:
+            assert bits_equal(ctx.read_zsurface(1)[0], zwin)
+        ctx.close()
+
+
 def test_config_c4_720p_pr2_plus_walls():
     """BASELINE config 4 shape: 1280x720, PR2-like robot + two static wall URDFs (full-screen boxes incl.
     quirk Q1: exercises the large-triangle path), several streams."""
