@@ -1,10 +1,13 @@
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, scenes as S
 import realtime_urdf_filter_amd as R
 from oracle import bindings as O
-seed = int(sys.argv[1]); force_cap = int(sys.argv[2]) if len(sys.argv) > 2 else -1
-sc = seed - 100000
+"""Re-runs one scene of scripts/fuzz_parity.py with details:  python scripts/repro_fuzz_scene.py SEED FIRST_SEED [bin_capacity]
+(SEED as printed by the fuzz run, FIRST_SEED = the fuzz run's second argument)."""
+seed = int(sys.argv[1]); seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0; force_cap = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+sc = seed - seed0
 rng = np.random.default_rng(seed)
 W = int(rng.choice([64, 150, 160, 320, 333, 640, 1000])); H = int(rng.choice([48, 100, 120, 240, 251, 480, 700]))
 f = float(rng.uniform(0.6, 1.6)) * 525.0 * W / 640
