@@ -53,3 +53,11 @@ def test_fuzz_parity_sample():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "80", "777"], capture_output=True, text=True, cwd=ROOT, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert "streams with mismatches 0" in r.stdout
+
+
+def test_fuzz_features_sample():
+    """A sample of scripts/fuzz_features.py: streams 1-9, several models with per-stream selection, primitives
+    and multi-chunk meshes, 16UC1, optional mask, several launch groups per batch, both modes."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_features.py"), "60", "4242"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "streams with mismatches 0" in r.stdout
