@@ -599,6 +599,43 @@ def test_clipper_vertex_just_outside_the_frustum():
         ctx.close()
 
 
+def test_fragment_bin_and_clip_list_overflow_regrow():
+    """Capacity stress: (a) 60,000 two-pixel triangles piled onto one 64x32 tile overflow that tile's fragment
+    bin (and its record bin), (b) 120,000 triangles that all cross the near plane overflow the clip list; both
+    are detected from the batch's counters, the buffers grow, the batch runs again and matches the oracle."""
+    W, H = 256, 128
+    P = S.projection(210.0, 210.0, (W - 1) / 2, (H - 1) / 2, W, H)
+    I = S.gl(np.eye(4))
+    depth = S.sensor_depth(W, H, 0.9)
+    rng = np.random.default_rng(99)
+    # (a) dust in a 0.05 x 0.03 m window at 1 m: about 10 x 6 pixels wide, thousands of layers
+    n = 60000
+    centre = np.stack([rng.uniform(-0.02, 0.03, n), rng.uniform(-0.02, 0.01, n), rng.uniform(0.9, 1.1, n)], axis=1)
+    va = (centre[:, None, :] + rng.normal(scale=0.006, size=(n, 3, 3))).reshape(-1, 3).astype(np.float32)
+    # (b) long needles from in front of the camera to behind it
+    n2 = 120000
+    a = np.stack([rng.uniform(-0.3, 0.3, n2), rng.uniform(-0.2, 0.2, n2), rng.uniform(0.3, 2.0, n2)], axis=1)
+    b = a + np.stack([rng.normal(scale=0.01, size=n2), rng.normal(scale=0.01, size=n2), -rng.uniform(2.5, 4.0, n2)], axis=1)
+    c = a + rng.normal(scale=0.004, size=(n2, 3))
+    vb = np.stack([a, b, c], axis=1).reshape(-1, 3).astype(np.float32)
+    for verts in (va, vb):
+        tris = np.arange(len(verts), dtype=np.uint32).reshape(-1, 3)
+        om, ok = O.filter_frame(depth, P, [(I, 0, [0.0, 0.0, 0.0], verts, tris)], I, I, replace_value=5.0)
+        ctx = R.Context(W, H, 1, 0, params(5.0, 0.05))
+        m = ctx.add_model()
+        ctx.add_draw(m, ctx.add_link(m), verts, tris, 0, [0.0, 0.0, 0.0])
+        ctx.finalize_models()
+        ctx.set_camera(0, P, I, I)
+        ctx.set_link_poses(0, m, np.stack([I]))
+        masked, mask = ctx.filter_batch(depth[None])
+        st = ctx.stats()
+        assert st["regrowths"] >= 1, st
+        assert (ok != mask[0]).sum() == 0 and bits_equal(om, masked[0])
+        masked, mask = ctx.filter_batch(depth[None])                 # steady state: no further growth, same result
+        assert ctx.stats()["regrowths"] == st["regrowths"] and (ok != mask[0]).sum() == 0 and bits_equal(om, masked[0])
+        ctx.close()
+
+
 def test_config_c4_720p_pr2_plus_walls():
     """BASELINE config 4 shape: 1280x720, PR2-like robot + two static wall URDFs (full-screen boxes incl.
     quirk Q1: exercises the large-triangle path), several streams."""
