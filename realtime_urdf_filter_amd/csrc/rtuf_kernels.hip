@@ -547,7 +547,7 @@ __device__ __forceinline__ void store_record(PackedTri* dst, const PackedTri& r)
 // atomic round trip instead of 49 serial ones in a single lane.
 constexpr int kCoopTiles = 4;
 #ifndef RTUF_FRONT_AREA
-#define RTUF_FRONT_AREA 16
+#define RTUF_FRONT_AREA 24
 #endif
 constexpr int kFrontArea = RTUF_FRONT_AREA;      // boxes up to this many pixel centres are binned from the front of a bin
 __device__ __forceinline__ uint32_t emit_big_records_wave(const SetupArgs& a, int slot, bool big, uint32_t bbx, uint32_t bby,
