@@ -16,8 +16,11 @@ bad_total = 0
 t0 = time.time()
 for sc in range(n_scenes):
     rng = np.random.default_rng(seed0 + sc)
-    W = int(rng.choice([64, 150, 160, 320, 333, 640, 1000]))
-    H = int(rng.choice([48, 100, 120, 240, 251, 480, 700]))
+    if os.environ.get("FUZZ_BIG"):        # the largest frames the ABI accepts: integer ranges at their limits
+        W = int(rng.choice([1280, 1920, 2047, 2048])); H = int(rng.choice([1080, 1536, 2048]))
+    else:
+        W = int(rng.choice([64, 150, 160, 320, 333, 640, 1000]))
+        H = int(rng.choice([48, 100, 120, 240, 251, 480, 700]))
     f = float(rng.uniform(0.6, 1.6)) * 525.0 * W / 640
     P = S.projection(f, f * float(rng.uniform(0.9, 1.1)), (W - 1) / 2 + float(rng.uniform(-20, 20)), (H - 1) / 2 + float(rng.uniform(-20, 20)), W, H)
     n_links = int(rng.integers(1, 6))
