@@ -85,7 +85,9 @@ void rtuf_destroy(rtuf_context *ctx);
 const char *rtuf_last_error(const rtuf_context *ctx);
 
 /* Uniforms can change between frames like the public data members of the reference
- * (include/realtime_urdf_filter/urdf_filter.h:112-135). */
+ * (include/realtime_urdf_filter/urdf_filter.h:112-135).  far_plane is the exception: the background
+ * quad is part of the finalized geometry, so changing it after rtuf_finalize_models returns
+ * RTUF_ERR_STATE. */
 int rtuf_set_params(rtuf_context *ctx, const rtuf_params *params);
 
 /* ---- geometry: loaded once into device buffers ------------------------------------

@@ -247,6 +247,9 @@ int rtuf_set_params(rtuf_context* c, const rtuf_params* p)
 {
   if (!c || !p) return RTUF_ERR_INVALID;
   WAIT_IF_PENDING(c);
+  // the background quad's geometry (0.99 * far, src/urdf_filter.cpp:591-596) is built by rtuf_finalize_models
+  if (c->finalized && p->far_plane != c->params.far_plane)
+    return c->fail(RTUF_ERR_STATE, "far_plane is fixed once the models are finalized (was %g)", (double)c->params.far_plane);
   const uint32_t keep_cap = c->params.bin_capacity, keep_inf = c->params.max_inflight_streams;
   const bool two_before = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
   c->params = *p;

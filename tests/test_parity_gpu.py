@@ -203,6 +203,37 @@ def test_single_stream_filter_api_and_errors():
     ctx.close()
 
 
+def test_set_params_between_frames():
+    """Threshold, replace value and near plane are plain uniforms that may change between frames
+    (include/realtime_urdf_filter/urdf_filter.h:112-135); the far plane is part of the finalized
+    background quad and is refused afterwards."""
+    fx = golden_io.Fixture("soup_seed11_160x120")
+    ctx = R.Context(fx.width, fx.height, 1, 0, params(fx.replace_value, fx.max_diff))
+    m, tfs = fx.load_into(ctx)
+    ctx.set_camera(0, None, fx.offset_inv, fx.cam_tf)
+    ctx.set_link_poses(0, m, tfs)
+    masked, mask = ctx.filter(fx.depth, fx.projection)
+    fx.check(masked, mask)
+    seen = set()
+    for thr, rep, near in ((0.3, -1.0, 0.1), (0.001, 7.5, 0.25), (fx.max_diff, fx.replace_value, 0.1)):
+        p = params(rep, thr, near_plane=near)
+        ctx.set_params(p)
+        masked, mask = ctx.filter(fx.depth, fx.projection)
+        om, ok = O.filter_frame(fx.depth, fx.projection, fx.draws, fx.offset_inv, fx.cam_tf, z_near=near,
+                                max_diff=thr, replace_value=rep)
+        assert np.array_equal(mask, ok)
+        assert np.array_equal(masked.view(np.uint32), om.view(np.uint32))
+        seen.add(int(ok.astype(bool).sum()))
+    assert len(seen) == 3                          # the three settings really classify differently
+    fx.check(masked, mask)                         # back at the fixture's settings
+    with pytest.raises(R.RtufError) as e:
+        ctx.set_params(params(fx.replace_value, fx.max_diff, far_plane=6.0))
+    assert e.value.code == -6
+    masked, mask = ctx.filter(fx.depth, fx.projection)      # the refused call left the context usable
+    fx.check(masked, mask)
+    ctx.close()
+
+
 def test_host_mirror_end_to_end_example_urdf():
     """URDF text -> URDFRenderer -> RealtimeURDFFilter.filter() on the GPU == the reference's output for
     urdf/example.urdf.xml (golden fixture of BASELINE config C1)."""
