@@ -184,6 +184,23 @@ int rtuf_filter_batch_device(rtuf_context *ctx, int n_streams, const float *d_de
  * HBM and PCIe bytes per pixel (5 instead of 9). */
 int rtuf_filter_batch_u16(rtuf_context *ctx, int n_streams, const uint16_t *const *depth_mm_in,
                           uint16_t *const *masked_mm_out, uint8_t *const *mask_out);
+/* Asynchronous forms of the two host-plane calls: the planes go up on one copy stream and come back on
+ * another, so with two batches in flight the PCIe transfers of one overlap the kernels of the other
+ * (the reference uploads, renders and reads back serially: src/urdf_filter.cpp:332-353, :729-735).
+ * All planes of a batch must stay valid until it is retired -- by rtuf_wait_oldest, rtuf_sync, or
+ * the second-next asynchronous call -- and should be pinned memory (rtuf_host_alloc); with pageable
+ * memory the calls are correct but block for the transfers.  Planes that follow each other in memory
+ * are moved as one transfer. */
+int rtuf_filter_batch_async(rtuf_context *ctx, int n_streams, const float *const *depth_in,
+                            float *const *masked_out, uint8_t *const *mask_out);
+int rtuf_filter_batch_u16_async(rtuf_context *ctx, int n_streams, const uint16_t *const *depth_mm_in,
+                                uint16_t *const *masked_mm_out, uint8_t *const *mask_out);
+/* Waits for the oldest batch in flight (device or host planes); its outputs are complete afterwards.
+ * RTUF_OK when nothing is pending. */
+int rtuf_wait_oldest(rtuf_context *ctx);
+/* Pinned host memory for the asynchronous calls.  rtuf_host_free waits for the batches in flight. */
+int rtuf_host_alloc(rtuf_context *ctx, size_t bytes, void **out);
+int rtuf_host_free(rtuf_context *ctx, void *ptr);
 int rtuf_filter_batch_device_u16(rtuf_context *ctx, int n_streams, const uint16_t *d_depth_mm,
                                  uint16_t *d_masked_mm, uint8_t *d_mask);
 /* Exact single-stream shape of RealtimeURDFFilter::filter(buffer, glTf, w, h)

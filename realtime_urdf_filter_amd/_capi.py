@@ -26,6 +26,7 @@ SYMBOLS = [
     "rtuf_projection_from_intrinsics", "rtuf_set_link_poses", "rtuf_set_cameras", "rtuf_set_link_poses_batch", "rtuf_set_kinematics", "rtuf_set_joint_positions", "rtuf_debug_read_poses", "rtuf_filter_batch",
     "rtuf_filter_batch_device", "rtuf_filter_batch_u16", "rtuf_filter_batch_device_u16", "rtuf_filter", "rtuf_get_masked_depth", "rtuf_get_mask", "rtuf_sync",
     "rtuf_stream", "rtuf_get_stats", "rtuf_enable_timing", "rtuf_debug_read_zsurface",
+    "rtuf_filter_batch_async", "rtuf_filter_batch_u16_async", "rtuf_wait_oldest", "rtuf_host_alloc", "rtuf_host_free",
 ]
 
 
@@ -59,6 +60,28 @@ class RtufError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  A ROCm PyTorch wheel carries its own libamdhip64 / libhsa-runtime64 and
+    loads them by path on `import torch`; librtuf.so is linked against the same soname (libamdhip64.so.7), so
+    whichever of the two is loaded first decides which runtime librtuf binds to -- and if that is the system
+    copy, torch later brings a second runtime into the process, which finds no GPU.  When such a wheel is
+    installed and torch is not loaded yet, its runtime is mapped first (without importing torch), so both
+    orders of use end up on the same runtime.  Without PyTorch the system runtime (/opt/rocm) is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    hip = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        ctypes.CDLL(hip, mode=ctypes.RTLD_GLOBAL)
+
+
 def load_library(path=None):
     """Loads librtuf.so (no GPU needed for loading; rtuf_create needs one)."""
     global _lib
@@ -68,6 +91,7 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise RtufError(-100, "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(there is no CPU fallback)" % p)
+    _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(p)
     vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
     lib.rtuf_default_params.argtypes = [ctypes.POINTER(Params)]
@@ -111,6 +135,11 @@ def load_library(path=None):
     lib.rtuf_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     lib.rtuf_enable_timing.argtypes = [vp, ci]
     lib.rtuf_debug_read_zsurface.argtypes = [vp, ci, vp]
+    lib.rtuf_filter_batch_async.argtypes = [vp, ci, vp, vp, vp]
+    lib.rtuf_filter_batch_u16_async.argtypes = [vp, ci, vp, vp, vp]
+    lib.rtuf_wait_oldest.argtypes = [vp]
+    lib.rtuf_host_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.rtuf_host_free.argtypes = [vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -147,6 +176,7 @@ class Context:
         if rc != RTUF_OK:
             raise RtufError(rc, self._lib.rtuf_last_error(None).decode())
         self.params = p
+        self._pinned = {}           # host_alloc() blocks: array address -> pointer
 
     def _check(self, rc):
         if rc < 0:
@@ -155,8 +185,9 @@ class Context:
 
     def close(self):
         if self._h:
-            self._lib.rtuf_destroy(self._h)
+            self._lib.rtuf_destroy(self._h)          # also releases host_alloc() blocks still held
             self._h = ctypes.c_void_p()
+            self._pinned = {}
 
     def __del__(self):
         try:
@@ -259,6 +290,40 @@ class Context:
         kout = PP(*[mask[i].ctypes.data for i in range(n)]) if want_mask else None
         self._check(self._lib.rtuf_filter_batch_u16(self._h, n, din, mout, kout))
         return masked, mask
+
+    # asynchronous host planes
+    def host_alloc(self, shape, dtype):
+        """Pinned host array (rtuf_host_alloc) for filter_batch_async; release with host_free()."""
+        dt = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dt.itemsize
+        p = ctypes.c_void_p()
+        self._check(self._lib.rtuf_host_alloc(self._h, nbytes, ctypes.byref(p)))
+        buf = (ctypes.c_char * nbytes).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dt).reshape(shape)
+        self._pinned[a.ctypes.data] = p.value
+        return a
+
+    def host_free(self, a):
+        p = self._pinned.pop(a.ctypes.data)
+        self._check(self._lib.rtuf_host_free(self._h, ctypes.c_void_p(p)))
+
+    def filter_batch_async(self, depth, masked, mask=None):
+        """Enqueue only: depth / masked [n,H,W] float32 (or uint16 for 16UC1) host arrays, mask [n,H,W] u8 or
+        None; the arrays must stay alive and untouched until wait_oldest() / sync() retires the batch."""
+        n = depth.shape[0]
+        u16 = depth.dtype == np.uint16
+        assert depth.flags.c_contiguous and masked.flags.c_contiguous and masked.dtype == depth.dtype
+        assert depth.dtype in (np.float32, np.uint16) and depth.shape == (n, self.height, self.width) == masked.shape
+        assert mask is None or (mask.flags.c_contiguous and mask.dtype == np.uint8 and mask.shape == depth.shape)
+        PP = ctypes.c_void_p * n
+        din = PP(*[depth[i].ctypes.data for i in range(n)])
+        mout = PP(*[masked[i].ctypes.data for i in range(n)])
+        kout = PP(*[mask[i].ctypes.data for i in range(n)]) if mask is not None else None
+        fn = self._lib.rtuf_filter_batch_u16_async if u16 else self._lib.rtuf_filter_batch_async
+        self._check(fn(self._h, n, din, mout, kout))
+
+    def wait_oldest(self):
+        self._check(self._lib.rtuf_wait_oldest(self._h))
 
     def filter_batch_device_u16(self, n, d_depth, d_masked, d_mask=None):
         self._check(self._lib.rtuf_filter_batch_device_u16(self._h, n, ctypes.c_void_p(d_depth), ctypes.c_void_p(d_masked),

@@ -85,8 +85,8 @@ struct rtuf_context {
   float* d_zsurface = nullptr;
 
   // staging for the host-pointer API
-  float* d_depth = nullptr; float* d_masked = nullptr; uint8_t* d_mask = nullptr;
-  size_t staged_streams = 0;
+  hipStream_t h2d = nullptr, d2h = nullptr;  // copy streams of the host-plane calls (rtuf_filter_batch*)
+  std::vector<void*> pinned;                 // rtuf_host_alloc blocks not yet freed
 
   // single-stream outputs (masked_depth_ / mask_ of the reference)
   std::vector<float> single_masked; std::vector<uint8_t> single_mask;
@@ -112,6 +112,12 @@ struct rtuf_context {
     hipEvent_t posed = nullptr;              // recorded on the side stream after the pose stage
     uint32_t setup_grid = 0xffffffffu;       // work items the set-up launch covered (single-group batches)
     int timing = 0;                          // event timing of this batch: 0 none, 1 every stage, 2 tile/compare kernel only
+    // Host-plane batches (rtuf_filter_batch*): device staging of this slot, the caller's planes, and the
+    // events that order upload -> kernels -> download across the copy streams.
+    bool host_io = false;
+    float* st_depth = nullptr; float* st_masked = nullptr; uint8_t* st_mask = nullptr; size_t st_streams = 0;
+    std::vector<void*> h_masked, h_mask;
+    hipEvent_t uploaded = nullptr, downloaded = nullptr;
   };
   Batch batch[kMaxInflight];
   hipStream_t side = nullptr;                // pose stages (see Batch)
@@ -210,10 +216,9 @@ static void free_frame_buffers(rtuf_context* c)
   dfree(c->d_model_mask);
   for (auto& b : c->batch) { dfree(b.d_cams); dfree(b.d_link_tf); dfree(b.d_mvp); dfree(b.d_bg); dfree(b.d_items); dfree(b.d_counters); }
   dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_zsurface);
-  dfree(c->d_depth); dfree(c->d_masked); dfree(c->d_mask);
+  for (auto& b : c->batch) { dfree(b.st_depth); dfree(b.st_masked); dfree(b.st_mask); b.st_streams = 0; }
   hfree(c->h_cams); hfree(c->h_link_tf); hfree(c->h_model_mask);
   for (auto& b : c->batch) hfree(b.h_counters);
-  c->staged_streams = 0;
 }
 
 void rtuf_destroy(rtuf_context* c)
@@ -222,6 +227,8 @@ void rtuf_destroy(rtuf_context* c)
   hipSetDevice(c->device);
   if (c->side) hipStreamSynchronize(c->side);
   if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->h2d) hipStreamSynchronize(c->h2d);
+  if (c->d2h) hipStreamSynchronize(c->d2h);
   for (HostModel& m : c->models) {
     Kinematics& k = m.kin;
     hipFree(k.d_depth); hipFree(k.d_parent); hipFree(k.d_type); hipFree(k.d_origin); hipFree(k.d_axis); hipFree(k.d_link_frame); hipFree(k.d_link_offset);
@@ -237,7 +244,12 @@ void rtuf_destroy(rtuf_context* c)
     for (hipEvent_t ev : b.events) hipEventDestroy(ev);
     if (b.done) hipEventDestroy(b.done);
     if (b.posed) hipEventDestroy(b.posed);
+    if (b.uploaded) hipEventDestroy(b.uploaded);
+    if (b.downloaded) hipEventDestroy(b.downloaded);
   }
+  for (void* p : c->pinned) hipHostFree(p);
+  if (c->h2d) hipStreamDestroy(c->h2d);
+  if (c->d2h) hipStreamDestroy(c->d2h);
   if (c->side) hipStreamDestroy(c->side);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -900,6 +912,30 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
 
 // Retires the oldest batch in flight: waits for it, reads its counters, and if a bin or the clip list
 // overflowed, enlarges them and runs that batch and every later one again (their inputs are intact).
+// Copies the results of a host-plane batch to the caller's planes on the download stream, after the
+// batch's kernels; consecutive planes go out as one transfer.
+static int enqueue_download(rtuf_context* c, rtuf_context::Batch& b)
+{
+  const size_t plane = (size_t)c->width * c->height;
+  const size_t esz = b.u16 ? sizeof(uint16_t) : sizeof(float);
+  HIP_TRY(c, hipStreamWaitEvent(c->d2h, b.done, 0));
+  for (int s = 0; s < b.n;) {
+    int e = s + 1;
+    while (e < b.n && (char*)b.h_masked[e] == (char*)b.h_masked[e - 1] + plane * esz) e++;
+    HIP_TRY(c, hipMemcpyAsync(b.h_masked[s], (char*)b.st_masked + (size_t)s * plane * esz, (size_t)(e - s) * plane * esz, hipMemcpyDeviceToHost, c->d2h));
+    s = e;
+  }
+  for (int s = 0; s < b.n;) {
+    if (!b.h_mask[s]) { s++; continue; }
+    int e = s + 1;
+    while (e < b.n && b.h_mask[e] && (char*)b.h_mask[e] == (char*)b.h_mask[e - 1] + plane) e++;
+    HIP_TRY(c, hipMemcpyAsync(b.h_mask[s], b.st_mask + (size_t)s * plane, (size_t)(e - s) * plane, hipMemcpyDeviceToHost, c->d2h));
+    s = e;
+  }
+  HIP_TRY(c, hipEventRecord(b.downloaded, c->d2h));
+  return RTUF_OK;
+}
+
 static int retire_oldest(rtuf_context* c)
 {
   for (int attempt = 0; attempt < 8; attempt++) {
@@ -927,6 +963,7 @@ static int retire_oldest(rtuf_context* c)
     const bool list_over = b.h_counters->work.n_items > b.setup_grid;     // the set-up grid was sized too small
     if (list_over) c->stats.regrowths++;
     if (!bin_over && !clip_over && !list_over) {
+      if (b.host_io) HIP_TRY(c, hipEventSynchronize(b.downloaded));
       if (b.timing == 1 && b.events.size() >= 2) {
         // events: [start, pose_end, (setup_end, tile_end, compare_end) per group ...]
         float ms = 0;
@@ -967,6 +1004,7 @@ static int retire_oldest(rtuf_context* c)
     }
     // overflow: wait for the later batches too, enlarge, and run everything in flight again in order
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d2h) HIP_TRY(c, hipStreamSynchronize(c->d2h));
     if (bin_over) { const int rc = grow_bins(c, k.max_bin_fill, k.max_fbin_fill); if (rc != RTUF_OK) { for (auto& o : c->batch) o.active = false; c->pending = 0; return rc; } }
     if (clip_over) {
       hipFree(c->d_clip_list); c->d_clip_list = nullptr;
@@ -978,7 +1016,9 @@ static int retire_oldest(rtuf_context* c)
     HIP_TRY(c, hipMemsetAsync(c->d_bin_count, 0, (size_t)c->group * tiles * 2 * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_fbin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->stream));
     for (int i = 0; i < c->pending; i++) {
-      const int rc = enqueue_batch(c, c->batch[(c->oldest + i) % kMaxInflight], true);
+      rtuf_context::Batch& r = c->batch[(c->oldest + i) % kMaxInflight];
+      int rc = enqueue_batch(c, r, true);
+      if (rc == RTUF_OK && r.host_io) rc = enqueue_download(c, r);
       if (rc != RTUF_OK) { for (auto& o : c->batch) o.active = false; c->pending = 0; return rc; }
     }
   }
@@ -996,7 +1036,7 @@ static int submit_batch(rtuf_context* c, int n, const float* d_depth, float* d_m
   const int limit = (c->params.flags & RTUF_FLAG_TWO_KERNEL) ? 1 : kMaxInflight;
   while (c->pending >= limit) { const int rc = retire_oldest(c); if (rc != RTUF_OK) return rc; }
   rtuf_context::Batch& b = c->batch[(c->oldest + c->pending) % kMaxInflight];
-  b.n = n; b.depth = d_depth; b.masked = d_masked; b.mask = d_mask; b.u16 = u16;
+  b.n = n; b.depth = d_depth; b.masked = d_masked; b.mask = d_mask; b.u16 = u16; b.host_io = false;
   const int rc = enqueue_batch(c, b, false);
   if (rc == RTUF_OK) { b.active = true; c->pending++; }
   return rc;
@@ -1030,75 +1070,114 @@ int rtuf_sync(rtuf_context* c)
 
 void* rtuf_stream(rtuf_context* c) { return c ? (void*)c->stream : nullptr; }
 
-static int ensure_staging(rtuf_context* c, size_t n)
+// ---- host planes -----------------------------------------------------------------------------------
+// The reference's filter() takes a host buffer and leaves host results (src/urdf_filter.cpp:233-234,
+// :729-735).  Here the planes of a batch go up on one copy stream and come back on another, so with two
+// batches in flight the transfers of one overlap the kernels of the other; every slot has its own
+// device staging.
+static int submit_host_batch(rtuf_context* c, int n, const void* const* depth_in, void* const* masked_out,
+                             void* const* mask_out, bool u16)
 {
-  if (c->staged_streams >= n) return RTUF_OK;
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (n <= 0 || n > c->max_streams || !depth_in || !masked_out) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
+  if (u16 && (c->width & 3)) return c->fail(RTUF_ERR_INVALID, "16UC1 path needs a width that is a multiple of 4");
+  for (int s = 0; s < n; s++)
+    if (!depth_in[s] || !masked_out[s]) return c->fail(RTUF_ERR_INVALID, "null plane for stream %d", s);
+  hipSetDevice(c->device);
+  if (!c->h2d) HIP_TRY(c, hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking));
+  if (!c->d2h) HIP_TRY(c, hipStreamCreateWithFlags(&c->d2h, hipStreamNonBlocking));
+  const int limit = (c->params.flags & RTUF_FLAG_TWO_KERNEL) ? 1 : kMaxInflight;
+  while (c->pending >= limit) { const int rc = retire_oldest(c); if (rc != RTUF_OK) return rc; }
+  rtuf_context::Batch& b = c->batch[(c->oldest + c->pending) % kMaxInflight];     // the slot submit_batch takes next
   const size_t plane = (size_t)c->width * c->height;
-  if (c->d_depth) { hipFree(c->d_depth); hipFree(c->d_masked); hipFree(c->d_mask); c->d_depth = nullptr; c->d_masked = nullptr; c->d_mask = nullptr; }
-  HIP_TRY(c, hipMalloc(&c->d_depth, n * plane * sizeof(float)));
-  HIP_TRY(c, hipMalloc(&c->d_masked, n * plane * sizeof(float)));
-  HIP_TRY(c, hipMalloc(&c->d_mask, n * plane));
-  c->staged_streams = n;
-  return RTUF_OK;
+  if (b.st_streams < (size_t)n) {
+    if (b.st_depth) { hipFree(b.st_depth); hipFree(b.st_masked); hipFree(b.st_mask); b.st_depth = nullptr; b.st_masked = nullptr; b.st_mask = nullptr; }
+    b.st_streams = 0;
+    HIP_TRY(c, hipMalloc(&b.st_depth, (size_t)n * plane * sizeof(float)));     // float-sized: large enough for uint16 planes
+    HIP_TRY(c, hipMalloc(&b.st_masked, (size_t)n * plane * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&b.st_mask, (size_t)n * plane));
+    b.st_streams = (size_t)n;
+  }
+  if (!b.uploaded) HIP_TRY(c, hipEventCreateWithFlags(&b.uploaded, hipEventDisableTiming));
+  if (!b.downloaded) HIP_TRY(c, hipEventCreateWithFlags(&b.downloaded, hipEventDisableTiming));
+  const size_t esz = u16 ? sizeof(uint16_t) : sizeof(float);
+  for (int s = 0; s < n;) {
+    int e = s + 1;
+    while (e < n && (const char*)depth_in[e] == (const char*)depth_in[e - 1] + plane * esz) e++;
+    HIP_TRY(c, hipMemcpyAsync((char*)b.st_depth + (size_t)s * plane * esz, depth_in[s], (size_t)(e - s) * plane * esz, hipMemcpyHostToDevice, c->h2d));
+    s = e;
+  }
+  HIP_TRY(c, hipEventRecord(b.uploaded, c->h2d));
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, b.uploaded, 0));
+  bool any_mask = false;
+  b.h_masked.assign(masked_out, masked_out + n);
+  b.h_mask.assign((size_t)n, nullptr);
+  if (mask_out) for (int s = 0; s < n; s++) { b.h_mask[s] = mask_out[s]; any_mask |= mask_out[s] != nullptr; }
+  int rc = submit_batch(c, n, b.st_depth, b.st_masked, any_mask ? b.st_mask : nullptr, u16);
+  if (rc != RTUF_OK) return rc;
+  b.host_io = true;
+  return enqueue_download(c, b);
+}
+
+int rtuf_filter_batch_async(rtuf_context* c, int n, const float* const* depth_in, float* const* masked_out,
+                            uint8_t* const* mask_out)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  return submit_host_batch(c, n, reinterpret_cast<const void* const*>(depth_in), reinterpret_cast<void* const*>(masked_out),
+                           reinterpret_cast<void* const*>(mask_out), false);
+}
+
+int rtuf_filter_batch_u16_async(rtuf_context* c, int n, const uint16_t* const* depth_in, uint16_t* const* masked_out,
+                                uint8_t* const* mask_out)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  return submit_host_batch(c, n, reinterpret_cast<const void* const*>(depth_in), reinterpret_cast<void* const*>(masked_out),
+                           reinterpret_cast<void* const*>(mask_out), true);
 }
 
 int rtuf_filter_batch(rtuf_context* c, int n, const float* const* depth_in, float* const* masked_out,
                       uint8_t* const* mask_out)
 {
-  if (!c) return RTUF_ERR_INVALID;
-  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
-  if (n <= 0 || n > c->max_streams || !depth_in || !masked_out) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
-  hipSetDevice(c->device);
-  int rc = ensure_staging(c, (size_t)n);
-  if (rc != RTUF_OK) return rc;
-  const size_t plane = (size_t)c->width * c->height;
-  for (int s = 0; s < n; s++) {
-    if (!depth_in[s] || !masked_out[s]) return c->fail(RTUF_ERR_INVALID, "null plane for stream %d", s);
-    HIP_TRY(c, hipMemcpyAsync(c->d_depth + s * plane, depth_in[s], plane * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  }
-  bool any_mask = false;
-  if (mask_out) for (int s = 0; s < n; s++) any_mask |= mask_out[s] != nullptr;
-  rc = rtuf_filter_batch_device(c, n, c->d_depth, c->d_masked, any_mask ? c->d_mask : nullptr);
-  if (rc != RTUF_OK) return rc;
-  rc = rtuf_sync(c);
-  if (rc != RTUF_OK) return rc;
-  for (int s = 0; s < n; s++) {
-    HIP_TRY(c, hipMemcpyAsync(masked_out[s], c->d_masked + s * plane, plane * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    if (mask_out && mask_out[s])
-      HIP_TRY(c, hipMemcpyAsync(mask_out[s], c->d_mask + s * plane, plane, hipMemcpyDeviceToHost, c->stream));
-  }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return RTUF_OK;
+  const int rc = rtuf_filter_batch_async(c, n, depth_in, masked_out, mask_out);
+  return rc != RTUF_OK ? rc : rtuf_sync(c);
 }
 
 int rtuf_filter_batch_u16(rtuf_context* c, int n, const uint16_t* const* depth_in, uint16_t* const* masked_out,
                           uint8_t* const* mask_out)
 {
+  const int rc = rtuf_filter_batch_u16_async(c, n, depth_in, masked_out, mask_out);
+  return rc != RTUF_OK ? rc : rtuf_sync(c);
+}
+
+int rtuf_wait_oldest(rtuf_context* c)
+{
   if (!c) return RTUF_ERR_INVALID;
-  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
-  if (n <= 0 || n > c->max_streams || !depth_in || !masked_out) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
   hipSetDevice(c->device);
-  int rc = ensure_staging(c, (size_t)n);       // float-sized staging is large enough for uint16 planes
+  return c->pending ? retire_oldest(c) : RTUF_OK;
+}
+
+int rtuf_host_alloc(rtuf_context* c, size_t bytes, void** out)
+{
+  if (!c || !out || !bytes) return RTUF_ERR_INVALID;
+  hipSetDevice(c->device);
+  void* p = nullptr;
+  HIP_TRY(c, hipHostMalloc(&p, bytes));
+  c->pinned.push_back(p);
+  *out = p;
+  return RTUF_OK;
+}
+
+int rtuf_host_free(rtuf_context* c, void* p)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  if (!p) return RTUF_OK;
+  hipSetDevice(c->device);
+  auto it = std::find(c->pinned.begin(), c->pinned.end(), p);
+  if (it == c->pinned.end()) return c->fail(RTUF_ERR_INVALID, "not a block of rtuf_host_alloc");
+  const int rc = rtuf_sync(c);          // no transfer may still target the block
   if (rc != RTUF_OK) return rc;
-  const size_t plane = (size_t)c->width * c->height;
-  uint16_t* din = reinterpret_cast<uint16_t*>(c->d_depth);
-  uint16_t* dout = reinterpret_cast<uint16_t*>(c->d_masked);
-  for (int s = 0; s < n; s++) {
-    if (!depth_in[s] || !masked_out[s]) return c->fail(RTUF_ERR_INVALID, "null plane for stream %d", s);
-    HIP_TRY(c, hipMemcpyAsync(din + s * plane, depth_in[s], plane * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-  }
-  bool any_mask = false;
-  if (mask_out) for (int s = 0; s < n; s++) any_mask |= mask_out[s] != nullptr;
-  rc = rtuf_filter_batch_device_u16(c, n, din, dout, any_mask ? c->d_mask : nullptr);
-  if (rc != RTUF_OK) return rc;
-  rc = rtuf_sync(c);
-  if (rc != RTUF_OK) return rc;
-  for (int s = 0; s < n; s++) {
-    HIP_TRY(c, hipMemcpyAsync(masked_out[s], dout + s * plane, plane * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
-    if (mask_out && mask_out[s])
-      HIP_TRY(c, hipMemcpyAsync(mask_out[s], c->d_mask + s * plane, plane, hipMemcpyDeviceToHost, c->stream));
-  }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->pinned.erase(it);
+  HIP_TRY(c, hipHostFree(p));
   return RTUF_OK;
 }
 

@@ -70,3 +70,28 @@ def test_product_package_never_touches_the_oracle():
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "oracle" not in txt.replace("the oracle", "").replace("oracle/", "").lower() or "import oracle" not in txt, f
                 assert "from oracle" not in txt and "import oracle" not in txt and "librtuf_oracle" not in txt, f
+
+
+def test_one_hip_runtime_per_process_in_either_import_order():
+    """librtuf.so and a ROCm PyTorch wheel must end up on the same libamdhip64 whichever is used first
+    (two runtimes in one process: the second one finds no GPU)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+order = sys.argv[1]
+def first():
+    import realtime_urdf_filter_amd as R
+    R.load_library()
+def second():
+    import torch
+for f in ((first, second) if order == "rtuf_first" else (second, first)):
+    f()
+libs = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+print(len(libs), libs)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for order in ("rtuf_first", "torch_first"):
+        out = subprocess.run([sys.executable, "-c", code, order], cwd=root, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.split()[0] == "1", (order, out.stdout)

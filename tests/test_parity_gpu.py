@@ -2,6 +2,8 @@
 (outputs of the reference's GLSL on llvmpipe) and (2) the CPU oracle on seeded inputs.
 Bar: bit-exact masks and bit-exact float depth (north_star tolerance for depth is 1e-4; the
 implementation is exact, so the tests demand equality)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -496,6 +498,76 @@ def test_two_batches_in_flight_and_regrowth_reruns_both():
         st = ctx.stats()
         assert (st["regrowths"] > 0) == (cap == 16)
         ctx.close()
+
+
+@pytest.mark.parametrize("cap", [0, 16])
+def test_asynchronous_host_planes(cap):
+    """rtuf_filter_batch_async / _u16_async: host planes go up and come back on copy streams while another
+    batch computes.  Three batches with different joint states and sensor images are enqueued without a wait
+    in between (pinned memory, then pageable memory with planes that are not adjacent); every output must
+    be the oracle's, also when too-small bins force both batches in flight to run again (cap=16)."""
+    n, W, H = 4, 320, 240
+    wls = [WL.pr2_workload(n, W, H, total_triangles=8000, first_state_seed=seed) for seed in (1000, 2000)]
+    A = wls[0]
+    depths = [A.depth_batch(first=0), A.depth_batch(first=11), A.depth_batch(first=23)]
+    order = [wls[0], wls[1], wls[0]]
+
+    def oracle(wl, depth, s):
+        return O.filter_frame(depth[s], wl.projection[s], wl.oracle_draws(s), wl.offset_inv[s], wl.cam_tf[s],
+                              max_diff=wl.max_diff, replace_value=wl.replace_value)
+
+    ctx = R.Context(W, H, n, 0, params(A.replace_value, A.max_diff, bin_capacity=cap))
+    ids = A.load_into(ctx)
+    A.load_kinematics(ctx, ids)
+    pin_in = [ctx.host_alloc((n, H, W), np.float32) for _ in range(3)]
+    pin_out = [ctx.host_alloc((n, H, W), np.float32) for _ in range(3)]
+    pin_mask = [ctx.host_alloc((n, H, W), np.uint8) for _ in range(3)]
+    for i in range(3):
+        pin_in[i][...] = depths[i]
+        pin_out[i][...] = -1.0
+        wl = order[i]
+        wl.stage_joint_positions(ctx, ids, first_call=(i == 0))
+        ctx.filter_batch_async(pin_in[i], pin_out[i], pin_mask[i])     # the third call retires the first
+    ctx.wait_oldest()
+    ctx.wait_oldest()
+    ctx.wait_oldest()                                                   # nothing pending: no-op
+    for i in range(3):
+        for s in range(n):
+            om, ok = oracle(order[i], depths[i], s)
+            assert np.array_equal(ok, pin_mask[i][s]) and bits_equal(om, pin_out[i][s]), (cap, i, s)
+    assert (ctx.stats()["regrowths"] > 0) == (cap == 16)
+
+    # pageable planes scattered in memory, no mask for stream 1, through the raw C ABI
+    lib = R.load_library()
+    planes_in = [depths[1][s].copy() for s in range(n)]
+    planes_out = [np.full((H, W), -1.0, np.float32) for _ in range(n)]
+    planes_mask = [np.full((H, W), 7, np.uint8) for _ in range(n)]
+    PP = ctypes.c_void_p * n
+    wls[1].stage_joint_positions(ctx, ids, first_call=False)
+    rc = lib.rtuf_filter_batch_async(ctx._h, n, PP(*[a.ctypes.data for a in planes_in]), PP(*[a.ctypes.data for a in planes_out]),
+                                     PP(*[(None if s == 1 else planes_mask[s].ctypes.data) for s in range(n)]))
+    assert rc == 0
+    ctx.sync()
+    for s in range(n):
+        om, ok = oracle(wls[1], depths[1], s)
+        assert bits_equal(om, planes_out[s])
+        assert np.array_equal(planes_mask[s], ok) if s != 1 else (planes_mask[s] == 7).all()
+
+    # 16UC1 planes
+    mm = depth_f32_to_u16(np.nan_to_num(depths[2], nan=0.0, posinf=0.0))
+    u_in, u_out = ctx.host_alloc((n, H, W), np.uint16), ctx.host_alloc((n, H, W), np.uint16)
+    u_in[...] = mm
+    wls[0].stage_joint_positions(ctx, ids, first_call=False)
+    ctx.filter_batch_async(u_in, u_out, pin_mask[0])
+    ctx.sync()
+    for s in range(n):
+        om, ok = oracle(wls[0], depth_u16_to_f32(mm), s)
+        assert np.array_equal(ok, pin_mask[0][s]) and np.array_equal(u_out[s], depth_f32_to_u16(om))
+    with pytest.raises(R.RtufError):
+        ctx._check(lib.rtuf_host_free(ctx._h, ctypes.c_void_p(planes_in[0].ctypes.data)))      # not a pinned block
+    for a in pin_in + pin_out + pin_mask[1:] + [u_in]:
+        ctx.host_free(a)
+    ctx.close()                                                          # releases the blocks still held
 
 
 def test_two_contexts_on_one_gpu_interleaved():
