@@ -910,8 +910,6 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
   return RTUF_OK;
 }
 
-// Retires the oldest batch in flight: waits for it, reads its counters, and if a bin or the clip list
-// overflowed, enlarges them and runs that batch and every later one again (their inputs are intact).
 // Copies the results of a host-plane batch to the caller's planes on the download stream, after the
 // batch's kernels; consecutive planes go out as one transfer.
 static int enqueue_download(rtuf_context* c, rtuf_context::Batch& b)
@@ -936,6 +934,8 @@ static int enqueue_download(rtuf_context* c, rtuf_context::Batch& b)
   return RTUF_OK;
 }
 
+// Retires the oldest batch in flight: waits for it, reads its counters, and if a bin or the clip list
+// overflowed, enlarges them and runs that batch and every later one again (their inputs are intact).
 static int retire_oldest(rtuf_context* c)
 {
   for (int attempt = 0; attempt < 8; attempt++) {

@@ -553,6 +553,31 @@ def test_asynchronous_host_planes(cap):
         assert bits_equal(om, planes_out[s])
         assert np.array_equal(planes_mask[s], ok) if s != 1 else (planes_mask[s] == 7).all()
 
+    # a device-plane batch and a host-plane batch in flight together, in both orders
+    import torch
+    dev = torch.device("cuda:0")
+    d_depth = torch.from_numpy(depths[2]).to(dev)
+    d_out = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+    d_mask = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for host_first in (True, False):
+        pin_out[0][...] = -1.0
+        d_out.fill_(-1.0)
+        torch.cuda.synchronize()
+        for kind in (("host", "device") if host_first else ("device", "host")):
+            wl = wls[0] if kind == "host" else wls[1]
+            wl.stage_joint_positions(ctx, ids, first_call=False)
+            if kind == "host":
+                ctx.filter_batch_async(pin_in[0], pin_out[0], pin_mask[0])
+            else:
+                ctx.filter_batch_device(n, d_depth.data_ptr(), d_out.data_ptr(), d_mask.data_ptr())
+        ctx.sync()
+        for s in range(n):
+            om, ok = oracle(wls[0], depths[0], s)
+            assert np.array_equal(ok, pin_mask[0][s]) and bits_equal(om, pin_out[0][s]), (host_first, s)
+            om, ok = oracle(wls[1], depths[2], s)
+            assert np.array_equal(ok, d_mask[s].cpu().numpy()) and bits_equal(om, d_out[s].cpu().numpy()), (host_first, s)
+
     # 16UC1 planes
     mm = depth_f32_to_u16(np.nan_to_num(depths[2], nan=0.0, posinf=0.0))
     u_in, u_out = ctx.host_alloc((n, H, W), np.uint16), ctx.host_alloc((n, H, W), np.uint16)
