@@ -1322,7 +1322,25 @@ __device__ __forceinline__ void fragment(unsigned long long* keys, const TriRec&
 #define RTUF_QUARTER_AREA 256
 #endif
 constexpr int kSmallArea = RTUF_SMALL_AREA;     // bounding boxes up to this many pixels are walked by their own lane
+constexpr int kHugeMax = 255;                    // whole-tile triangles a workgroup parks for its cooperative pass
 constexpr int kQuarterArea = RTUF_QUARTER_AREA;   // up to this many by a quarter wave (4 triangles at a time), larger by the whole wave
+
+// The tile's part of a record's box (local lx0..ly1) against the three edges: an edge function is largest /
+// smallest at a corner.  Not positive at its largest for some edge: no pixel centre of this tile is covered
+// (half of the tiles of a screen-filling triangle's box) -> returns 0.  Positive at its smallest for all
+// three: every candidate is covered -> returns 2 (no edge tests needed).  Otherwise 1.
+__device__ __forceinline__ int classify_box(const TriRec& r, int x_base, int y_base, int lx0, int lx1, int ly0, int ly1)
+{
+  bool reject = false, inside = true;
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    const int xa = x_base + (r.A[e] > 0 ? lx1 : lx0), xi = x_base + (r.A[e] > 0 ? lx0 : lx1);
+    const int ya = y_base + (r.B[e] > 0 ? ly1 : ly0), yi = y_base + (r.B[e] > 0 ? ly0 : ly1);
+    reject = reject || (__mul24(r.A[e], xa) + __mul24(r.B[e], ya) + r.C[e]) <= 0;
+    inside = inside && (__mul24(r.A[e], xi) + __mul24(r.B[e], yi) + r.C[e]) > 0;
+  }
+  return reject ? 0 : (inside ? 2 : 1);
+}
 
 // Broadcast of one lane's record to the whole wave through scalar registers (v_readlane): the
 // cooperative path then runs with the triangle's 16 words as SGPR operands.
@@ -1356,7 +1374,8 @@ __device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriR
 // 8x8 stamps for anything larger.
 template <int MODE>
 __device__ __forceinline__ void raster_bin(unsigned long long* keys, const PackedTri* recs, uint32_t n,
-                                           int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, uint32_t n_front, uint32_t capacity, int dbg_skip = 0)
+                                           int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, uint32_t n_front, uint32_t capacity,
+                                           uint32_t* s_huge, int dbg_skip = 0)
 {
   const int lane = tid & 63;
   for (uint32_t base = 0; base < n; base += kTileThreads) {
@@ -1427,6 +1446,22 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     // whole-wave cooperative: triangles that cover a large part of the tile, one at a time with the
     // record in scalar registers (v_readlane), 64 candidate pairs per step
     unsigned long long huge = __ballot(area > kQuarterArea);
+    if (huge) {
+      // those whose triangle misses this tile altogether drop out here
+      huge &= ~__ballot(area > kQuarterArea && classify_box(r, x_base, y_base, lx0, lx1, ly0, ly1) == 0);
+    }
+    if (huge) {
+      // park them in the workgroup's list (s_huge[0] = count, then bin indices): after this loop all four
+      // waves rasterise each of them together.  Only what does not fit the list stays with this wave.
+      const int leader = __ffsll((long long)huge) - 1;
+      uint32_t hb = 0;
+      if (lane == leader) hb = atomicAdd(&s_huge[0], (uint32_t)__popcll(huge));
+      hb = (uint32_t)__builtin_amdgcn_readlane((int)hb, leader);
+      const uint32_t hs = hb + (uint32_t)__popcll(huge & ((1ull << lane) - 1ull));
+      const bool parked = ((huge >> lane) & 1ull) != 0 && hs < (uint32_t)kHugeMax;
+      if (parked) s_huge[1 + hs] = ri;
+      huge &= ~__ballot(parked);
+    }
     while (huge) {
       const int src = __ffsll((long long)huge) - 1;
       huge &= huge - 1;
@@ -1469,6 +1504,87 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       const uint32_t inv = (uint32_t)ceilf(1048576.0f * __builtin_amdgcn_rcpf((float)max(qw, 1)));
       for (int idx = sub; __ballot(idx < npair); idx += 16) {
         if (idx < npair) {
+          const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
+          raster_pair<MODE>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1);
+        }
+      }
+    }
+  }
+  // workgroup-cooperative: the parked triangles (those that cover a large part of the tile: walls, close
+  // links), one at a time, the box's run of candidate pairs spread over all four waves.  Every wave loads
+  // and unpacks the same (few) records itself and takes the record it works on from its own lanes.
+  __syncthreads();
+  const uint32_t nh = min(s_huge[0], (uint32_t)kHugeMax);
+  uint32_t zfull = 0xffffffffu;                  // largest depth any pixel of the tile can still have (24-bit)
+  for (uint32_t hb = 0; hb < nh; hb += 64) {
+    const bool have = hb + (uint32_t)lane < nh;
+    TriRec r;
+    if (have) {
+      PackedTri pk;
+      const uint4* src = reinterpret_cast<const uint4*>(recs + s_huge[1 + hb + lane]);
+      uint4* dst = reinterpret_cast<uint4*>(&pk);
+      dst[0] = src[0]; dst[1] = src[1];
+      r = unpack_record(pk, width, height);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; k++) reinterpret_cast<int*>(&r)[k] = 0;
+    }
+    // per lane: the record's part of the tile, whether it is covered entirely, and the range of its depth
+    // there.  The plane is evaluated exactly like fragment() does, which is monotonic in px and in py, so
+    // the extremes over the box are at its corners.
+    const int lx0 = max((int)(r.bbx & 0xffff) - x_base, 0), lx1 = min((int)(r.bbx >> 16) - x_base, kTileW - 1);
+    const int ly0 = max((int)(r.bby & 0xffff) - y_base, 0), ly1 = min((int)(r.bby >> 16) - y_base, kTileH - 1);
+    const int cls = have ? classify_box(r, x_base, y_base, lx0, lx1, ly0, ly1) : 0;
+    const float cx0 = __fmaf_rn(r.dzdx, (float)(x_base + lx0), r.a0), cx1 = __fmaf_rn(r.dzdx, (float)(x_base + lx1), r.a0);
+    const float fy0 = (float)(y_base + ly0), fy1 = (float)(y_base + ly1);
+    const float z00 = __fmaf_rn(r.dzdy, fy0, cx0), z10 = __fmaf_rn(r.dzdy, fy0, cx1);
+    const float z01 = __fmaf_rn(r.dzdy, fy1, cx0), z11 = __fmaf_rn(r.dzdy, fy1, cx1);
+    const uint32_t zmin24 = z24_of(fminf(fminf(z00, z10), fminf(z01, z11))), zmax24 = z24_of(fmaxf(fmaxf(z00, z10), fmaxf(z01, z11)));
+    // Occlusion among them: once a triangle covers every pixel of the tile, no pixel's key can have a
+    // larger depth than that triangle's largest; a triangle whose smallest depth here is larger still
+    // (the back of a wall, the wall behind it) cannot win anywhere in this tile and is skipped.
+    const bool whole = cls == 2 && lx0 == 0 && ly0 == 0 && lx1 == min(kTileW, width - x_base) - 1 && ly1 == min(kTileH, height - y_base) - 1;
+    uint32_t zf = whole ? zmax24 : 0xffffffffu;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) zf = min(zf, (uint32_t)__shfl_xor((int)zf, o));
+    zfull = min(zfull, zf);
+    unsigned long long m = __ballot(have && zmin24 <= zfull);
+    const unsigned long long full = __ballot(cls == 2);
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const bool inside = ((full >> src) & 1ull) != 0;
+      const TriRec q = broadcast_record(r, src);
+      const int qx0 = max((int)(q.bbx & 0xffff) - x_base, 0), qx1 = min((int)(q.bbx >> 16) - x_base, kTileW - 1);
+      const int qy0 = max((int)(q.bby & 0xffff) - y_base, 0), qy1 = min((int)(q.bby >> 16) - y_base, kTileH - 1);
+      const int qw = qx1 - qx0 + 1, npair = qw * ((qy1 - qy0 + 2) >> 1);
+      const uint32_t inv = (uint32_t)ceilf(1048576.0f * __builtin_amdgcn_rcpf((float)qw));
+      if (inside && qw == kTileW) {
+        // the triangle covers the tile's full width on these rows (the interior of a wall): one column per
+        // lane, the waves interleave the rows; per pixel one fma on top of the column's part of the plane
+        // (the same two roundings as fragment()), the 24-bit conversion and the LDS atomic
+        const int px = x_base + lane;
+        const float zc = __fmaf_rn(q.dzdx, (float)px, q.a0);
+        for (int ly = qy0 + (tid >> 6); ly <= qy1; ly += kTileThreads / 64) {
+          const float z = __fmaf_rn(q.dzdy, (float)(y_base + ly), zc);
+          const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | q.order;
+          const int lidx = ly * kTileW + lane;
+          if (MODE == 0) {
+            atomicMin(&keys[lidx], key);
+          } else {
+            if (keys[lidx] == key) keys[lidx] = kResolvedBit | (unsigned long long)__float_as_uint(z);
+          }
+        }
+      } else if (inside) {
+        for (int idx = tid; idx < npair; idx += kTileThreads) {
+          const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
+          const int lx = qx0 + idx - __mul24(yy, qw), ly = qy0 + 2 * yy;
+          const int lidx = ly * kTileW + lx;
+          fragment<MODE>(keys, q, x_base + lx, y_base + ly, lidx);
+          if (ly < qy1) fragment<MODE>(keys, q, x_base + lx, y_base + ly + 1, lidx + kTileW);
+        }
+      } else {
+        for (int idx = tid; idx < npair; idx += kTileThreads) {
           const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
           raster_pair<MODE>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1);
         }
@@ -1525,6 +1641,7 @@ template <bool TWO_KERNEL, bool U16>
 __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 {
   __shared__ unsigned long long keys[kTileW * kTileH];
+  __shared__ uint32_t s_huge[1 + kHugeMax];        // raster_bin's list of whole-tile triangles
 
   const int tid = threadIdx.x;
   const int tiles = a.tiles_x * a.tiles_y;
@@ -1576,6 +1693,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
   if (empty && (a.flags & 0x1000000u)) return;                     // timing experiment: raster tiles only
   if (!empty) {
     for (int i = tid; i < kTileW * kTileH; i += kTileThreads) keys[i] = bgkey;
+    if (tid == 0) s_huge[0] = 0;
     __syncthreads();
     if (tid == 0) {
       a.bin_count[2 * bin] = 0;             // ready for the next batch
@@ -1585,9 +1703,10 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
       if (count) atomicMax(&sh.max_bin_fill, count);
       if (fcount) atomicMax(&sh.max_fbin_fill, fcount);
     }
-    if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, (int)((a.flags >> 12) & 3u));
+    if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, (int)((a.flags >> 12) & 3u));
     if (!(a.flags & 0x400u)) raster_frags(keys, frags, nf, tid);
     __syncthreads();
+    if (tid == 0) s_huge[0] = 0;             // the exact-z pass below builds its list again
 
     // Does any pixel need the exact float z of its winner?  Only when the winning depth is in the
     // lower half of the depth range (z24 <= 2^23): above it, float z == (z24 + 1) * 2^-24 exactly.
@@ -1597,7 +1716,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
       if (k != bgkey && (uint32_t)(k >> 32) <= 8388608u) need = true;
     }
     if (__syncthreads_or(need)) {
-      raster_bin<1>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity);
+      raster_bin<1>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge);
       __syncthreads();
     }
   }

@@ -764,6 +764,53 @@ def test_fragment_bin_and_clip_list_overflow_regrow():
         ctx.close()
 
 
+@pytest.mark.parametrize("size", [(640, 480), (333, 251)])
+def test_screen_filling_layers(size):
+    """Stacked screen-filling triangles (walls): coincident duplicates in both diagonal splits, a layer behind,
+    a tilted layer that cuts through them, a nearer partial layer, a layer a few ulps behind -- the tile
+    kernel's cooperative pass classifies tiles against the edges and skips triangles that a complete nearer
+    layer hides; every pixel must still be the oracle's."""
+    W, H = size
+    fx = 525.0 * W / 640
+    P = S.projection(fx, fx, (W - 1) / 2, (H - 1) / 2, W, H)
+    rng = np.random.default_rng(W)
+
+    def quad(z, u0=-0.2, u1=1.2, v0=-0.2, v1=1.2, flip=False):
+        """z: depth at the four corners (tl, tr, bl, br); u, v: fractions of the image (beyond 0..1 = off-screen)."""
+        pts = []
+        for (u, v), zz in zip(((u0, v0), (u1, v0), (u0, v1), (u1, v1)), z):
+            pts.append(((u * W - (W - 1) / 2) / fx * zz, (v * H - (H - 1) / 2) / fx * zz, zz))
+        v = np.array(pts, np.float32)
+        t = np.array([[0, 1, 2], [2, 1, 3]] if not flip else [[0, 1, 3], [0, 3, 2]], np.uint32)
+        return v, t
+
+    layers = [quad((2.0,) * 4, flip=True), quad((2.0,) * 4), quad((2.0,) * 4), quad((3.0,) * 4),
+              quad((1.6, 2.4, 1.6, 2.4)), quad((1.2,) * 4, u1=0.4), quad((2.0000002,) * 4),
+              quad((2.5, 2.5, 1.7, 1.7), u0=0.3)]
+    soup = S.soup_geometry(rng, n_links=2, tris_per_link=150, scale_lo=0.02, scale_hi=0.3)
+    geo = [(0, [0.0, 0.0, 0.0], v, t) for v, t in layers] + soup
+    n = 3
+    ctx = R.Context(W, H, n, 0, params())
+    m = ctx.add_model()
+    for pre, op, v, t in geo:
+        l = ctx.add_link(m)
+        ctx.add_draw(m, l, v, t, pre, op)
+    ctx.finalize_models()
+    depth = np.stack([S.sensor_depth(W, H, 0.7 * s) for s in range(n)])
+    per = []
+    ident = np.eye(4).T.reshape(16)
+    for s in range(n):
+        tfs = [ident.copy() for _ in layers] + S.random_link_poses(rng, len(soup))
+        offinv, camtf = (None, None) if s == 0 else S.random_camera(rng, small=True)
+        ctx.set_camera(s, P, offinv, camtf)
+        ctx.set_link_poses(s, m, np.stack(tfs))
+        per.append((tfs, offinv, camtf))
+    masked, mask = ctx.filter_batch(depth)
+    check_vs_oracle(masked, mask, P, geo, depth, per)
+    assert mask[0].astype(bool).mean() > 0.5          # the layers really fill the view
+    ctx.close()
+
+
 def test_config_c4_720p_pr2_plus_walls():
     """BASELINE config 4 shape: 1280x720, PR2-like robot + two static wall URDFs (full-screen boxes incl.
     quirk Q1: exercises the large-triangle path), several streams."""
