@@ -764,7 +764,7 @@ def test_fragment_bin_and_clip_list_overflow_regrow():
         ctx.close()
 
 
-@pytest.mark.parametrize("size", [(640, 480), (333, 251)])
+@pytest.mark.parametrize("size", [(640, 480), (333, 251), (96, 64)])
 def test_screen_filling_layers(size):
     """Stacked screen-filling triangles (walls): coincident duplicates in both diagonal splits, a layer behind,
     a tilted layer that cuts through them, a nearer partial layer, a layer a few ulps behind -- the tile
@@ -787,6 +787,11 @@ def test_screen_filling_layers(size):
     layers = [quad((2.0,) * 4, flip=True), quad((2.0,) * 4), quad((2.0,) * 4), quad((3.0,) * 4),
               quad((1.6, 2.4, 1.6, 2.4)), quad((1.2,) * 4, u1=0.4), quad((2.0000002,) * 4),
               quad((2.5, 2.5, 1.7, 1.7), u0=0.3)]
+    if W == 96:
+        # more whole-tile triangles per tile than the workgroup's list holds (255): the rest stay with their wave
+        for _ in range(200):
+            z = rng.uniform(1.0, 4.0) + rng.uniform(-0.3, 0.3, 4) * (rng.random() < 0.5)
+            layers.append(quad(tuple(float(x) for x in np.broadcast_to(z, 4)), flip=bool(rng.integers(0, 2))))
     soup = S.soup_geometry(rng, n_links=2, tris_per_link=150, scale_lo=0.02, scale_hi=0.3)
     geo = [(0, [0.0, 0.0, 0.0], v, t) for v, t in layers] + soup
     n = 3
