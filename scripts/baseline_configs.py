@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs 4 and 5 at their per-GPU sizes, with parity against the oracle
+"""BASELINE.json configs 1, 4 and 5 at their per-GPU sizes, with parity against the oracle
 on sampled streams.  bench.py measures config 3 (the one the metric is quoted on); these are parity cases
 with a rate beside them.
 
+  C1: urdf/example.urdf.xml, one 640x480 stream (latency of one frame)
   C4: 1280x720, PR2-like robot (250 k triangles) + the two wall URDFs, 64 streams per GPU (512 / 8 GPUs)
   C5: 640x480, 8 distinct articulated URDFs x 128 cameras each = 1024 streams per GPU (8,192 / 8 GPUs);
       every stream renders only its own robot; forward kinematics of all 8 robots on the GPU
@@ -59,6 +60,32 @@ def timed(ctx, n, stage, d_depth, outs, steps):
     st = ctx.stats()
     ctx.enable_timing(0)
     return el, {k: round(st[k], 4) for k in ("ms_pose", "ms_setup", "ms_raster", "ms_total")}
+
+
+def config1(steps):
+    """C1: urdf/example.urdf.xml (two walls incl. quirk Q1), one 640x480 stream: per-frame latency on the GPU."""
+    wl = WL.example_workload()
+    ctx = R.Context(wl.width, wl.height, 1, 0, params(wl))
+    ids = wl.load_into(ctx)
+    wl.stage(ctx, ids)
+    dev = torch.device("cuda:0")
+    depth = wl.depth_batch()
+    d_depth = torch.from_numpy(depth).to(dev)
+    outs = [(torch.empty((1, wl.height, wl.width), dtype=torch.float32, device=dev), torch.empty((1, wl.height, wl.width), dtype=torch.uint8, device=dev)) for _ in range(2)]
+    el, stages = timed(ctx, 1, lambda k: None, d_depth, outs, steps)
+    # one frame at a time (what a single camera node sees): enqueue + wait
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ctx.filter_batch_device(1, d_depth.data_ptr(), outs[0][0].data_ptr(), outs[0][1].data_ptr())
+        ctx.sync()
+    lat = (time.perf_counter() - t0) / steps
+    om, ok = O.filter_frame(depth[0], wl.projection[0], wl.oracle_draws(0), wl.offset_inv[0], wl.cam_tf[0],
+                            max_diff=wl.max_diff, replace_value=wl.replace_value)
+    masked, mask = outs[0][0].cpu().numpy()[0], outs[0][1].cpu().numpy()[0]
+    bad = int((ok != mask).sum()) + int((om.view(np.uint32) != masked.view(np.uint32)).sum())
+    ctx.close()
+    return {"config": "C1: urdf/example.urdf.xml, 640x480, one stream", "frames_per_s_pipelined": steps / el, "ms_per_frame_pipelined": el / steps * 1e3,
+            "ms_per_frame_enqueue_and_wait": lat * 1e3, "steps": steps, "stage_ms_isolated": stages, "mismatching_values": bad}
 
 
 def config4(steps, check):
@@ -155,12 +182,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--check", type=int, default=2, help="streams per robot checked against the oracle")
-    ap.add_argument("--only", choices=["c4", "c5"], default=None)
+    ap.add_argument("--only", choices=["c1", "c4", "c5"], default=None)
     ap.add_argument("--debug-flags", type=lambda x: int(x, 0), default=0, help="timing experiments only (results are wrong)")
     args = ap.parse_args()
     global DEBUG_FLAGS
     DEBUG_FLAGS = args.debug_flags
     out = {}
+    if args.only in (None, "c1"):
+        out["C1"] = config1(max(args.steps, 200))
     if args.only in (None, "c4"):
         out["C4"] = config4(args.steps, 2 * args.check)
     if args.only in (None, "c5"):
