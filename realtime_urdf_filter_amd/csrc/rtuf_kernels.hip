@@ -1369,9 +1369,10 @@ __device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriR
   if (min(e0 + q.B[0], min(e1 + q.B[1], e2 + q.B[2])) > 0 && ly < qy1) fragment<MODE>(keys, q, px, py + 1, lidx + kTileW);
 }
 
-// Rasterises the bin's records into the LDS key tile.  Every wave works on its own records
-// (no workgroup barrier inside): lane-per-triangle for tiny bounding boxes, the whole wave in
-// 8x8 stamps for anything larger.
+// Rasterises the bin's records into the LDS key tile.  Every wave works on the records it loaded:
+// lane-per-triangle for small bounding boxes, a quarter wave each for the middle class; triangles
+// that cover a large part of the tile are parked and, after one workgroup barrier at the end, walked
+// by all waves together (all threads of the workgroup must call this function).
 template <int MODE>
 __device__ __forceinline__ void raster_bin(unsigned long long* keys, const PackedTri* recs, uint32_t n,
                                            int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, uint32_t n_front, uint32_t capacity,
