@@ -1404,6 +1404,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     if (dbg_load_only) { if (r.order == 0xdeadbeefu) keys[0] = 0; area = 0; }
     if (dbg_skip == 1 && area <= kSmallArea) area = 0;      // timing experiment: no lane-per-triangle walk
     if (dbg_skip == 2 && area > kSmallArea) area = 0;       // timing experiment: no quarter-wave walk
+    if (dbg_skip == 3 && area > kQuarterArea) area = 0;     // timing experiment: no whole-tile walks
     const bool small = area > 0 && area <= kSmallArea;
     // lane-per-triangle: walk the bounding box as one run of 2x2 candidate QUADS, quad row by quad row.
     // The three edge values of a quad's upper left pixel are stepped incrementally (one add each, a
