@@ -69,7 +69,8 @@ typedef struct {
   float filter_replace_value;       /* rosparam filter_replace_value     -> shader uniform replace_value (:631) */
   uint32_t flags;                   /* RTUF_FLAG_* */
   uint32_t bin_capacity;            /* triangles per (stream, screen tile) bin; 0 = automatic */
-  uint32_t max_inflight_streams;    /* streams rasterised per internal launch group; 0 = automatic */
+  uint32_t max_inflight_streams;    /* streams rasterised per internal launch group; 0 = automatic: up to 1024,
+                                       fewer if the bins would exceed a third of the free device memory */
   uint32_t reserved[5];
 } rtuf_params;
 

@@ -1322,7 +1322,16 @@ __device__ __forceinline__ void fragment(unsigned long long* keys, const TriRec&
 #define RTUF_QUARTER_AREA 256
 #endif
 constexpr int kSmallArea = RTUF_SMALL_AREA;     // bounding boxes up to this many pixels are walked by their own lane
-constexpr int kHugeMax = 255;                    // whole-tile triangles a workgroup parks for its cooperative pass
+#ifndef RTUF_PARK_BELOW
+#define RTUF_PARK_BELOW 128
+#endif
+#ifndef RTUF_WALL_AREA
+#define RTUF_WALL_AREA 1536
+#endif
+constexpr int kWallArea = RTUF_WALL_AREA;         // ... larger bins only for boxes covering more of the tile than this
+constexpr int kParkBelow = RTUF_PARK_BELOW;       // bins of at most this many records use the cooperative whole-tile pass
+constexpr int kHugeMax = 255;
+constexpr uint32_t kParkClosed = 0x10000u;        // initial list count of a bin that does not park                    // whole-tile triangles a workgroup parks for its cooperative pass
 constexpr int kQuarterArea = RTUF_QUARTER_AREA;   // up to this many by a quarter wave (4 triangles at a time), larger by the whole wave
 
 // The tile's part of a record's box (local lx0..ly1) against the three edges: an edge function is largest /
@@ -1452,15 +1461,19 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       // those whose triangle misses this tile altogether drop out here
       huge &= ~__ballot(area > kQuarterArea && classify_box(r, x_base, y_base, lx0, lx1, ly0, ly1) == 0);
     }
-    if (huge) {
-      // park them in the workgroup's list (s_huge[0] = count, then bin indices): after this loop all four
-      // waves rasterise each of them together.  Only what does not fit the list stays with this wave.
-      const int leader = __ffsll((long long)huge) - 1;
+    const unsigned long long park = huge ? (huge & __ballot(area > (int)s_huge[1 + kHugeMax])) : 0ull;
+    if (park) {
+      // In a bin that one or two waves hold alone (typical: a few walls) all of them, in fuller bins only those
+      // that cover nearly the whole tile (the kernel puts the area threshold behind the list) are parked in
+      // the workgroup's list (s_huge[0] = count, then bin indices): after this loop all four waves rasterise
+      // each of them together.  Otherwise every wave has its own, and walking them alone avoids paying each
+      // triangle's fixed cost four times.  What does not fit the list stays with this wave, too.
+      const int leader = __ffsll((long long)park) - 1;
       uint32_t hb = 0;
-      if (lane == leader) hb = atomicAdd(&s_huge[0], (uint32_t)__popcll(huge));
+      if (lane == leader) hb = atomicAdd(&s_huge[0], (uint32_t)__popcll(park));
       hb = (uint32_t)__builtin_amdgcn_readlane((int)hb, leader);
-      const uint32_t hs = hb + (uint32_t)__popcll(huge & ((1ull << lane) - 1ull));
-      const bool parked = ((huge >> lane) & 1ull) != 0 && hs < (uint32_t)kHugeMax;
+      const uint32_t hs = hb + (uint32_t)__popcll(park & ((1ull << lane) - 1ull));
+      const bool parked = ((park >> lane) & 1ull) != 0 && hs < (uint32_t)kHugeMax;
       if (parked) s_huge[1 + hs] = ri;
       huge &= ~__ballot(parked);
     }
@@ -1643,7 +1656,7 @@ template <bool TWO_KERNEL, bool U16>
 __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
 {
   __shared__ unsigned long long keys[kTileW * kTileH];
-  __shared__ uint32_t s_huge[1 + kHugeMax];        // raster_bin's list of whole-tile triangles
+  __shared__ uint32_t s_huge[2 + kHugeMax];        // raster_bin's list of whole-tile triangles (+ count in front, area threshold behind)
 
   const int tid = threadIdx.x;
   const int tiles = a.tiles_x * a.tiles_y;
@@ -1695,7 +1708,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
   if (empty && (a.flags & 0x1000000u)) return;                     // timing experiment: raster tiles only
   if (!empty) {
     for (int i = tid; i < kTileW * kTileH; i += kTileThreads) keys[i] = bgkey;
-    if (tid == 0) s_huge[0] = 0;
+    if (tid == 0) { s_huge[0] = 0; s_huge[1 + kHugeMax] = n <= (uint32_t)kParkBelow ? (uint32_t)kQuarterArea : (uint32_t)kWallArea; }
     __syncthreads();
     if (tid == 0) {
       a.bin_count[2 * bin] = 0;             // ready for the next batch

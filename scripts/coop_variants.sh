@@ -3,7 +3,7 @@
 for v in "$@"; do
   L=realtime_urdf_filter_amd/lib/variants/librtuf_$v.so
   echo -n "$v: "
-  for t in 250000 1000 5000; do
+  for t in 250000 1000 5000 20000; do
     RTUF_LIB=$L python bench.py --triangles $t --steps ${STEPS:-50} --warmup 3 --cpu-seconds 0 --check-frames 2 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print('t$t', round(d['value']), round(d['kernel_ms_per_step']['ms_raster'],4), d['parity']['mask_mismatch_pixels'] + d['parity']['depth_mismatch_pixels'], end=' | ')"
   done
