@@ -110,6 +110,21 @@ def test_bin_regrowth_and_inflight_groups():
     ctx.close()
 
 
+def test_many_streams_in_one_launch_group():
+    """600 small streams: more than the 256 a launch group used to hold, fewer than the 1024 it holds now;
+    too-small bins force a regrowth of the large group as well."""
+    n = 600
+    ctx, P, geo, depth, per = run_soups(96, 64, n, seed=21, bin_capacity=8)
+    masked, mask = ctx.filter_batch(depth)
+    pick = list(range(0, n, 53)) + [255, 256, 257, n - 1]
+    sub = [per[s] for s in pick]
+    check_vs_oracle(masked[pick], mask[pick], P, geo, depth[pick], sub)
+    assert ctx.stats()["regrowths"] >= 1
+    masked2, mask2 = ctx.filter_batch(depth)
+    assert bits_equal(masked, masked2) and np.array_equal(mask, mask2)
+    ctx.close()
+
+
 def test_pr2_like_workload_streams():
     wl = WL.pr2_workload(6, 640, 480, total_triangles=20000)
     ctx = R.Context(640, 480, 6, 0, params(wl.replace_value, wl.max_diff))
