@@ -1653,7 +1653,7 @@ __device__ __forceinline__ float shade(float sensor, float z, const ShadeConsts&
 }
 
 template <bool TWO_KERNEL, bool U16>
-__global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
+__device__ __forceinline__ void tile_body(const TileArgs& a)
 {
   __shared__ unsigned long long keys[kTileW * kTileH];
   __shared__ uint32_t s_huge[2 + kHugeMax];        // raster_bin's list of whole-tile triangles (+ count in front, area threshold behind)
@@ -1814,6 +1814,15 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a)
     finish(ps, z, thr, frag);
   }
 }
+
+template <bool TWO_KERNEL, bool U16>
+__global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a) { tile_body<TWO_KERNEL, U16>(a); }
+// two-kernel mode writes the z-surface instead of resolving the compare: one register over 64 VGPRs without
+// the hint, i.e. 7 instead of 8 waves/SIMD (+10 % kernel time)
+template <>
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(8))) void tile_kernel<true, false>(TileArgs a) { tile_body<true, false>(a); }
+template <>
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(8))) void tile_kernel<true, true>(TileArgs a) { tile_body<true, true>(a); }
 
 // ---------------------------------------------------------------------------------------
 // compare_kernel (two-kernel mode): streaming, 13 B/pixel (4 sensor + 4 z + 4 masked + 1 mask)
