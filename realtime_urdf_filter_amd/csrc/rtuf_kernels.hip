@@ -1862,7 +1862,7 @@ __global__ __launch_bounds__(kBlock) void compare_kernel(CompareArgs a)
       const float4 s = load_stream4(a.depth + 4 * i);
       sv[0] = s.x; sv[1] = s.y; sv[2] = s.z; sv[3] = s.w;
     }
-    const float4 z = reinterpret_cast<const float4*>(a.zsurface)[i];
+    const float4 z = load_stream4(a.zsurface + 4 * i);      // (the tile kernel's z stores stay temporal: this read may still find them in MALL)
     const float zv[4] = {z.x, z.y, z.z, z.w};
     float o[4];
     uint32_t mbits = 0;
