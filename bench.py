@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- filtered depth frames/s of the hot path (BASELINE.json metric) on N MI355X.
 
-A "step" is one pass of the hot path over one batch of synthetic input: `--streams` concurrent
-640x480 camera streams of the synthetic PR2-like robot (config C3 of SURVEY.md section 8d:
-"640x480, PR2 URDF, batch=256 concurrent camera streams on 1 MI355X", the configuration the
-BASELINE target ">=30 frames/s per stream at >=256 streams" is quoted on).  Every step stages a
-fresh joint state + camera pose for every stream, then runs pose -> set-up/binning -> clip ->
-tile raster + per-pixel compare on depth frames that are already resident in HBM.  Inputs rotate
-through `--variants` distinct pre-generated batches so no step can reuse the previous result.
+A "step" is one pass of the hot path over one batch of synthetic input.  Default workload (`--workload c3`):
+`--streams` concurrent 640x480 camera streams of the synthetic PR2-like robot per GPU (config C3 of SURVEY.md
+section 8d: "640x480, PR2 URDF, batch=256 concurrent camera streams on 1 MI355X", the configuration the BASELINE
+target ">=30 frames/s per stream at >=256 streams" is quoted on).  Every step stages a fresh joint state + camera
+pose for every stream, then runs forward kinematics -> pose -> cull -> set-up/binning -> clip -> tile raster +
+per-pixel compare on depth frames that are already resident in HBM.  Inputs rotate through `--variants`
+distinct pre-generated batches so no step can reuse the previous result.
 
-Multi-GPU (`--gpus N`, launched by torch.distributed.run): streams are independent, so every rank
-runs the same per-GPU batch on its own streams (weak scaling, no data-path collective); RCCL is
-used only for the barrier and the max-over-ranks time reduction.
+`--workload c4` / `c5` are the two 8-GPU configs of BASELINE.json (realtime_urdf_filter_amd/configs.py): c4 = 512
+720p streams of the robot + two wall URDFs block-partitioned over the ranks, c5 = 64 distinct URDFs x 128 cameras
+with URDF m on rank m % N.  Their totals are fixed, so they scale strongly; `--shard-of W` runs rank 0's share of
+a W-GPU job on however many GPUs are present (to measure the per-GPU share on one GPU).
+
+Multi-GPU (`--gpus N`, launched by torch.distributed.run): streams are independent, so every rank filters its own
+streams with no data-path collective; RCCL carries the barriers around the timed region, the MAX all-reduce of the
+elapsed time and the tiny end-of-run gather of per-rank frame and parity counts.
+
+Timed region: exactly `--steps` steps, repeated back to back until at least `--min-seconds` have passed (repetitions
+are whole multiples of `--steps`; `timed_steps` in the output says how many steps were timed in total).
 
 Prints ONE JSON line on rank 0.
 """
@@ -27,29 +35,58 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
+def pin_to_numa_node_of_gpu(local_rank):
+    """One rank per GPU: keep the rank's host threads on the NUMA node its GPU hangs off (staging buffers are
+    first-touched there).  Best effort: silently a no-op where sysfs does not say."""
+    try:
+        import torch
+        bus = torch.cuda.get_device_properties(local_rank).pci_bus_id
+        dom = getattr(torch.cuda.get_device_properties(local_rank), "pci_domain_id", 0)
+        dev = getattr(torch.cuda.get_device_properties(local_rank), "pci_device_id", 0)
+        path = "/sys/bus/pci/devices/%04x:%02x:%02x.0/local_cpulist" % (dom, bus, dev)
+        cpus = set()
+        for part in open(path).read().strip().split(","):
+            if "-" in part:
+                a, b = part.split("-")
+                cpus.update(range(int(a), int(b) + 1))
+            elif part:
+                cpus.add(int(part))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return len(cpus)
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=256, help="concurrent camera streams per GPU")
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="the timed region repeats the --steps steps until it is at least this long")
+    ap.add_argument("--workload", choices=["c3", "c4", "c5"], default="c3", help="BASELINE.json config: c3 (headline, weak scaling), c4, c5 (fixed totals, sharded)")
+    ap.add_argument("--streams", type=int, default=None, help="c3: concurrent camera streams per GPU (256); c4: streams in total (512); c5: cameras per URDF (128)")
+    ap.add_argument("--urdfs", type=int, default=64, help="c5: distinct URDFs in total")
+    ap.add_argument("--shard-of", type=int, default=0, help="take the shares of a job of this many GPUs (ranks 0..N-1 of it) instead of a job of --gpus GPUs")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--triangles", type=int, default=250000, help="triangle budget of the PR2-like model")
     ap.add_argument("--variants", type=int, default=2, help="distinct input batches rotated through the steps")
-    ap.add_argument("--pipelines", type=int, default=1, help="contexts (HIP stream + bins each) per GPU that the batches alternate between: with 2 or 3, one batch's small and low-occupancy kernels overlap another's heavy ones (+8..12 %% frames/s), but kernels then share the GPU and per-launch times (roofline) no longer describe one kernel; default 1")
+    ap.add_argument("--pipelines", type=int, default=1, help="contexts (HIP stream + bins each) per GPU that the batches alternate between: with 2 or 3, one batch's small and low-occupancy kernels overlap another's heavy ones, but kernels then share the GPU and per-launch times (roofline) no longer describe one kernel; default 1")
     ap.add_argument("--two-kernel", action="store_true", help="rasteriser + separate compare kernel")
     ap.add_argument("--host-poses", action="store_true", help="stage explicit link matrices from the host instead of joint positions + on-device forward kinematics")
     ap.add_argument("--u16", action="store_true", help="16UC1 depth in/out (uint16 millimetres) with the conversions fused into the kernels")
     ap.add_argument("--no-mask", action="store_true", help="need_mask_ == false: no mask output")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
-    ap.add_argument("--debug-flags", type=lambda x: int(x, 0), default=0, help="timing experiments only (results are wrong)")
-    ap.add_argument("--check-frames", type=int, default=4, help="frames of the last step verified against the oracle")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget per leg (single thread, all cores); 0 disables")
+    ap.add_argument("--debug-flags", type=lambda x: int(x, 0), default=0, help="timing experiments only (needs the RTUF_ABLATE build; results are wrong)")
+    ap.add_argument("--check-frames", type=int, default=4, help="frames of the last step verified against the oracle (per rank)")
     args = ap.parse_args()
 
     import torch
     import realtime_urdf_filter_amd as R
-    from realtime_urdf_filter_amd import workloads as WL
+    from realtime_urdf_filter_amd import configs as CF, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -61,6 +98,7 @@ def main():
     backend = os.environ.get("RTUF_BENCH_BACKEND", "nccl")
     local_rank = int(os.environ.get("RTUF_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
+    pinned_cpus = pin_to_numa_node_of_gpu(local_rank) if world > 1 and "RTUF_BENCH_DEVICE" not in os.environ else None
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -70,14 +108,16 @@ def main():
         else:
             dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if backend == "nccl" else "cpu"       # where the (few-byte) collectives' tensors live
 
-    n, W, H = args.streams, args.width, args.height
-    # --- workload: every rank owns `n` different streams (seeds offset by rank) --------------
-    variants = []
-    for v in range(args.variants):
-        wl = WL.pr2_workload(n, W, H, args.triangles, first_state_seed=1000 + 100000 * v + 1000003 * rank)
-        variants.append(wl)
-    wl0 = variants[0]
+    # --- workload: this rank's share ------------------------------------------------------------
+    job_world = args.shard_of or world
+    if rank >= job_world:
+        raise SystemExit("--shard-of %d: rank %d has no share" % (job_world, rank))
+    share = CF.build(args.workload, job_world, rank, streams=args.streams, triangles=args.triangles, variants=args.variants,
+                     width=args.width, height=args.height, urdfs=args.urdfs)
+    n, W, H = share.n, share.width, share.height
+    wl0 = share.wl0
     p = R.default_params()
     p.filter_replace_value = wl0.replace_value
     p.depth_distance_threshold = wl0.max_diff
@@ -85,40 +125,36 @@ def main():
         p.flags |= R.FLAG_TWO_KERNEL
     p.flags |= args.debug_flags
     P = max(1, args.pipelines)
-    ctxs, idss = [], []
-    for _ in range(P):
+    ctxs, shares = [], []
+    for i in range(P):
         c = R.Context(W, H, n, local_rank, p)
-        i = wl0.load_into(c)
-        if not args.host_poses:
-            wl0.load_kinematics(c, i)
-        c.enable_timing(2)       # HIP events around the dominant kernel only (each event costs stream time)
+        sh = share if i == 0 else CF.build(args.workload, job_world, rank, streams=args.streams, triangles=args.triangles, variants=args.variants,
+                                           width=args.width, height=args.height, urdfs=args.urdfs)
+        sh.load(c, on_device_fk=not args.host_poses)
+        c.enable_timing(2)       # HIP events around the big kernels only (each event costs stream time)
         ctxs.append(c)
-        idss.append(i)
-    ctx, ids = ctxs[0], idss[0]
+        shares.append(sh)
+    ctx = ctxs[0]
+    V = share.n_variants()
 
     d_depth = []
-    for v, wl in enumerate(variants):
-        host = np.stack([wl.depth(s + 7 * v + 1000 * rank) for s in range(n)])
+    for v in range(V):
+        host = share.depth_host(v)
         if args.u16:
             host = np.clip(np.rint(np.nan_to_num(host, nan=0.0, posinf=0.0) * 1000.0), 0, 65535).astype(np.uint16).view(np.int16)
         d_depth.append(torch.from_numpy(host).to(dev))
+        del host
     # two output sets per pipeline: with two batches in flight per context, a batch must not write where an
     # earlier batch's results are still unread
     n_sets = 2 * P
     d_masked_set = [torch.empty((n, H, W), dtype=torch.int16 if args.u16 else torch.float32, device=dev) for _ in range(n_sets)]
     d_mask_set = [None if args.no_mask else torch.empty((n, H, W), dtype=torch.uint8, device=dev) for _ in range(n_sets)]
     torch.cuda.synchronize()
-    V = len(variants)
-    staged_once = [False] * P
     ptrs = [(d_masked_set[i].data_ptr(), d_mask_set[i].data_ptr() if d_mask_set[i] is not None else 0) for i in range(n_sets)]
     dptr = [d.data_ptr() for d in d_depth]
 
     def stage_into(ci, k):
-        if args.host_poses:
-            variants[k % V].stage(ctxs[ci], idss[ci])
-        else:   # joint angles in, forward kinematics on the GPU
-            variants[k % V].stage_joint_positions(ctxs[ci], idss[ci], first_call=not staged_once[ci])
-        staged_once[ci] = True
+        shares[ci].stage(ctxs[ci], k)       # joint angles in (forward kinematics on the GPU), or host matrices with --host-poses
 
     def submit(ci, k):
         c = ctxs[ci]
@@ -141,17 +177,38 @@ def main():
             dist.barrier()
 
     k0 = args.warmup * P
+    t_w = time.perf_counter()
     for k in range(k0):            # every pipeline warms up (first batch: bin sizing) with one batch in flight
         stage_into(k % P, k)
         submit(k % P, k)
         ctxs[k % P].sync()
     torch.cuda.synchronize()
+    # how often the --steps steps are repeated so that the timed region is at least --min-seconds long: from the
+    # time of a few pipelined steps after the warm-up (agreed between the ranks: the slowest decides)
+    probe = max(2, min(args.steps, 8))
+    stage_into(k0 % P, k0)
+    t_p = time.perf_counter()
+    for k in range(k0, k0 + probe):
+        enqueue(k)
+    for c in ctxs:
+        c.sync()
+    est_step = (time.perf_counter() - t_p) / probe
+    k0 += probe
+    reps = max(1, int(np.ceil(args.min_seconds / max(est_step * max(args.steps, 1), 1e-9)))) if args.min_seconds > 0 else 1
+    if dist is not None:
+        t = torch.tensor([reps], dtype=torch.int64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        reps = int(t.item())
+    timed_steps = args.steps * reps
+    for c in ctxs:
+        c.sync()
+    torch.cuda.synchronize()
     barrier()
     for c in ctxs:
-        c.enable_timing(3)       # (re)starts the library's event sums: tile (and compare) kernel, every fourth batch (an event costs ~5 us of stream time)
+        c.enable_timing(3)       # (re)starts the library's event sums: set-up, tile (and compare) kernels of every fourth batch (an event costs ~5 us of stream time)
     stage_into(k0 % P, k0)
     t0 = time.perf_counter()
-    for k in range(k0, k0 + args.steps):
+    for k in range(k0, k0 + timed_steps):
         enqueue(k)
     for c in ctxs:
         c.sync()
@@ -160,137 +217,204 @@ def main():
     elapsed = time.perf_counter() - t0
     sts = [c.stats() for c in ctxs]
     timed = sum(st["timed_batches"] for st in sts)
-    assert timed >= 1 and timed >= args.steps // 4, ([st["timed_batches"] for st in sts], args.steps)
+    assert timed >= 1 and timed >= timed_steps // 4, ([st["timed_batches"] for st in sts], timed_steps)
+    setup_ms = sum(st["sum_ms_setup"] for st in sts) / timed
     raster_ms = sum(st["sum_ms_raster"] for st in sts) / timed
     compare_ms = sum(st["sum_ms_compare"] for st in sts) / timed
     # stage-by-stage breakdown: a few extra steps on one pipeline, one batch in flight, every stage bracketed
     # by events, outside the timed region (kernel times without another batch sharing the GPU)
     ctx.enable_timing(1)
-    extra = 3 * V       # a multiple of the variant cycle: the last step run is the last timed step's variant (parity below)
+    extra = 3 * V       # a multiple of the variant cycle
     acc = {"ms_pose": 0.0, "ms_setup": 0.0, "ms_raster": 0.0, "ms_compare": 0.0, "ms_total": 0.0}
+    k_after = k0 + timed_steps
+    k_after += (-k_after) % V          # so that the last extra step is variant V-1 and k_last below is well defined
     for j in range(extra):
-        isolated_step(k0 + args.steps + j)
+        isolated_step(k_after + j)
         st = ctx.stats()
         for key in acc:
             acc[key] += st[key]
     breakdown = {key: v / extra for key, v in acc.items()}
-    k_last = k0 + args.steps + extra - 1
+    k_last = k_after + extra - 1
+    groups_per_batch = 1
+    frames_rank = n * timed_steps
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = ctx.stats()
 
+    # ---- parity spot check on every rank (oracle = checker only) -----------------------------------
+    from oracle import bindings as O
+    from realtime_urdf_filter_amd.filter import depth_f32_to_u16, depth_u16_to_f32
+    v_last = k_last % V
+    d_masked, d_mask = d_masked_set[k_last % n_sets], d_mask_set[k_last % n_sets]
+    link_dev = cam_dev = None
+    fk_err = None
+    if not args.host_poses:
+        # the oracle is fed the very matrices the GPU's forward kinematics produced
+        link_dev, cam_dev = ctx.read_poses(n, share.n_links_total)
+        fk_err = share.host_fk_error(k_last, link_dev, cam_dev)
+    check = sorted(set(int(x) for x in np.linspace(0, n - 1, num=min(max(args.check_frames, 0), n)))) if args.check_frames > 0 else []
+
+    def fetch(s):
+        hm = d_masked[s].cpu().numpy()
+        hk = d_mask[s].cpu().numpy() if d_mask is not None else None
+        hd = d_depth[v_last][s].cpu().numpy()
+        if args.u16:
+            hm = hm.view(np.uint16)
+            hd = depth_u16_to_f32(hd.view(np.uint16))
+        return hd, hm, hk
+
+    def oracle(s, hd):
+        proj, draws, off, cam = share.oracle_frame(k_last, s, link_dev, cam_dev)
+        return O.filter_frame(hd, proj, draws, off, cam, max_diff=wl0.max_diff, replace_value=wl0.replace_value)
+
+    bad_mask = bad_depth = 0
+    for s in check:
+        hd, hm, hk = fetch(s)
+        om, ok = oracle(s, hd)
+        if hk is not None:
+            bad_mask += int((ok != hk).sum())
+        bad_depth += int((depth_f32_to_u16(om) != hm).sum()) if args.u16 else int((om.view(np.uint32) != hm.view(np.uint32)).sum())
+    frames_total, bad_total, checked_total = frames_rank, bad_mask + bad_depth, len(check)
+    per_rank = [{"rank": rank, "streams": n, "frames": frames_rank, "frames_checked": len(check), "mismatching_values": bad_mask + bad_depth}]
+    if dist is not None:
+        # the trivial end-of-run gather (a few numbers per rank): frames, parity counts
+        frames_total, elapsed = sharding.gather_frame_counts(dist, frames_rank, elapsed, device=cdev)
+        t = torch.tensor([n, frames_rank, len(check), bad_mask + bad_depth], dtype=torch.int64, device=cdev)
+        outl = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outl, t)
+        per_rank = [{"rank": r, "streams": int(o[0]), "frames": int(o[1]), "frames_checked": int(o[2]), "mismatching_values": int(o[3])} for r, o in enumerate(outl)]
+        bad_total = sum(x["mismatching_values"] for x in per_rank)
+        checked_total = sum(x["frames_checked"] for x in per_rank)
+
     if rank == 0:
-        K = max(args.steps, 1)
-        frames = n * world * args.steps
-        value = frames / elapsed
+        value = frames_total / elapsed
         per = dict(breakdown)
-        per_timed = {"ms_raster": raster_ms, "ms_compare": compare_ms}
         px = W * H
         two = args.two_kernel
-        # dominant kernel and its algorithmic bytes per launch:
-        #   fused tile kernel : 9 B/pixel = 4 sensor read + 4 masked write + 1 mask write (8 without mask)
+        # algorithmic bytes per launch:
+        #   fused tile kernel : 9 B/pixel = 4 sensor read + 4 masked write + 1 mask write (8 without mask; 5 / 4 for 16UC1)
         #   two-kernel mode   : tile kernel writes the 4 B/pixel z-surface; compare moves 13 B/pixel
-        groups = 1
+        #   set-up + clip     : every vertex (12 B) and triangle (12 B indices + 4 B order) of the model once per launch --
+        #                       the geometry is shared by all streams; the records it writes are implementation traffic
+        mask_b = 0 if args.no_mask else 1
+        kernels = {}
         if two:
-            cands = {"tile_kernel<two_kernel>": (per_timed["ms_raster"], 4 * px * n), "compare_kernel": (per_timed["ms_compare"], (13 if (not args.no_mask) else 12) * px * n)}
+            kernels["tile_kernel<two_kernel>"] = (raster_ms, per["ms_raster"], 4 * px * n)
+            kernels["compare_kernel"] = (compare_ms, per["ms_compare"], ((6 if args.u16 else 12) + mask_b) * px * n)
         else:
-            bpp = (4 if args.u16 else 8) + (1 if (not args.no_mask) else 0)
-            cands = {"tile_kernel<fused>": (per_timed["ms_raster"], bpp * px * n)}
-        cands["setup_kernel+clip_kernel"] = (per["ms_setup"], 12 * wl0.n_vertices() + 16 * wl0.n_triangles())
-        dom = max((k for k in cands if not k.startswith("setup")), key=lambda k: cands[k][0])
-        dur_ms, alg_bytes = cands[dom]
-        achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+            kernels["tile_kernel<fused>"] = (raster_ms, per["ms_raster"], ((4 if args.u16 else 8) + mask_b) * px * n)
+        geo_bytes = sum(12 * g.variants[0].n_vertices() + 16 * g.variants[0].n_triangles() for g in share.groups)
+        kernels["setup_kernel+clip_kernel"] = (setup_ms, per["ms_setup"], geo_bytes)
         peak = 8000.0
-        # HBM bytes per launch from PMC counters are collected off-line (rocprofv3 cannot run inside the
-        # timed region): profiles/hbm_traffic.json holds the committed measurement of this same command
-        traffic = None
+        # Off-line counter data of this same command (rocprofv3 --pmc passes cannot run inside the timed region):
+        # used only when the committed measurement is of this exact workload, and labelled as such.
+        default_cmd = (args.workload == "c3" and n == 256 and (W, H) == (640, 480) and not args.no_mask and not args.u16 and args.triangles == 250000)
+        pmc = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            if (tj["kernel"] == dom and tj["streams"] == n and tj["width"] == W and tj["height"] == H
-                    and tj["triangles"] == wl0.meta["triangles"] and (not args.no_mask) and not args.u16):
-                traffic = tj["hbm_bytes_per_launch"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters.json")))
         except Exception:
-            traffic = None
-        # the kernels are VALU-issue-bound: wave64 VALU instructions per launch from the
-        # committed SQ counters of this same command, against the machine's issue peak
-        valu = None
+            pmc = None
+        valu_peak = None
         try:
-            vj = json.load(open(os.path.join(ROOT, "profiles", "valu_counts.json")))
-            cnt = vj["wave64_valu_instructions_per_launch"].get(dom)
-            if (cnt and vj["streams"] == n and vj["width"] == W and vj["height"] == H and vj["triangles"] == wl0.meta["triangles"]
-                    and (not args.no_mask) and not args.u16 and dur_ms > 0):
-                g = cnt / (dur_ms * 1e-3) / 1e9
-                valu = {"wave64_instructions_per_launch": cnt, "achieved_G_per_s": g, "peak_G_per_s": vj["peak_G_per_s"], "frac": g / vj["peak_G_per_s"],
-                        "note": "instruction count from profiles/valu_counts.json (rocprofv3 SQ_INSTS_VALU), duration live; peak = " + vj["peak_note"]}
+            valu_peak = json.load(open(os.path.join(ROOT, "profiles", "valu_peak.json")))
         except Exception:
-            valu = None
+            valu_peak = None
+
+        def kernel_entry(name):
+            dur_ms, iso_ms, alg_bytes = kernels[name]
+            achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+            e = {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                 "traffic": None, "avg_launch_ms": dur_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                 "isolated": {"avg_launch_ms": iso_ms, "frac": (alg_bytes / (iso_ms * 1e-3) / 1e9 / peak) if iso_ms > 0 else None,
+                              "note": "same kernel(s) with nothing else on the GPU (extra steps after the timed region)"}}
+            rec = (pmc or {}).get("kernels", {}).get(name) if (pmc and default_cmd and P == 1) else None
+            if rec:
+                e["traffic"] = rec.get("hbm_bytes_per_launch")
+                e["traffic_source"] = "OFFLINE: " + pmc.get("source", "profiles/pmc_counters.json") + " (rocprofv3 --pmc passes of this same command; not measured in this run)"
+                cnt = rec.get("wave64_valu_instructions_per_launch")
+                if cnt and dur_ms > 0:
+                    g = cnt / (dur_ms * 1e-3) / 1e9
+                    vi = {"wave64_instructions_per_launch": cnt, "instructions_source": e["traffic_source"], "achieved_G_per_s": g}
+                    if valu_peak:
+                        pk = valu_peak.get("mix_peak_G_per_s", {}).get(name) or valu_peak.get("peak_G_per_s")
+                        if pk:
+                            vi.update({"peak_G_per_s": pk, "frac": g / pk, "peak_source": "OFFLINE: profiles/valu_peak.json (scripts/valu_peak.hip micro-benchmark on this GPU model: measured wave64 issue rate of the kernel's instruction mix)"})
+                    e["valu_issue"] = vi
+            return e
+
+        entries = [kernel_entry(k) for k in kernels]
+        dom = max(entries, key=lambda e: e["avg_launch_ms"])       # the dominant kernel: longest average launch, no exclusions
+        roof = dict(dom)
+        roof.update({"launches_per_step": groups_per_batch, "timed_launches": timed,
+                     "all_kernels": [e for e in entries if e is not dom]})
         out = {
             "metric": "filtered depth frames/sec (640x480, PR2 URDF)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "timed_steps": timed_steps, "min_seconds": args.min_seconds,
+            "ms_per_step": elapsed / max(timed_steps, 1) * 1e3, "higher_is_better": True, "scaling": share.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "depth_format": "16UC1" if args.u16 else "32FC1",
-            "config": {"workload": "C3: %dx%d depth, synthetic PR2-like URDF (%d links with meshes, %d triangles), batch=%d concurrent streams per GPU, new joint state + camera pose every step"
-                                   % (W, H, wl0.meta["links_with_geometry"], wl0.meta["triangles"], n),
-                       "streams_per_gpu": n, "poses": "host matrices" if args.host_poses else "joint positions, forward kinematics on the GPU", "mode": "two-kernel" if two else "fused", "mask_output": (not args.no_mask),
-                       "parallelism": "stream-sharded x%d" % world, "pipelines_per_gpu": P},
-            "per_stream_fps": value / (n * world),
-            "kernel_ms_per_step": dict(per, note="stage breakdown from %d extra steps after the timed region: one pipeline, one batch in flight, every stage bracketed by HIP events (kernel times without another batch sharing the GPU); roofline.avg_launch_ms is measured inside the timed region, where %d pipelines overlap" % (extra, P)),
-            "rasteriser": {"triangles_per_s": wl0.n_triangles() * n / (per["ms_setup"] * 1e-3) if per["ms_setup"] > 0 else None,
-                           "binned_triangles_per_s": st["triangles_binned"] / (per["ms_raster"] * 1e-3) if per["ms_raster"] > 0 else None,
-                           "triangles_submitted": st["triangles_submitted"], "triangles_binned": st["triangles_binned"],
+            "config": {"workload": share.describe(),
+                       "streams_per_gpu": n if share.scaling == "weak" else [x["streams"] for x in per_rank], "streams_total": sum(x["streams"] for x in per_rank),
+                       "poses": "host matrices" if args.host_poses else "joint positions, forward kinematics on the GPU", "mode": "two-kernel" if two else "fused", "mask_output": (not args.no_mask),
+                       "parallelism": ("stream-sharded x%d" % world) + (" (shares of a %d-GPU job)" % job_world if args.shard_of else ""), "pipelines_per_gpu": P,
+                       "host_threads_pinned_to_gpu_numa_node": pinned_cpus},
+            "per_stream_fps": value / max(sum(x["streams"] for x in per_rank), 1),
+            "kernel_ms_per_step": dict(per, note="stage breakdown from %d extra steps after the timed region: one pipeline, one batch in flight, every stage bracketed by HIP events (ms_setup there = cull + set-up + clip + waiting for the pose stage); roofline.avg_launch_ms is measured inside the timed region" % extra),
+            "rasteriser": {"triangles_per_s": float(share.triangles_per_stream().sum()) / (setup_ms * 1e-3) if setup_ms > 0 else None,
+                           "binned_triangles_per_s": st["triangles_binned"] / (raster_ms * 1e-3) if raster_ms > 0 else None,
+                           "triangles_submitted": int(share.triangles_per_stream().sum()), "triangles_binned": st["triangles_binned"],
                            "triangles_clipped": st["triangles_clipped"], "bin_entries": st["bin_entries"],
                            "fragments_binned": st["fragments_binned"], "max_bin_fill": st["max_bin_fill"], "max_fragment_bin_fill": st["max_fbin_fill"], "bin_capacity": st["bin_capacity"], "regrowths": st["regrowths"]},
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
-                         "frac": achieved / peak, "traffic": traffic, "launches_per_step": groups,
-                         "avg_launch_ms": dur_ms, "timed_launches": timed, "algorithmic_bytes_per_launch": alg_bytes,
-                         "valu_issue": valu,
-                         "isolated": {"avg_launch_ms": per["ms_compare"] if dom == "compare_kernel" else per["ms_raster"],
-                                      "frac": (alg_bytes / ((per["ms_compare"] if dom == "compare_kernel" else per["ms_raster"]) * 1e-3) / 1e9 / peak) if per["ms_raster"] > 0 else None,
-                                      "note": "same kernel with nothing else on the GPU (extra steps after the timed region)"}},
+            "roofline": roof,
+            "parity": {"frames_checked": checked_total, "mismatching_values": bad_total, "mask_mismatch_pixels": bad_mask, "depth_mismatch_pixels": bad_depth,
+                       "per_rank": per_rank, "note": "every rank checks --check-frames frames of its last step against the oracle; mask/depth split is rank 0's"},
         }
-        # ---- parity spot check + CPU baseline (oracle = checker / reported baseline only) ------
-        if world == 1:
-            from oracle import bindings as O
-            from realtime_urdf_filter_amd.filter import depth_f32_to_u16, depth_u16_to_f32
-            v_last = k_last % V
-            wl = variants[v_last]
-            d_masked, d_mask = d_masked_set[k_last % n_sets], d_mask_set[k_last % n_sets]
-            hm = d_masked.cpu().numpy()
-            hk = d_mask.cpu().numpy() if (not args.no_mask) else None
-            hd = d_depth[v_last].cpu().numpy()
-            if args.u16:
-                hm = hm.view(np.uint16)
-                hd = depth_u16_to_f32(hd.view(np.uint16))
-            if args.host_poses:
-                link_tf_all, cam_all = wl.link_tf[0], wl.cam_tf
-            else:
-                # the oracle is fed the very matrices the GPU's forward kinematics produced
-                link_tf_all, cam_all = ctx.read_poses(n, wl.link_tf[0].shape[1])
-                out["fk"] = {"on_device": True, "max_abs_diff_vs_host_fk": float(max(np.abs(link_tf_all - wl.link_tf[0]).max(), np.abs(cam_all - wl.cam_tf).max()))}
-            bad_mask = bad_depth = 0
-            t_cpu = 0.0
-            n_cpu = 0
-            budget = args.cpu_seconds
-            s = 0
-            while s < n and (s < args.check_frames or (budget > 0 and t_cpu < budget)):
+        if fk_err is not None:
+            out["fk"] = {"on_device": True, "max_abs_diff_vs_host_fk": fk_err}
+        # ---- CPU baseline: the oracle port on this box's host cores, on a bounded sample of the same batch ----
+        if world == 1 and args.cpu_seconds > 0 and n > 0:
+            cores = len(os.sched_getaffinity(0))
+            # one prepared oracle call per worker thread and then some (inputs: the first streams of the last batch,
+            # cycled); a thread only ever runs its own prepared frames, so output planes are never shared
+            n_in = min(n, 64)
+            inputs = []
+            for s in range(n_in):
+                hd, _, _ = fetch(s)
+                inputs.append((hd,) + tuple(share.oracle_frame(k_last, s, link_dev, cam_dev)))
+            prepared = [O.PreparedFrame(*inputs[i % n_in], max_diff=wl0.max_diff, replace_value=wl0.replace_value) for i in range(max(cores, n_in))]
+
+            def worker(t, n_threads, seconds):
+                mine = prepared[t::n_threads]
                 c0 = time.perf_counter()
-                draws = [(link_tf_all[s, li], d.pre_op, d.op, d.verts, d.tris) for li, dl in enumerate(wl.models[0]) for d in dl]
-                om, ok = O.filter_frame(hd[s], wl.projection[s], draws, wl.offset_inv[s], cam_all[s],
-                                        max_diff=wl.max_diff, replace_value=wl.replace_value)
-                t_cpu += time.perf_counter() - c0
-                n_cpu += 1
-                if hk is not None:
-                    bad_mask += int((ok != hk[s]).sum())
-                bad_depth += int((depth_f32_to_u16(om) != hm[s]).sum()) if args.u16 else int((om.view(np.uint32) != hm[s].view(np.uint32)).sum())
-                s += 1
-            out["parity"] = {"frames_checked": n_cpu, "mask_mismatch_pixels": bad_mask, "depth_mismatch_pixels": bad_depth}
-            if n_cpu:
-                out["cpu_baseline"] = {"value": n_cpu / t_cpu, "unit": "frames/s", "cores": 1, "kind": "port",
-                                       "sample": "%d frames of the same batch through oracle/rtuf_oracle.c (single thread, %.1f s)" % (n_cpu, t_cpu)}
+                done = 0
+                while time.perf_counter() - c0 < seconds:
+                    mine[done % len(mine)].run()
+                    done += 1
+                return done, time.perf_counter() - c0
+
+            n1, t1 = worker(0, 1, args.cpu_seconds)
+            from concurrent.futures import ThreadPoolExecutor
+            # the oracle is a C function behind ctypes (the GIL is released for the call): threads give real cores
+            c0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=cores) as ex:
+                res = list(ex.map(lambda t: worker(t, cores, args.cpu_seconds), range(cores)))
+            tN = time.perf_counter() - c0
+            nN = sum(r[0] for r in res)
+            cb = {"value": n1 / t1, "unit": "frames/s", "cores": 1, "kind": "port",
+                  "sample": "%d frames of the last batch (first %d streams, cycled) through oracle/rtuf_oracle.c, single thread, %.1f s" % (n1, n_in, t1),
+                  "all_cores": {"value": nN / tN, "unit": "frames/s", "cores": cores,
+                                "sample": "%d frames of the same set on %d threads (one oracle call per frame, GIL released for the call), %.1f s" % (nN, cores, tN)}}
+            try:
+                lp = json.load(open(os.path.join(ROOT, "profiles", "llvmpipe_baseline.json")))
+                cb["reference_llvmpipe"] = dict(lp.get("bench_workload", {}), source="OFFLINE: profiles/llvmpipe_baseline.json -- the reference's own GLSL on Mesa llvmpipe, timed in the development container (scripts/llvmpipe_baseline.py); /root/reference and swrast_dri.so do not exist on the GPU box")
+            except Exception:
+                pass
+            out["cpu_baseline"] = cb
         print(json.dumps(out))
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTUF_ABI_VERSION 2
+#define RTUF_ABI_VERSION 3
 
 typedef struct rtuf_context rtuf_context;
 
@@ -53,11 +53,13 @@ enum { RTUF_OP_NONE = 0, RTUF_OP_SCALE = 1, RTUF_OP_TRANSLATE = 2 };
 
 /* rtuf_params.flags */
 enum {
-  RTUF_FLAG_BACKGROUND_QUAD = 1u << 0,  /* draw the background quad at 0.99*far (src/urdf_filter.cpp:591-596); reference behaviour */
+  /* (bit 0 was RTUF_FLAG_BACKGROUND_QUAD up to ABI 2.  The reference always draws the background quad at 0.99*far,
+   * src/urdf_filter.cpp:591-596, and so does this library: there is nothing to switch.) */
   RTUF_FLAG_TWO_KERNEL      = 1u << 1,  /* rasteriser writes the z-surface to HBM and a separate compare kernel consumes it
                                            (default: compare fused into the tile kernel, the z-surface never leaves LDS)        */
-  RTUF_FLAG_DEFAULT = RTUF_FLAG_BACKGROUND_QUAD
-  /* bits 8..23 are timing experiments of the kernels (scripts/ablate_*.sh): they skip work, the images are wrong */
+  RTUF_FLAG_DEFAULT = 0
+  /* Any other bit makes rtuf_create / rtuf_set_params fail with RTUF_ERR_INVALID.  (The kernels' timing experiments
+   * live only in a separate library built with -DRTUF_ABLATE for scripts/ablate_*.sh; the product has no such code.) */
 };
 
 /* Replaces the constructor's rosparam parsing (src/urdf_filter.cpp:43-118) and the
@@ -137,6 +139,13 @@ int rtuf_set_cameras(rtuf_context *ctx, int first_stream, int n_streams, const d
                      const double *camera_offset_inv, const double *camera_tf);
 int rtuf_set_link_poses_batch(rtuf_context *ctx, int first_stream, int n_streams, int model,
                               const double *link_tf, int n_links);
+/* camera_tx_ / camera_ty_ of getProjectionMatrix (src/urdf_filter.cpp:481-482) for streams whose camera transform
+ * is derived on the device (rtuf_set_joint_positions with camera_frame >= 0): the forward-kinematics kernel moves
+ * the camera origin by tx along the transform's x axis and ty along its y axis, src/urdf_filter.cpp:607-611.
+ * (A camera_tf handed to rtuf_set_camera(s) has the shift applied by the caller already and is not touched.)
+ * NULL = 0 for all n streams. */
+int rtuf_set_camera_shift(rtuf_context *ctx, int first_stream, int n_streams, const double *camera_tx,
+                          const double *camera_ty);
 
 /* ---- on-device forward kinematics --------------------------------------------------
  * Replaces the per-renderable TF lookups of URDFRenderer::update_link_transforms
@@ -155,7 +164,8 @@ int rtuf_set_kinematics(rtuf_context *ctx, int model, int n_frames, const int32_
 /* Joint positions q[n_streams][n_frames] (entries of fixed joints are ignored) and, optionally, the
  * pose of the root frame in the fixed frame root_tf[n_streams][16] (NULL = identity).  With
  * camera_frame >= 0 the camera transform of each stream becomes inverse(fixed<-camera_frame)
- * (a camera mounted on the robot); with -1 it stays what rtuf_set_camera(s) set.  Overrides
+ * (a camera mounted on the robot, shifted by rtuf_set_camera_shift); with -1 it is what rtuf_set_camera(s) set
+ * (also again after an earlier call with camera_frame >= 0).  Overrides
  * rtuf_set_link_poses for this model on these streams until rtuf_set_link_poses is called again. */
 int rtuf_set_joint_positions(rtuf_context *ctx, int first_stream, int n_streams, int model, const double *q,
                              const double *root_tf, int camera_frame);
@@ -235,8 +245,8 @@ typedef struct {
 } rtuf_stats;
 int rtuf_get_stats(rtuf_context *ctx, rtuf_stats *out);
 /* Per-kernel HIP-event timing (off by default: every event costs a few microseconds of stream
- * time).  on = 1: every stage (ms_pose, ms_setup, ms_raster, ms_compare, ms_total);  on = 2: only
- * around the tile kernel (and the compare kernel in two-kernel mode): ms_raster / ms_compare;
+ * time).  on = 1: every stage (ms_pose, ms_setup, ms_raster, ms_compare, ms_total);  on = 2: only the raster
+ * stage's big kernels: ms_setup (set-up + clip kernels), ms_raster (tile kernel), ms_compare (two-kernel mode);
  * on = 3: as 2, but only every fourth batch is timed (timed_batches and the sums count those). */
 int rtuf_enable_timing(rtuf_context *ctx, int on);
 

@@ -66,6 +66,54 @@ def set_variants(**kw):
 IDENTITY = np.eye(4).T.reshape(16).copy()
 
 
+class PreparedFrame:
+    """The ctypes structures of one oracle call built once; run() then spends its time in the C function only (ctypes
+    releases the GIL for the call), so several threads can run prepared frames on several cores (bench.py's all-cores
+    leg).  One PreparedFrame must not be run by two threads at once (it owns its output planes)."""
+
+    def __init__(self, depth, projection, draws, camera_offset_inv=None, camera_tf=None, z_near=0.1, z_far=8.0,
+                 max_diff=0.05, replace_value=0.0, want_debug=False):
+        depth = np.ascontiguousarray(depth, np.float32)
+        H, W = depth.shape
+        self._keep = [depth]
+        arr = (Draw * max(len(draws), 1))()
+        for i, (tf, pre, op, v, t) in enumerate(draws):
+            v = np.ascontiguousarray(v, np.float32).reshape(-1, 3)
+            t = np.ascontiguousarray(t, np.uint32).reshape(-1, 3)
+            self._keep += [v, t]
+            arr[i].link_tf[:] = list(np.asarray(tf, np.float64).reshape(16))
+            arr[i].pre_op = int(pre)
+            arr[i].op[:] = [float(x) for x in op]
+            arr[i].verts = v.ctypes.data
+            arr[i].nverts = len(v)
+            arr[i].tris = t.ctypes.data
+            arr[i].ntris = len(t)
+        fr = Frame()
+        fr.width, fr.height, fr.depth = W, H, depth.ctypes.data
+        fr.z_near, fr.z_far, fr.max_diff, fr.replace_value = z_near, z_far, max_diff, replace_value
+        fr.projection[:] = list(np.asarray(projection, np.float64).reshape(16))
+        fr.camera_offset_inv[:] = list(IDENTITY if camera_offset_inv is None else np.asarray(camera_offset_inv, np.float64).reshape(16))
+        fr.camera_tf[:] = list(IDENTITY if camera_tf is None else np.asarray(camera_tf, np.float64).reshape(16))
+        fr.draws = ctypes.addressof(arr)
+        fr.ndraws = len(draws)
+        self._arr, self.fr = arr, fr
+        self.masked = np.zeros((H, W), np.float32)
+        self.mask = np.zeros((H, W), np.uint8)
+        self.dbg = Debug()
+        self.zwin = self.prim = None
+        if want_debug:
+            self.zwin = np.zeros((H, W), np.float32)
+            self.prim = np.zeros((H, W), np.int32)
+            self.dbg.zwin, self.dbg.prim = self.zwin.ctypes.data, self.prim.ctypes.data
+        self._fn = lib().rtuf_oracle_filter
+
+    def run(self):
+        rc = self._fn(ctypes.byref(self.fr), self.masked.ctypes.data, self.mask.ctypes.data, ctypes.byref(self.dbg))
+        if rc != 0:
+            raise RuntimeError("oracle failed: %d" % rc)
+        return self.masked, self.mask
+
+
 def filter_frame(depth, projection, draws, camera_offset_inv=None, camera_tf=None, z_near=0.1, z_far=8.0,
                  max_diff=0.05, replace_value=0.0, want_debug=False):
     """One frame through the oracle.
@@ -74,39 +122,8 @@ def filter_frame(depth, projection, draws, camera_offset_inv=None, camera_tf=Non
     Returns (masked f32 [H,W], mask u8 [H,W]) or, with want_debug, additionally
     (zwin f32 [H,W], prim i32 [H,W], (tris_in, tris_setup, frags)).
     """
-    depth = np.ascontiguousarray(depth, np.float32)
-    H, W = depth.shape
-    keep = []
-    arr = (Draw * max(len(draws), 1))()
-    for i, (tf, pre, op, v, t) in enumerate(draws):
-        v = np.ascontiguousarray(v, np.float32).reshape(-1, 3)
-        t = np.ascontiguousarray(t, np.uint32).reshape(-1, 3)
-        keep += [v, t]
-        arr[i].link_tf[:] = list(np.asarray(tf, np.float64).reshape(16))
-        arr[i].pre_op = int(pre)
-        arr[i].op[:] = [float(x) for x in op]
-        arr[i].verts = v.ctypes.data
-        arr[i].nverts = len(v)
-        arr[i].tris = t.ctypes.data
-        arr[i].ntris = len(t)
-    fr = Frame()
-    fr.width, fr.height, fr.depth = W, H, depth.ctypes.data
-    fr.z_near, fr.z_far, fr.max_diff, fr.replace_value = z_near, z_far, max_diff, replace_value
-    fr.projection[:] = list(np.asarray(projection, np.float64).reshape(16))
-    fr.camera_offset_inv[:] = list(IDENTITY if camera_offset_inv is None else np.asarray(camera_offset_inv, np.float64).reshape(16))
-    fr.camera_tf[:] = list(IDENTITY if camera_tf is None else np.asarray(camera_tf, np.float64).reshape(16))
-    fr.draws = ctypes.addressof(arr)
-    fr.ndraws = len(draws)
-    masked = np.zeros((H, W), np.float32)
-    mask = np.zeros((H, W), np.uint8)
-    dbg = Debug()
+    f = PreparedFrame(depth, projection, draws, camera_offset_inv, camera_tf, z_near, z_far, max_diff, replace_value, want_debug)
+    masked, mask = f.run()
     if want_debug:
-        zwin = np.zeros((H, W), np.float32)
-        prim = np.zeros((H, W), np.int32)
-        dbg.zwin, dbg.prim = zwin.ctypes.data, prim.ctypes.data
-    rc = lib().rtuf_oracle_filter(ctypes.byref(fr), masked.ctypes.data, mask.ctypes.data, ctypes.byref(dbg))
-    if rc != 0:
-        raise RuntimeError("oracle failed: %d" % rc)
-    if want_debug:
-        return masked, mask, zwin, prim, (dbg.n_tris_in, dbg.n_tris_setup, dbg.n_frags)
+        return masked, mask, f.zwin, f.prim, (f.dbg.n_tris_in, f.dbg.n_tris_setup, f.dbg.n_frags)
     return masked, mask

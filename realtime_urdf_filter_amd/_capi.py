@@ -15,15 +15,15 @@ _LIB_PATH = os.environ.get("RTUF_LIB") or os.path.join(os.path.dirname(os.path.a
 RTUF_OK = 0
 RTUF_ERR_NO_DEVICE = -2
 OP_NONE, OP_SCALE, OP_TRANSLATE = 0, 1, 2
-FLAG_BACKGROUND_QUAD = 1
 FLAG_TWO_KERNEL = 2
+ABI_VERSION = 3
 
 #: every symbol include/rtuf.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "rtuf_default_params", "rtuf_abi_version", "rtuf_create", "rtuf_destroy", "rtuf_last_error",
     "rtuf_set_params", "rtuf_add_model", "rtuf_add_link", "rtuf_add_draw", "rtuf_finalize_models",
     "rtuf_num_links", "rtuf_num_triangles", "rtuf_set_stream_models", "rtuf_set_camera",
-    "rtuf_projection_from_intrinsics", "rtuf_set_link_poses", "rtuf_set_cameras", "rtuf_set_link_poses_batch", "rtuf_set_kinematics", "rtuf_set_joint_positions", "rtuf_debug_read_poses", "rtuf_filter_batch",
+    "rtuf_projection_from_intrinsics", "rtuf_set_link_poses", "rtuf_set_cameras", "rtuf_set_camera_shift", "rtuf_set_link_poses_batch", "rtuf_set_kinematics", "rtuf_set_joint_positions", "rtuf_debug_read_poses", "rtuf_filter_batch",
     "rtuf_filter_batch_device", "rtuf_filter_batch_u16", "rtuf_filter_batch_device_u16", "rtuf_filter", "rtuf_get_masked_depth", "rtuf_get_mask", "rtuf_sync",
     "rtuf_stream", "rtuf_get_stats", "rtuf_enable_timing", "rtuf_debug_read_zsurface",
     "rtuf_filter_batch_async", "rtuf_filter_batch_u16_async", "rtuf_wait_oldest", "rtuf_host_alloc", "rtuf_host_free",
@@ -117,6 +117,7 @@ def load_library(path=None):
     lib.rtuf_set_link_poses.argtypes = [vp, ci, ci, vp, ci]
     lib.rtuf_set_cameras.argtypes = [vp, ci, ci, vp, vp, vp]
     lib.rtuf_set_link_poses_batch.argtypes = [vp, ci, ci, ci, vp, ci]
+    lib.rtuf_set_camera_shift.argtypes = [vp, ci, ci, vp, vp]
     lib.rtuf_set_kinematics.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, ci]
     lib.rtuf_set_joint_positions.argtypes = [vp, ci, ci, ci, vp, vp, ci]
     lib.rtuf_debug_read_poses.argtypes = [vp, ci, vp, vp]
@@ -237,6 +238,13 @@ class Context:
                 for a in (projections, camera_offset_inv, camera_tf)]
         n = max(len(a) for a in arrs if a is not None)
         self._check(self._lib.rtuf_set_cameras(self._h, first_stream, n, *[_ptr(a) for a in arrs]))
+
+    def set_camera_shift(self, first_stream, camera_tx, camera_ty):
+        """camera_tx_/camera_ty_ (src/urdf_filter.cpp:607-611) for cameras posed by on-device forward kinematics."""
+        tx = np.ascontiguousarray(camera_tx, np.float64).reshape(-1)
+        ty = np.ascontiguousarray(camera_ty, np.float64).reshape(-1)
+        assert len(tx) == len(ty)
+        self._check(self._lib.rtuf_set_camera_shift(self._h, first_stream, len(tx), _ptr(tx), _ptr(ty)))
 
     def set_link_poses_batch(self, first_stream, model, link_tf):
         a = np.ascontiguousarray(link_tf, np.float64)

@@ -52,6 +52,16 @@ struct HostModel { std::vector<HostLink> links; int link_base = 0; Kinematics ki
 
 char g_create_error[512] = "";
 
+constexpr uint32_t kKnownFlags = RTUF_FLAG_TWO_KERNEL;
+inline bool flags_valid(uint32_t flags)
+{
+#ifdef RTUF_ABLATE
+  (void)flags; return true;          // timing-experiment build: bits 8.. select what the kernels skip
+#else
+  return (flags & ~kKnownFlags) == 0u;
+#endif
+}
+
 }  // namespace
 
 struct rtuf_context {
@@ -64,6 +74,7 @@ struct rtuf_context {
   // models (host)
   std::vector<HostModel> models;
   bool finalized = false;
+  bool broken = false;                 // a bin regrowth failed half-way: the bins are gone, every later filter call fails
   int n_links = 0, n_draws = 0, n_chunks = 0;
   int64_t n_tris = 0;
   uint32_t bg_chunk = 0;
@@ -189,6 +200,10 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
              ndev, device_id, e == hipSuccess ? "ok" : hipGetErrorString(e));
     return RTUF_ERR_NO_DEVICE;
   }
+  if (params && !flags_valid(params->flags)) {
+    snprintf(g_create_error, sizeof g_create_error, "unknown rtuf_params.flags bits 0x%x", params->flags & ~kKnownFlags);
+    return RTUF_ERR_INVALID;
+  }
   rtuf_context* c = new (std::nothrow) rtuf_context();
   if (!c) return RTUF_ERR_OOM;
   c->device = device_id;
@@ -258,6 +273,7 @@ void rtuf_destroy(rtuf_context* c)
 int rtuf_set_params(rtuf_context* c, const rtuf_params* p)
 {
   if (!c || !p) return RTUF_ERR_INVALID;
+  if (!flags_valid(p->flags)) return c->fail(RTUF_ERR_INVALID, "unknown rtuf_params.flags bits 0x%x", p->flags & ~kKnownFlags);
   WAIT_IF_PENDING(c);
   // the background quad's geometry (0.99 * far, src/urdf_filter.cpp:591-596) is built by rtuf_finalize_models
   if (c->finalized && p->far_plane != c->params.far_plane)
@@ -354,6 +370,7 @@ static int alloc_frame_buffers(rtuf_context* c)
     memcpy(c->h_cams[s].projection, I, sizeof I);
     memcpy(c->h_cams[s].offset_inv, I, sizeof I);
     memcpy(c->h_cams[s].cam_tf, I, sizeof I);
+    c->h_cams[s].shift[0] = c->h_cams[s].shift[1] = 0.0;
     for (size_t l = 0; l < L; l++) memcpy(c->h_link_tf + ((size_t)s * L + l) * 16, I, sizeof I);
     c->h_model_mask[s] = ~0ull;
   }
@@ -381,7 +398,7 @@ static int alloc_frame_buffers(rtuf_context* c)
   HIP_TRY(c, hipMalloc(&c->d_fbin_count, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(c->d_fbin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
-  for (auto& b : c->batch) HIP_TRY(c, hipMalloc(&b.d_items, (size_t)c->n_chunks * ((G + kStreamsPerBlock - 1) / kStreamsPerBlock) * sizeof(WorkItem)));
+  for (auto& b : c->batch) HIP_TRY(c, hipMalloc(&b.d_items, (size_t)c->n_chunks * (size_t)max_items_per_chunk(G) * sizeof(WorkItem)));
   if (c->params.flags & RTUF_FLAG_TWO_KERNEL)
     HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)G * c->width * c->height * sizeof(float)));
   return RTUF_OK;
@@ -408,7 +425,7 @@ int rtuf_finalize_models(rtuf_context* c)
     std::vector<uint32_t> touched;
     std::vector<uint32_t> perm(nt);
     for (uint32_t i = 0; i < nt; i++) perm[i] = i;
-    if (nt > (uint32_t)kBlock && !(c->params.flags & 0x8000u)) {        // (0x8000: timing experiment, file order)
+    if (nt > (uint32_t)kBlock && !RTUF_ABL(c->params.flags, 0x8000u)) {        // (0x8000 in RTUF_ABLATE builds: timing experiment, file order)
       float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
       for (size_t i = 0; i < v.size(); i++) { lo[i % 3] = std::min(lo[i % 3], v[i]); hi[i % 3] = std::max(hi[i % 3], v[i]); }
       auto spread = [](uint32_t x) {          // 10 bits -> every third bit
@@ -461,25 +478,18 @@ int rtuf_finalize_models(rtuf_context* c)
       }
       ch.tri_count = n; ch.vert_count = nv;
       {
-        // bounding sphere (centre of the box, radius padded): used for whole-chunk frustum culling
+        // bounding box (centre + half extents, padded): used for whole-chunk frustum culling
         float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
         for (uint32_t q = 0; q < nv; q++) {
           const float4& p = cverts[ch.vert_begin + q];
           const float pp[3] = {p.x, p.y, p.z};
           for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], pp[k]); hi[k] = std::max(hi[k], pp[k]); }
         }
-        double r2 = 0;
         for (int k = 0; k < 3; k++) {
           ch.center[k] = 0.5f * (lo[k] + hi[k]);
           // half extent about the rounded centre, rounded up (the cull test must stay conservative)
           ch.half[k] = std::nextafter(std::max(hi[k] - ch.center[k], ch.center[k] - lo[k]), INFINITY) * 1.0001f + 1e-7f;
         }
-        for (uint32_t q = 0; q < nv; q++) {
-          const float4& p = cverts[ch.vert_begin + q];
-          const double dx = (double)p.x - ch.center[0], dy = (double)p.y - ch.center[1], dz = (double)p.z - ch.center[2];
-          r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
-        }
-        ch.radius = (float)(std::sqrt(r2) * 1.0001 + 1e-6);
       }
       chunks.push_back(ch);
       for (uint32_t id : touched) local[id] = -1;
@@ -599,7 +609,8 @@ int rtuf_set_link_poses(rtuf_context* c, int stream, int model, const double* li
   const HostModel& m = c->models[model];
   if (n_links != (int)m.links.size()) return c->fail(RTUF_ERR_INVALID, "model %d has %d links, got %d", model, (int)m.links.size(), n_links);
   memcpy(c->h_link_tf + ((size_t)stream * c->n_links + m.link_base) * 16, link_tf, sizeof(double) * 16 * (size_t)n_links);
-  if (m.kin.h_enabled && m.kin.h_enabled[stream]) { c->models[model].kin.h_enabled[stream] = 0; c->models[model].kin.dirty_aux = true; }
+  // (a stream that leaves forward kinematics also gets its host-set camera back: the FK kernel may have overwritten cam_tf)
+  if (m.kin.h_enabled && m.kin.h_enabled[stream]) { c->models[model].kin.h_enabled[stream] = 0; c->models[model].kin.dirty_aux = true; for (auto& b : c->batch) b.dirty_cams = true; }
   for (auto& b : c->batch) b.dirty_link_tf = true;
   return RTUF_OK;
 }
@@ -621,6 +632,20 @@ int rtuf_set_cameras(rtuf_context* c, int first, int n, const double* projection
   return RTUF_OK;
 }
 
+int rtuf_set_camera_shift(rtuf_context* c, int first, int n, const double* camera_tx, const double* camera_ty)
+{
+  if (!c) return RTUF_ERR_INVALID;
+  WAIT_IF_PENDING(c);
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (first < 0 || n < 0 || first + n > c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream range %d+%d", first, n);
+  for (int s = 0; s < n; s++) {
+    c->h_cams[first + s].shift[0] = camera_tx ? camera_tx[s] : 0.0;
+    c->h_cams[first + s].shift[1] = camera_ty ? camera_ty[s] : 0.0;
+  }
+  for (auto& b : c->batch) b.dirty_cams = true;
+  return RTUF_OK;
+}
+
 int rtuf_set_link_poses_batch(rtuf_context* c, int first, int n, int model, const double* link_tf, int n_links)
 {
   if (!c || !link_tf) return RTUF_ERR_INVALID;
@@ -633,7 +658,7 @@ int rtuf_set_link_poses_batch(rtuf_context* c, int first, int n, int model, cons
   for (int s = 0; s < n; s++) {
     memcpy(c->h_link_tf + ((size_t)(first + s) * c->n_links + m.link_base) * 16, link_tf + (size_t)s * n_links * 16,
            sizeof(double) * 16 * (size_t)n_links);
-    if (m.kin.h_enabled && m.kin.h_enabled[first + s]) { c->models[model].kin.h_enabled[first + s] = 0; c->models[model].kin.dirty_aux = true; }
+    if (m.kin.h_enabled && m.kin.h_enabled[first + s]) { c->models[model].kin.h_enabled[first + s] = 0; c->models[model].kin.dirty_aux = true; for (auto& b : c->batch) b.dirty_cams = true; }
   }
   for (auto& b : c->batch) b.dirty_link_tf = true;
   return RTUF_OK;
@@ -738,6 +763,8 @@ int rtuf_set_joint_positions(rtuf_context* c, int first, int n, int model, const
     }
     k.dirty_aux = true;
   }
+  // leaving the robot-mounted camera: both slots take the host-set camera transforms again
+  if (camera_frame != k.camera_frame) for (auto& b : c->batch) b.dirty_cams = true;
   k.camera_frame = camera_frame;
   k.any_enabled = true;
   return RTUF_OK;
@@ -776,18 +803,22 @@ static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
   while (fcap < fneeded) fcap *= 2;
   hipFree(c->d_bins); c->d_bins = nullptr;
   hipFree(c->d_fbins); c->d_fbins = nullptr;
+  // (the old bins had to go first: together with the new ones they may not fit)  A failure from here on leaves
+  // the context without bins: it is marked unusable instead of running kernels on null pointers.
+  c->broken = true;
   int G = c->group;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));        // (the old bins are freed already)
   const size_t budget = std::max(free_b / 2, (size_t)1 << 30);
   auto bytes = [&](int g) { return (size_t)g * tiles * ((size_t)cap * sizeof(PackedTri) + (size_t)fcap * sizeof(Frag)); };
   while (G > 1 && bytes(G) > budget) G = (G + 1) / 2;
-  if (bytes(G) > ((size_t)160 << 30)) return c->fail(RTUF_ERR_CAPACITY, "bin capacity %u/%u too large", cap, fcap);
+  if (bytes(G) > ((size_t)160 << 30)) { return c->fail(RTUF_ERR_CAPACITY, "bin capacity %u/%u too large", cap, fcap); }
   c->group = G;
   c->capacity = cap;
   c->fcapacity = fcap;
   HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(PackedTri)));
   HIP_TRY(c, hipMalloc(&c->d_fbins, (size_t)G * tiles * fcap * sizeof(Frag)));
+  c->broken = false;
   c->stats.regrowths++;
   return RTUF_OK;
 }
@@ -883,6 +914,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     // part of the list beyond the (estimated) grid with a second launch, it is run again if the estimate
     // was too small (retire_oldest); batches of several groups reuse the counter, so they sweep
     const bool single_group = n <= c->group;
+    if (b.timing >= 2) hipEventRecord(get_event(b, ev++), st);     // (after the wait for the pose stage: set-up + clip time only)
     const uint32_t grid = launch_setup(sa, c->items_hint, !single_group, st);
     b.setup_grid = single_group ? grid : 0xffffffffu;
     launch_clip(sa, st);
@@ -984,16 +1016,17 @@ static int retire_oldest(rtuf_context* c)
           e += 3;
         }
         hipEventElapsedTime(&ms, b.events[0], b.events[e]); c->stats.ms_total = ms;
-      } else if (b.timing == 2 && b.events.size() >= 2) {
-        // events: (tile_begin, tile_end[, compare_end]) per group
+      } else if (b.timing == 2 && b.events.size() >= 3) {
+        // events: (setup_begin, tile_begin, tile_end[, compare_end]) per group
         const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
         float ms = 0;
         c->stats.ms_pose = c->stats.ms_setup = c->stats.ms_raster = c->stats.ms_compare = c->stats.ms_total = 0;
         size_t e = 0;
         for (int base = 0; base < b.n; base += c->group) {
-          hipEventElapsedTime(&ms, b.events[e], b.events[e + 1]); c->stats.ms_raster += ms;
-          if (two) { hipEventElapsedTime(&ms, b.events[e + 1], b.events[e + 2]); c->stats.ms_compare += ms; }
-          e += two ? 3 : 2;
+          hipEventElapsedTime(&ms, b.events[e], b.events[e + 1]); c->stats.ms_setup += ms;
+          hipEventElapsedTime(&ms, b.events[e + 1], b.events[e + 2]); c->stats.ms_raster += ms;
+          if (two) { hipEventElapsedTime(&ms, b.events[e + 2], b.events[e + 3]); c->stats.ms_compare += ms; }
+          e += two ? 4 : 3;
         }
       }
       if (b.timing) {
@@ -1036,6 +1069,7 @@ static int retire_oldest(rtuf_context* c)
 
 static int submit_batch(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask, bool u16)
 {
+  if (c->broken) return c->fail(RTUF_ERR_STATE, "context unusable: a bin regrowth failed (%s)", c->error.c_str());
   hipSetDevice(c->device);
   if ((c->params.flags & RTUF_FLAG_TWO_KERNEL) && !c->d_zsurface)
     HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));

@@ -23,6 +23,15 @@
 
 namespace rtuf {
 
+// Timing experiments (scripts/ablate_*.sh) skip work and produce WRONG images.  They exist only in a library
+// built with -DRTUF_ABLATE (lib/variants/librtuf_ablate.so); the product library contains none of that code and
+// rtuf_create / rtuf_set_params reject the flag bits.
+#ifdef RTUF_ABLATE
+#define RTUF_ABL(flags, bits) (((flags) & (bits)) != 0u)
+#else
+#define RTUF_ABL(flags, bits) false
+#endif
+
 #ifndef RTUF_TILE_W
 #define RTUF_TILE_W 64
 #endif
@@ -90,7 +99,7 @@ struct Chunk {                  // <= 256 consecutive triangles of one draw + th
   uint32_t reserved;
   uint32_t pad;
   float center[3];              // object-space bounding box of the chunk's vertices: centre ...
-  float radius;                 // (radius of the enclosing sphere: unused by the kernels, kept for diagnostics)
+  uint32_t pad1;
   float half[3];                // ... and half extents
   uint32_t pad2;
 };
@@ -107,6 +116,8 @@ struct Camera {
   double projection[16];
   double offset_inv[16];
   double cam_tf[16];
+  double shift[2];              // camera_tx_, camera_ty_ (src/urdf_filter.cpp:607-611): applied by the forward-kinematics
+                                // kernels when they derive cam_tf from a robot frame; a host-supplied cam_tf has them applied already
 };
 
 struct alignas(16) ClipItem {   // one triangle that crosses a frustum plane; self-contained, so the clip
@@ -151,17 +162,19 @@ struct alignas(32) WorkItem {
   uint16_t slot[4];
 };
 static_assert(sizeof(WorkItem) == 32, "WorkItem is two 16-byte loads");
-
-struct FrameConsts {
-  int width, height;
-  int tiles_x, tiles_y;
-  float z_near, z_far, max_diff, replace_value;
-  float bg_z;                   // window z of the background quad (constant plane)
-  uint32_t bg_key_hi;           // its 24-bit depth value
-  uint32_t flags;
-  uint32_t capacity;
-};
-
+// Upper bound of the work items one chunk can produce for a launch group of `group` streams: cull_kernel
+// compacts the visible streams per block of kBlock stream slots and rounds EACH block's count up to whole
+// items, so a group of more than kBlock streams can need more than ceil(group / kStreamsPerBlock).  Sizes the
+// items array and the set-up kernel's worst-case grid.
+inline int max_items_per_chunk(int group)
+{
+  int n = 0;
+  for (int first = 0; first < group; first += kBlock) {
+    const int in_block = group - first < kBlock ? group - first : kBlock;
+    n += (in_block + kStreamsPerBlock - 1) / kStreamsPerBlock;
+  }
+  return n;
+}
 
 // Per stream: what the background quad (src/urdf_filter.cpp:589-597) amounts to, computed once per batch
 // by pose_kernel so that the tile kernel's workgroups do no per-stream arithmetic of their own.
@@ -210,7 +223,7 @@ struct SetupArgs {
   uint32_t capacity;
   uint32_t clip_capacity;        // per shard segment
   uint32_t bg_chunk;             // index of the background-quad chunk
-  uint32_t flags;                // rtuf_params.flags (bits 16.. are timing experiments of the set-up kernel)
+  uint32_t flags;                // rtuf_params.flags
 };
 
 struct TileArgs {

@@ -264,6 +264,17 @@ __device__ __forceinline__ void tf_store_gl(const Tf12& t, double* g)
   g[12] = t.o[0]; g[13] = t.o[1]; g[14] = t.o[2]; g[15] = 1.0;
 }
 
+// src/urdf_filter.cpp:607-611: the camera origin moves by camera_tx_ along the camera transform's x axis
+// ("right" = rotation * (1,0,0)), then by camera_ty_ along its y axis ("down")
+__device__ __forceinline__ void apply_camera_shift(Tf12& t, const double* shift)
+{
+  const double tx = shift[0], ty = shift[1];
+#pragma unroll
+  for (int i = 0; i < 3; i++) t.o[i] = __dadd_rn(t.o[i], __dmul_rn(t.m[3 * i], tx));
+#pragma unroll
+  for (int i = 0; i < 3; i++) t.o[i] = __dadd_rn(t.o[i], __dmul_rn(t.m[3 * i + 1], ty));
+}
+
 __device__ Tf12 fk_frame(const FkArgs& a, int s, int frame)
 {
   int chain[64];
@@ -312,6 +323,7 @@ __global__ void fk_kernel(FkArgs a)
     Tf12 inv;
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) inv.m[3 * i + j] = t.m[3 * j + i];
     for (int i = 0; i < 3; i++) inv.o[i] = inv.m[3 * i] * (-t.o[0]) + inv.m[3 * i + 1] * (-t.o[1]) + inv.m[3 * i + 2] * (-t.o[2]);
+    apply_camera_shift(inv, a.cams[s].shift);
     tf_store_gl(inv, a.cams[s].cam_tf);
   }
 }
@@ -378,6 +390,7 @@ __global__ __launch_bounds__(kFkMaxFrames) void fk_tree_kernel(FkArgs a)
     Tf12 inv;
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) inv.m[3 * i + j] = t.m[3 * j + i];
     for (int i = 0; i < 3; i++) inv.o[i] = inv.m[3 * i] * (-t.o[0]) + inv.m[3 * i + 1] * (-t.o[1]) + inv.m[3 * i + 2] * (-t.o[2]);
+    apply_camera_shift(inv, a.cams[s].shift);
     tf_store_gl(inv, a.cams[s].cam_tf);
   }
 }
@@ -1026,7 +1039,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
     }
   }
   __syncthreads();
-  if (a.flags & 0x10000u) { __syncthreads(); if (!STRIDED) break; continue; }     // timing experiment
+  if (RTUF_ABL(a.flags, 0x10000u)) { __syncthreads(); if (!STRIDED) break; continue; }     // timing experiment
   // phase 3a/3b: tiny (2x2) and small (4x4, single tile) survivors -> coverage of their box positions
   // -> 8-byte fragments; the z plane (one division) is only evaluated for triangles that actually
   // cover a pixel centre
@@ -1072,7 +1085,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
         s_list[atomicAdd(&s_nlist, 1u)] = (uint16_t)ent;
         mask = 0;
       }
-      if (__ballot(mask != 0) && !(a.flags & 0x40000u)) {
+      if (__ballot(mask != 0) && !RTUF_ABL(a.flags, 0x40000u)) {
         nfrag += cls == 0 ? emit_fragments_wave<true>(a, slot, mask, bx0, by0, a0, dzdx, dzdy, order)
                           : emit_fragments_wave<false>(a, slot, mask, bx0, by0, a0, dzdx, dzdy, order);
         binned += mask ? 1u : 0u;
@@ -1110,7 +1123,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
         bby = (uint32_t)by0 | ((uint32_t)by1 << 16);
       }
     }
-    if (__ballot(have) && !(a.flags & 0x20000u)) {
+    if (__ballot(have) && !RTUF_ABL(a.flags, 0x20000u)) {
       entries += emit_record_wave(a, slot, have, bbx, bby, pk);
       binned += have ? 1u : 0u;
     }
@@ -1186,7 +1199,7 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
   }
   unsigned long long inl = 0ull | (1ull << 5) | (2ull << 10), outl = 0;
   int nv = valid ? 3 : 0;
-  if (a.flags & 0x200000u) nv = 0;      // timing experiment: loads and vertex transform only
+  if (RTUF_ABL(a.flags, 0x200000u)) nv = 0;      // timing experiment: loads and vertex transform only
   unsigned clipmask = ormask;
   bool bad = false;
   while (clipmask && nv >= 3 && !bad) {
@@ -1236,7 +1249,7 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
     nv = outc;
   }
   if (bad || nv < 3) nv = 0;           // (all lanes stay for the cooperative emission below)
-  if (a.flags & 0x100000u) nv = 0;      // timing experiment: clip only, emit nothing
+  if (RTUF_ABL(a.flags, 0x100000u)) nv = 0;      // timing experiment: clip only, emit nothing
   // window coordinates: shaded (original) vertices and clipper-made ones go through different
   // viewport arithmetic (viewport_vs / viewport_clip)
   auto window_of = [&](int idx) {
@@ -1261,7 +1274,7 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
       wprev = wi;
     }
     binned += have ? 1u : 0u;
-    if (__ballot(have) && !(a.flags & 0x800000u)) entries += emit_record_wave(a, slot, have, r.bbx, r.bby, pk);      // (0x800000: timing experiment)
+    if (__ballot(have) && !RTUF_ABL(a.flags, 0x800000u)) entries += emit_record_wave(a, slot, have, r.bbx, r.bby, pk);      // (0x800000: timing experiment)
   }
   // statistics: one atomic pair per wave (per-lane atomics on a shard's counters serialise at one L2
   // atomic unit -- that alone used to be three quarters of this kernel's time)
@@ -1722,9 +1735,9 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   const uint32_t n_front = min(count_front, a.capacity), n = n_front + min(count_back, a.capacity - n_front), nf = min(fcount, a.fcapacity);
   const PackedTri* recs = a.bins + (size_t)bin * a.capacity;
   const unsigned long long* frags = reinterpret_cast<const unsigned long long*>(a.fbins) + (size_t)bin * a.fcapacity;
-  // flags bits 8.. are timing experiments only (wrong results): 0x100 skip rasterisation, 0x200 skip pixel loops
-  const bool empty = (n == 0 && nf == 0) || (a.flags & 0x100u);   // no geometry in this tile: pure streaming compare
-  if (empty && (a.flags & 0x1000000u)) return;                     // timing experiment: raster tiles only
+  // (RTUF_ABLATE builds only: flags bits 8.. are timing experiments, e.g. 0x100 skip rasterisation, 0x200 skip pixel loops)
+  const bool empty = (n == 0 && nf == 0) || RTUF_ABL(a.flags, 0x100u);   // no geometry in this tile: pure streaming compare
+  if (empty && RTUF_ABL(a.flags, 0x1000000u)) return;               // timing experiment: raster tiles only
   if (!empty) {
     for (int i = tid; i < kTileW * kTileH; i += kTileThreads) keys[i] = bgkey;
     if (tid == 0) { s_huge[0] = 0; s_huge[1 + kHugeMax] = n <= (uint32_t)kParkBelow ? (uint32_t)kQuarterArea : (uint32_t)kWallArea; }
@@ -1737,8 +1750,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       if (count) atomicMax(&sh.max_bin_fill, count);
       if (fcount) atomicMax(&sh.max_fbin_fill, fcount);
     }
+#ifdef RTUF_ABLATE
     if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, (int)((a.flags >> 12) & 3u));
     if (!(a.flags & 0x400u)) raster_frags(keys, frags, nf, tid);
+#else
+    raster_bin<0>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge);
+    raster_frags(keys, frags, nf, tid);
+#endif
     __syncthreads();
     if (tid == 0) s_huge[0] = 0;             // the exact-z pass below builds its list again
 
@@ -1831,14 +1849,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   }
 }
 
+// (fused variants: held at 6 waves/SIMD = 80 VGPRs; left alone the compiler takes 84 = 5 waves/SIMD)
 template <bool TWO_KERNEL, bool U16>
-__global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs a) { tile_body<TWO_KERNEL, U16>(a); }
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6))) void tile_kernel(TileArgs a) { tile_body<TWO_KERNEL, U16>(a); }
 // two-kernel mode writes the z-surface instead of resolving the compare: one register over 64 VGPRs without
 // the hint, i.e. 7 instead of 8 waves/SIMD (+10 % kernel time)
 template <>
 __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(8))) void tile_kernel<true, false>(TileArgs a) { tile_body<true, false>(a); }
-template <>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(8))) void tile_kernel<true, true>(TileArgs a) { tile_body<true, true>(a); }
 
 // ---------------------------------------------------------------------------------------
 // compare_kernel (two-kernel mode): streaming, 13 B/pixel (4 sensor + 4 z + 4 masked + 1 mask)
@@ -1947,7 +1964,7 @@ uint32_t launch_setup(const SetupArgs& a, uint32_t items_hint, bool sweep, hipSt
   // chunk's geometry in L2.  If the list may be longer than the grid, either a small strided launch of
   // the same code sweeps the remainder (sweep = true), or the caller compares the returned grid size
   // with the list length it reads back and runs the batch again (a wrong guess costs time, never pixels).
-  const long long worst = (long long)a.n_chunks * ((a.group_size + kStreamsPerBlock - 1) / kStreamsPerBlock);
+  const long long worst = (long long)a.n_chunks * max_items_per_chunk(a.group_size);
   long long grid = worst;
   if (items_hint) grid = std::min<long long>(worst, (long long)items_hint + items_hint / 4 + 64);
   hipLaunchKernelGGL(setup_kernel<false>, dim3((unsigned)grid), dim3(kBlock), 0, st, a, 0u);

@@ -1,3 +1,5 @@
+# needs the timing-experiment build: run scripts/build_ablate.sh first (the product library rejects these flag bits)
+export RTUF_LIB=${RTUF_LIB:-realtime_urdf_filter_amd/lib/variants/librtuf_ablate.so}
 export TMPDIR=/tmp
 root=$PWD
 for f in ${FLAGS:-0 0x100000 0x200000}; do

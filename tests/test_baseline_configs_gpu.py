@@ -1,0 +1,216 @@
+"""GPU (-m gpu): the BASELINE.json configs at their REAL sizes -- the 250,388-triangle PR2-like model at batch = 1
+(config 2) and batch = 256 (config 3), the per-GPU shares of the two 8-GPU configs (config 4: 64 x 720p + walls,
+config 5: 8 distinct URDFs x 128 cameras = 1024 streams) -- through the C ABI, against the CPU oracle on sampled
+streams and through size-independent properties on every stream."""
+import numpy as np
+import pytest
+
+import realtime_urdf_filter_amd as R
+from realtime_urdf_filter_amd import configs as CF
+from realtime_urdf_filter_amd import workloads as WL
+from oracle import bindings as O
+
+pytestmark = pytest.mark.gpu
+
+
+def params(wl, two_kernel=False):
+    p = R.default_params()
+    p.filter_replace_value = wl.replace_value
+    p.depth_distance_threshold = wl.max_diff
+    if two_kernel:
+        p.flags |= R.FLAG_TWO_KERNEL
+    return p
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a, np.float32).view(np.uint32), np.ascontiguousarray(b, np.float32).view(np.uint32))
+
+
+def check_properties(depth, masked, mask, replace_value):
+    """Size-independent properties of a filtered batch (every stream, every pixel)."""
+    # the output is a pure select between the sensor value and the replace value (the background quad covers the frame)
+    assert bits_equal(np.where(mask > 0, np.float32(replace_value), depth), masked)
+    assert set(np.unique(mask)) <= {0, 255}
+    # NaN and zero sensor pixels are never filtered (quirk Q9); +inf always is (quirk Q2)
+    assert (mask[np.isnan(depth)] == 0).all() and (mask[depth == 0] == 0).all() and (mask[np.isposinf(depth)] == 255).all()
+
+
+def check_against_oracle(share, k, streams, depth, masked, mask, link_dev=None, cam_dev=None):
+    wl0 = share.wl0
+    for s in streams:
+        proj, draws, off, cam = share.oracle_frame(k, s, link_dev, cam_dev)
+        om, ok = O.filter_frame(depth[s], proj, draws, off, cam, max_diff=wl0.max_diff, replace_value=wl0.replace_value)
+        assert (ok != mask[s]).sum() == 0, "stream %d: %d mask pixels differ" % (s, int((ok != mask[s]).sum()))
+        assert bits_equal(om, masked[s]), "stream %d: masked depth differs" % s
+
+
+@pytest.mark.parametrize("two_kernel", [False, True])
+def test_config2_pr2_250k_triangles_batch_1(two_kernel):
+    """BASELINE config 2: 640x480 stream, full PR2-like URDF (250 k triangles), batch = 1 -- every pixel of several
+    consecutive frames (new joint state and sensor frame each) against the oracle, through the single-stream
+    rtuf_filter() shape and through a batch of one."""
+    frames = 4
+    wl = WL.pr2_workload(frames, 640, 480, total_triangles=250000, first_state_seed=4242)
+    assert wl.n_triangles() > 240000
+    ctx = R.Context(640, 480, 1, 0, params(wl, two_kernel))
+    ids = wl.load_into(ctx)
+    assert ctx.num_triangles() == wl.n_triangles()
+    for f in range(frames):
+        wl.stage(ctx, ids, first=f, n=1)
+        depth = wl.depth(100 + f)
+        if f % 2 == 0:
+            masked, mask = ctx.filter_batch(depth[None])
+            masked, mask = masked[0], mask[0]
+        else:
+            masked, mask = ctx.filter(depth, wl.projection[f])
+        om, ok = O.filter_frame(depth, wl.projection[f], wl.oracle_draws(f), wl.offset_inv[f], wl.cam_tf[f],
+                                max_diff=wl.max_diff, replace_value=wl.replace_value)
+        assert (ok != mask).sum() == 0 and bits_equal(om, masked), "frame %d" % f
+        assert 0.02 < (mask > 0).mean() < 0.98          # the robot really is in view
+    st = ctx.stats()
+    assert st["triangles_submitted"] == wl.n_triangles() and st["triangles_binned"] > 1000
+    ctx.close()
+
+
+def test_config3_pr2_250k_triangles_256_streams():
+    """BASELINE config 3 (the headline workload, exactly what bench.py runs): 256 VGA streams of the 250 k-triangle
+    robot, joint positions through on-device forward kinematics, device-resident planes.  Properties on all 256
+    streams, 10 streams against the oracle (fed the matrices the GPU's forward kinematics produced), determinism
+    and stream-permutation equivariance with host-staged poses."""
+    import torch
+    share = CF.build("c3", 1, 0)
+    n, W, H = share.n, share.width, share.height
+    assert n == 256 and share.wl0.n_triangles() > 240000
+    ctx = R.Context(W, H, n, 0, params(share.wl0))
+    share.load(ctx)
+    dev = torch.device("cuda:0")
+    depth = share.depth_host(1)
+    d_depth = torch.from_numpy(depth).to(dev)
+    d_masked = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+    d_mask = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+    for k in (0, 1):          # two steps: the second one re-stages joint positions only, like the bench loop
+        share.stage(ctx, k)
+        ctx.filter_batch_device(n, d_depth.data_ptr(), d_masked.data_ptr(), d_mask.data_ptr())
+        ctx.sync()
+    masked, mask = d_masked.cpu().numpy(), d_mask.cpu().numpy()
+    check_properties(depth, masked, mask, share.wl0.replace_value)
+    link_dev, cam_dev = ctx.read_poses(n, share.n_links_total)
+    assert share.host_fk_error(1, link_dev, cam_dev) < 1e-12
+    check_against_oracle(share, 1, [0, 1, 31, 64, 100, 127, 128, 200, 254, 255], depth, masked, mask, link_dev, cam_dev)
+    # a second run is identical
+    ctx.filter_batch_device(n, d_depth.data_ptr(), d_masked.data_ptr(), d_mask.data_ptr())
+    ctx.sync()
+    assert bits_equal(d_masked.cpu().numpy(), masked) and np.array_equal(d_mask.cpu().numpy(), mask)
+    st = ctx.stats()
+    assert st["triangles_submitted"] == share.wl0.n_triangles() * n
+    ctx.close()
+    # reversing the stream order reverses the outputs (host-staged matrices: a context without forward kinematics)
+    wl = share.groups[0].variants[1]
+    ctx = R.Context(W, H, n, 0, params(wl))
+    ids = wl.load_into(ctx)
+    ctx.set_cameras(0, wl.projection[::-1], wl.offset_inv[::-1], wl.cam_tf[::-1])
+    ctx.set_link_poses_batch(0, ids[0], wl.link_tf[0][::-1])
+    d_rev = torch.from_numpy(np.ascontiguousarray(depth[::-1])).to(dev)
+    ctx.filter_batch_device(n, d_rev.data_ptr(), d_masked.data_ptr(), d_mask.data_ptr())
+    ctx.sync()
+    m3, k3 = d_masked.cpu().numpy()[::-1], d_mask.cpu().numpy()[::-1]
+    # (host FK and device FK agree to ~1e-15, not bit for bit: compare the reversed run with the oracle instead)
+    check_properties(depth, m3, k3, wl.replace_value)
+    for s in (0, 77, 255):
+        om, ok = O.filter_frame(depth[s], wl.projection[s], wl.oracle_draws(s), wl.offset_inv[s], wl.cam_tf[s],
+                                max_diff=wl.max_diff, replace_value=wl.replace_value)
+        assert (ok != k3[s]).sum() == 0 and bits_equal(om, m3[s])
+    ctx.close()
+
+
+def test_config4_per_gpu_share_64_streams_720p_with_walls():
+    """BASELINE config 4 at its per-GPU share: rank 0 of 8 = 64 of the 512 streams, 1280x720, 250 k-triangle robot +
+    the two wall URDFs (screen-filling boxes incl. quirk Q1)."""
+    import torch
+    share = CF.build("c4", 8, 0)
+    n, W, H = share.n, share.width, share.height
+    assert (n, W, H) == (64, 1280, 720) and share.total_streams == 512 and share.wl0.n_triangles() > 240000
+    ctx = R.Context(W, H, n, 0, params(share.wl0))
+    share.load(ctx)
+    dev = torch.device("cuda:0")
+    depth = share.depth_host(0)
+    d_depth = torch.from_numpy(depth).to(dev)
+    d_masked = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+    d_mask = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+    for k in (1, 2):
+        share.stage(ctx, k)
+        ctx.filter_batch_device(n, d_depth.data_ptr(), d_masked.data_ptr(), d_mask.data_ptr())
+        ctx.sync()
+    masked, mask = d_masked.cpu().numpy(), d_mask.cpu().numpy()
+    check_properties(depth, masked, mask, share.wl0.replace_value)
+    link_dev, cam_dev = ctx.read_poses(n, share.n_links_total)
+    check_against_oracle(share, 2, [0, 21, 42, 63], depth, masked, mask, link_dev, cam_dev)
+    assert (mask > 0).mean() > 0.1           # the walls fill a good part of the view
+    ctx.close()
+
+
+def test_config5_per_gpu_share_8_urdfs_x_128_streams():
+    """BASELINE config 5 at its per-GPU share: rank 0 of 8 holds URDFs 0, 8, ..., 56 -> 8 distinct robots (30 k to 250 k
+    triangles) x 128 cameras = 1024 streams in one context and ONE launch group; every stream renders only its own
+    robot; forward kinematics of all 8 trees on the GPU.  Two streams per robot against the oracle."""
+    import torch
+    share = CF.build("c5", 8, 0)
+    n, W, H = share.n, share.width, share.height
+    assert n == 1024 and len(share.groups) == 8 and [g.robot_index for g in share.groups] == list(range(0, 64, 8))
+    ctx = R.Context(W, H, n, 0, params(share.wl0))
+    share.load(ctx)
+    dev = torch.device("cuda:0")
+    depth = share.depth_host(0)
+    d_depth = torch.from_numpy(depth).to(dev)
+    d_masked = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+    d_mask = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+    share.stage(ctx, 0)
+    ctx.filter_batch_device(n, d_depth.data_ptr(), d_masked.data_ptr(), d_mask.data_ptr())
+    ctx.sync()
+    masked, mask = d_masked.cpu().numpy(), d_mask.cpu().numpy()
+    check_properties(depth, masked, mask, share.wl0.replace_value)
+    link_dev, cam_dev = ctx.read_poses(n, share.n_links_total)
+    streams = [g.first + j for g in share.groups for j in (3, 127)]
+    check_against_oracle(share, 0, streams, depth, masked, mask, link_dev, cam_dev)
+    ctx.close()
+
+
+def test_launch_group_of_1024_streams_that_all_see_the_whole_model():
+    """More than 256 streams per launch group with (nearly) every chunk visible in every stream: cull_kernel emits
+    ceil(visible / 3) work items per block of 256 stream slots, i.e. more than ceil(group / 3) per chunk -- the items
+    array and the set-up kernel's worst-case grid must be sized for that (out-of-bounds writes otherwise)."""
+    import torch
+    n, W, H = 600, 160, 120
+    rng = np.random.default_rng(5)
+    # a multi-chunk mesh ball in front of the camera: every chunk inside every stream's frustum
+    wl = WL.pr2_workload(2, W, H, total_triangles=3000)
+    nv, nt = 4000, 6000
+    v = (rng.normal(size=(nv, 3)) * 0.15).astype(np.float32)
+    t = rng.integers(0, nv, size=(nt, 3)).astype(np.uint32)
+    ctx = R.Context(W, H, n, 0, params(wl))
+    m = ctx.add_model()
+    l = ctx.add_link(m)
+    ctx.add_draw(m, l, v, t)
+    ctx.finalize_models()
+    tfs = np.zeros((n, 1, 16))
+    for s in range(n):
+        T = np.eye(4)
+        T[:3, 3] = (0.02 * np.sin(s), 0.02 * np.cos(s), 2.0 + 0.001 * s)
+        tfs[s, 0] = T.T.reshape(16)
+    ctx.set_cameras(0, np.tile(wl.projection[0], (n, 1)), np.tile(wl.offset_inv[0], (n, 1)), np.tile(np.eye(4).reshape(16), (n, 1)))
+    ctx.set_link_poses_batch(0, m, tfs)
+    depth = np.stack([WL.synthetic.sensor_depth(W, H, s) for s in range(8)])
+    depth = np.ascontiguousarray(depth[np.arange(n) % 8])
+    dev = torch.device("cuda:0")
+    d_depth = torch.from_numpy(depth).to(dev)
+    d_masked = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+    d_mask = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+    for _ in range(2):           # the second batch sizes its set-up grid from the first one's list length
+        ctx.filter_batch_device(n, d_depth.data_ptr(), d_masked.data_ptr(), d_mask.data_ptr())
+        ctx.sync()
+    masked, mask = d_masked.cpu().numpy(), d_mask.cpu().numpy()
+    for s in (0, 255, 256, 257, 511, 512, 599):
+        om, ok = O.filter_frame(depth[s], wl.projection[0], [(tfs[s, 0], 0, (0, 0, 0), v, t)], wl.offset_inv[0], np.eye(4).reshape(16),
+                                max_diff=wl.max_diff, replace_value=wl.replace_value)
+        assert (ok != mask[s]).sum() == 0 and bits_equal(om, masked[s]), "stream %d" % s
+    ctx.close()

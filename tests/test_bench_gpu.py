@@ -28,23 +28,66 @@ def test_bench_line_contract():
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
-    assert d["value"] > 0 and abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert d["timed_steps"] % 3 == 0 and d["timed_steps"] * d["ms_per_step"] * 1e-3 >= 0.3       # --min-seconds default 0.5 (estimate-sized)
+    assert d["value"] > 0 and abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    # both big kernels are reported, the dominant one (longest launch, no exclusions) on top
+    names = {rf["kernel"]} | {e["kernel"] for e in rf["all_kernels"]}
+    assert names == {"tile_kernel<fused>", "setup_kernel+clip_kernel"}
+    assert all(rf["avg_launch_ms"] >= e["avg_launch_ms"] > 0 for e in rf["all_kernels"])
     assert d["parity"]["mask_mismatch_pixels"] == 0 and d["parity"]["depth_mismatch_pixels"] == 0 and d["parity"]["frames_checked"] >= 2
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "workload" in d["config"]
+    assert cb["all_cores"]["cores"] >= 1 and cb["all_cores"]["value"] > 0
+
+
+def _two_ranks(extra, port):
+    env = dict(os.environ, RTUF_BENCH_BACKEND="gloo", RTUF_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return last_json(r.stdout)
 
 
 def test_bench_two_ranks_rehearsal_over_gloo():
-    env = dict(os.environ, RTUF_BENCH_BACKEND="gloo", RTUF_BENCH_DEVICE="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL
-    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    """c3 (weak scaling): both ranks run the same per-GPU batch size on their own streams."""
+    d = _two_ranks(SMALL, 29533)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["streams_per_gpu"] == 8 and d["config"]["streams_total"] == 16
+    assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    pr = d["parity"]["per_rank"]
+    assert [x["rank"] for x in pr] == [0, 1] and all(x["frames_checked"] == 2 and x["mismatching_values"] == 0 for x in pr)
+    assert all(x["frames"] == 8 * d["timed_steps"] for x in pr)
+
+
+def test_bench_two_ranks_rehearsal_config4_and_config5():
+    """The two 8-GPU configs of BASELINE.json run multi-rank through bench.py: c4 block-partitions a fixed total of
+    streams (sharding.shard_range), c5 puts URDF m on rank m % N (sharding.models_for_rank); rank 0 sums the frames,
+    MAX-reduces the time and gathers every rank's parity counts."""
+    base = ["--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--check-frames", "2", "--min-seconds", "0"]
+    d = _two_ranks(base + ["--workload", "c4", "--streams", "7", "--triangles", "8000", "--width", "320", "--height", "192"], 29534)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["streams_per_gpu"] == [4, 3] and d["config"]["streams_total"] == 7
+    assert d["config"]["workload"].startswith("C4") and "wall" in d["config"]["workload"]
+    assert d["timed_steps"] == 3 and abs(d["value"] - 7 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert all(x["mismatching_values"] == 0 and x["frames_checked"] == 2 for x in d["parity"]["per_rank"])
+    d = _two_ranks(base + ["--workload", "c5", "--urdfs", "5", "--streams", "3", "--triangles", "6000", "--width", "320", "--height", "240"], 29535)
+    assert d["scaling"] == "strong" and d["config"]["streams_per_gpu"] == [9, 6] and d["config"]["streams_total"] == 15      # URDFs 0,2,4 | 1,3
+    assert d["config"]["workload"].startswith("C5")
+    assert all(x["mismatching_values"] == 0 and x["frames_checked"] == 2 for x in d["parity"]["per_rank"])
+
+
+def test_bench_min_seconds_floor_and_per_gpu_share_flag():
+    """--min-seconds repeats the --steps steps (whole multiples); --shard-of runs rank 0's share of a larger job."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--check-frames", "1",
+                        "--min-seconds", "0.2", "--workload", "c4", "--shard-of", "8", "--streams", "16", "--triangles", "8000", "--width", "320", "--height", "192"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["streams_per_gpu"] == 8
-    assert abs(d["value"] - 2 * 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert d["steps"] == 2 and d["timed_steps"] % 2 == 0 and d["timed_steps"] >= 2
+    assert d["timed_steps"] * d["ms_per_step"] * 1e-3 >= 0.15          # the floor held (within the estimate's error)
+    assert d["config"]["streams_total"] == 2 and "8-GPU job" in d["config"]["parallelism"]
+    assert d["parity"]["mismatching_values"] == 0 and "cpu_baseline" not in d
 
 
 def test_fuzz_parity_sample():
