@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--host-poses", action="store_true", help="stage explicit link matrices from the host instead of joint positions + on-device forward kinematics")
     ap.add_argument("--u16", action="store_true", help="16UC1 depth in/out (uint16 millimetres) with the conversions fused into the kernels")
     ap.add_argument("--no-mask", action="store_true", help="need_mask_ == false: no mask output")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget per leg (single thread, all cores); 0 disables")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per leg (single thread, all cores); 0 disables")
     ap.add_argument("--debug-flags", type=lambda x: int(x, 0), default=0, help="timing experiments only (needs the RTUF_ABLATE build; results are wrong)")
     ap.add_argument("--check-frames", type=int, default=4, help="frames of the last step verified against the oracle (per rank)")
     args = ap.parse_args()
@@ -376,39 +376,32 @@ def main():
         # ---- CPU baseline: the oracle port on this box's host cores, on a bounded sample of the same batch ----
         if world == 1 and args.cpu_seconds > 0 and n > 0:
             cores = len(os.sched_getaffinity(0))
-            # one prepared oracle call per worker thread and then some (inputs: the first streams of the last batch,
-            # cycled); a thread only ever runs its own prepared frames, so output planes are never shared
+            # inputs: the first streams of the last batch (exactly what the GPU just filtered), prepared once
             n_in = min(n, 64)
             inputs = []
             for s in range(n_in):
                 hd, _, _ = fetch(s)
                 inputs.append((hd,) + tuple(share.oracle_frame(k_last, s, link_dev, cam_dev)))
-            prepared = [O.PreparedFrame(*inputs[i % n_in], max_diff=wl0.max_diff, replace_value=wl0.replace_value) for i in range(max(cores, n_in))]
-
-            def worker(t, n_threads, seconds):
-                mine = prepared[t::n_threads]
-                c0 = time.perf_counter()
-                done = 0
-                while time.perf_counter() - c0 < seconds:
-                    mine[done % len(mine)].run()
-                    done += 1
-                return done, time.perf_counter() - c0
-
-            n1, t1 = worker(0, 1, args.cpu_seconds)
-            from concurrent.futures import ThreadPoolExecutor
-            # the oracle is a C function behind ctypes (the GIL is released for the call): threads give real cores
+            prepared = [O.PreparedFrame(*inputs[i % n_in], max_diff=wl0.max_diff, replace_value=wl0.replace_value) for i in range(n_in)]
             c0 = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=cores) as ex:
-                res = list(ex.map(lambda t: worker(t, cores, args.cpu_seconds), range(cores)))
+            n1 = 0
+            while time.perf_counter() - c0 < args.cpu_seconds:
+                prepared[n1 % n_in].run()
+                n1 += 1
+            t1 = time.perf_counter() - c0
+            # all cores: POSIX threads inside the oracle library (a shared counter hands out frames; no Python in the
+            # loop), sized from the single-thread rate for about --cpu-seconds of wall time if the cores scaled perfectly
+            repeat = max(1, int(np.ceil(n1 / t1 * args.cpu_seconds * cores / n_in)))
+            c0 = time.perf_counter()
+            nN = O.filter_throughput(prepared, repeat, cores)
             tN = time.perf_counter() - c0
-            nN = sum(r[0] for r in res)
             cb = {"value": n1 / t1, "unit": "frames/s", "cores": 1, "kind": "port",
                   "sample": "%d frames of the last batch (first %d streams, cycled) through oracle/rtuf_oracle.c, single thread, %.1f s" % (n1, n_in, t1),
                   "all_cores": {"value": nN / tN, "unit": "frames/s", "cores": cores,
-                                "sample": "%d frames of the same set on %d threads (one oracle call per frame, GIL released for the call), %.1f s" % (nN, cores, tN)}}
+                                "sample": "%d frames of the same set on %d POSIX threads inside the oracle library, %.1f s" % (nN, cores, tN)}}
             try:
                 lp = json.load(open(os.path.join(ROOT, "profiles", "llvmpipe_baseline.json")))
-                cb["reference_llvmpipe"] = dict(lp.get("bench_workload", {}), source="OFFLINE: profiles/llvmpipe_baseline.json -- the reference's own GLSL on Mesa llvmpipe, timed in the development container (scripts/llvmpipe_baseline.py); /root/reference and swrast_dri.so do not exist on the GPU box")
+                cb["reference_llvmpipe"] = dict(lp.get("bench_workload", {}), source="OFFLINE: profiles/llvmpipe_baseline.json -- the reference's own GLSL on Mesa llvmpipe, timed in the development container (scripts/llvmpipe_baseline.py): the harness reads the reference's shaders from /root/reference at run time, which does not exist on the GPU box")
             except Exception:
                 pass
             out["cpu_baseline"] = cb

@@ -51,6 +51,8 @@ def lib():
             build()
         _lib = ctypes.CDLL(_SO)
         _lib.rtuf_oracle_filter.argtypes = [ctypes.POINTER(Frame), ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Debug)]
+        _lib.rtuf_oracle_filter_throughput.argtypes = [ctypes.POINTER(Frame), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        _lib.rtuf_oracle_filter_throughput.restype = ctypes.c_long
         _lib.rtuf_oracle_compose_mvp.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     return _lib
 
@@ -112,6 +114,16 @@ class PreparedFrame:
         if rc != 0:
             raise RuntimeError("oracle failed: %d" % rc)
         return self.masked, self.mask
+
+
+def filter_throughput(prepared, repeat, n_threads):
+    """Runs the prepared frames `repeat` times on n_threads POSIX threads inside the C library (no Python in the
+    loop); returns the number of frames filtered.  bench.py's cpu_baseline.all_cores leg."""
+    arr = (Frame * len(prepared))(*[p.fr for p in prepared])
+    n = lib().rtuf_oracle_filter_throughput(arr, len(prepared), int(repeat), int(n_threads))
+    if n < 0:
+        raise RuntimeError("oracle throughput run failed: %d" % n)
+    return int(n)
 
 
 def filter_frame(depth, projection, draws, camera_offset_inv=None, camera_tf=None, z_near=0.1, z_far=8.0,

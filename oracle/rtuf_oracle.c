@@ -495,3 +495,62 @@ void rtuf_oracle_compose_mvp(const double *projection, const double *camera_offs
   else if (pre_op == RTUF_ORACLE_OP_TRANSLATE) mat_translate(mv, op[0], op[1], op[2]);
   matmul4(out_mvp, proj, mv);
 }
+
+/* ------------------------------------------------------------------ */
+/* all-cores throughput (bench.py cpu_baseline.all_cores)             */
+/* ------------------------------------------------------------------ */
+#include <pthread.h>
+#include <stdatomic.h>
+
+typedef struct {
+  const rtuf_oracle_frame *frames;
+  int n_frames;
+  long total;
+  atomic_long *next;
+  atomic_long *done;
+  atomic_int *failed;
+} tp_job;
+
+static void *tp_worker(void *arg)
+{
+  tp_job *j = (tp_job *)arg;
+  float *masked = NULL;
+  uint8_t *mask = NULL;
+  size_t cap = 0;
+  for (;;) {
+    const long i = atomic_fetch_add(j->next, 1);
+    if (i >= j->total) break;
+    const rtuf_oracle_frame *fr = &j->frames[i % j->n_frames];
+    const size_t px = (size_t)fr->width * (size_t)fr->height;
+    if (px > cap) {
+      free(masked); free(mask);
+      masked = (float *)malloc(px * sizeof(float));
+      mask = (uint8_t *)malloc(px);
+      cap = px;
+      if (!masked || !mask) { atomic_store(j->failed, 1); break; }
+    }
+    if (rtuf_oracle_filter(fr, masked, mask, NULL) != 0) { atomic_store(j->failed, 1); break; }
+    atomic_fetch_add(j->done, 1);
+  }
+  free(masked); free(mask);
+  return NULL;
+}
+
+long rtuf_oracle_filter_throughput(const rtuf_oracle_frame *frames, int n_frames, int repeat, int n_threads)
+{
+  if (!frames || n_frames <= 0 || repeat <= 0 || n_threads <= 0) return -1;
+  atomic_long next = 0, done = 0;
+  atomic_int failed = 0;
+  tp_job job = { frames, n_frames, (long)n_frames * repeat, &next, &done, &failed };
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+  if (!th) return -2;
+  int started = 0;
+  for (int t = 0; t < n_threads; t++) {
+    if (pthread_create(&th[t], NULL, tp_worker, &job) != 0) break;
+    started++;
+  }
+  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+  free(th);
+  if (started == 0 || atomic_load(&failed)) return -3;
+  return atomic_load(&done);
+}

@@ -1,65 +1,88 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): regenerates everything under profiles/ for the current build.
-#   bash scripts/refresh_profiles.sh <tag>       e.g. r01  -> gpurun_out/profiles/<tag>_*
-# rocprofv3 passes are separate: --kernel-trace --stats, then --pmc FETCH_SIZE, then --pmc WRITE_SIZE.
-tag=${1:-r01}
+# Run on the GPU box (gpurun): regenerates everything under profiles/ for the current build in one go.
+#   bash scripts/refresh_profiles.sh <tag>       e.g. r02  -> gpurun_out/profiles/<tag>_* (+ the three un-tagged json files
+#   bench.py reads: pmc_counters.json, valu_peak.json; llvmpipe_baseline.json comes from the development container)
+# rocprofv3 passes are separate runs: --kernel-trace --stats, then one --pmc pass per counter group (never together
+# with other trace domains).
+tag=${1:-r02}
 export TMPDIR=/tmp
 root=$PWD
 out=$root/gpurun_out/profiles
 rm -rf $out; mkdir -p $out
 B="python $root/bench.py"
-$B --cpu-seconds 20 > $out/${tag}_bench.json 2> $out/bench.err
+PROF_ARGS="--steps 20 --min-seconds 0 --cpu-seconds 0 --check-frames 0"
+
+# ---- 1. bench lines ---------------------------------------------------------------------------------------------
+$B > /dev/null 2> $out/bench.err                                   # first run on a fresh box is the slowest: warm-up
+$B --cpu-seconds 12 > $out/${tag}_bench.json 2>> $out/bench.err
 $B --cpu-seconds 0 --two-kernel > $out/${tag}_bench_two_kernel.json 2>> $out/bench.err
+$B --cpu-seconds 0 --two-kernel --streams 1024 --steps 30 > $out/${tag}_bench_two_kernel_1024.json 2>> $out/bench.err
+$B --cpu-seconds 0 --streams 1024 --steps 30 > $out/${tag}_bench_1024.json 2>> $out/bench.err
 $B --cpu-seconds 0 --u16 > $out/${tag}_bench_u16.json 2>> $out/bench.err
 $B --steps 200 --cpu-seconds 0 --streams 1 > $out/${tag}_bench_batch1.json 2>> $out/bench.err
 $B --cpu-seconds 0 --host-poses > $out/${tag}_bench_host_poses.json 2>> $out/bench.err
 $B --cpu-seconds 0 --pipelines 2 > $out/${tag}_bench_pipelines2.json 2>> $out/bench.err
-$B --cpu-seconds 0 --pipelines 3 > $out/${tag}_bench_pipelines3.json 2>> $out/bench.err
+$B --cpu-seconds 0 --workload c4 --shard-of 8 --steps 50 > $out/${tag}_bench_c4_share.json 2>> $out/bench.err
+$B --cpu-seconds 0 --workload c5 --shard-of 8 --steps 30 > $out/${tag}_bench_c5_share.json 2>> $out/bench.err
+
+# ---- 2. kernel traces -------------------------------------------------------------------------------------------
 cd /tmp
-for mode in "" "--two-kernel"; do
-  suffix=${mode:+_two_kernel}
-  rm -rf /tmp/rp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp -o t -- $B --steps 20 --cpu-seconds 0 --check-frames 0 $mode > /dev/null 2>&1
-  cp $(find /tmp/rp -name '*kernel_stats.csv' | head -1) $out/${tag}_kernel_stats${suffix}.csv
+trace() {   # name, bench args
+  rm -rf /tmp/rp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp -o t -- $B $PROF_ARGS $2 > /dev/null 2>&1
+  cp $(find /tmp/rp -name '*kernel_stats.csv' | head -1) $out/${tag}_kernel_stats$1.csv
+}
+trace "" ""
+trace "_two_kernel" "--two-kernel"
+trace "_two_kernel_1024" "--two-kernel --streams 1024"
+trace "_c4_share" "--workload c4 --shard-of 8"
+
+# ---- 3. counters (one pass per group) ---------------------------------------------------------------------------
+pmc() {     # output file, bench args, counters...
+  local f=$1 args=$2; shift 2
+  rm -rf /tmp/rp; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/rp -o t -- $B $PROF_ARGS $args > /dev/null 2>&1
+  { echo "## $*"; python $root/scripts/pmc_summary.py $(find /tmp/rp -name '*counter_collection.csv' | head -1); } >> $f
+}
+hdr="# rocprofv3 --kernel-trace --pmc <group> (one pass per '##' group), command: python bench.py $PROF_ARGS"
+for mode in "" "--two-kernel" "--two-kernel --streams 1024"; do
+  suffix=$(echo "$mode" | sed 's/--//g; s/ /_/g; s/-/_/g'); suffix=${suffix:+_$suffix}
+  f=$out/${tag}_pmc${suffix}.txt
+  echo "$hdr $mode   (values per launch, averaged over the launches of the run; FETCH_SIZE / WRITE_SIZE in KiB)" > $f
+  pmc $f "$mode" FETCH_SIZE
+  pmc $f "$mode" WRITE_SIZE
+  if [ -z "$mode" ]; then
+    pmc $f "$mode" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES
+    pmc $f "$mode" SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES
+    pmc $f "$mode" SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM
+    pmc $f "$mode" SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY
+  fi
 done
-{
-  echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), command: python bench.py --steps 20 --warmup 3 --cpu-seconds 0 --check-frames 0"
-  echo "# values are KiB per launch, averaged over the launches of the run (MI355X, gfx950, ROCm 7.2)"
-  for ctr in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/rp; rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/rp -o t -- $B --steps 20 --cpu-seconds 0 --check-frames 0 > /dev/null 2>&1
-    echo "## $ctr"
-    python $root/scripts/pmc_summary.py $(find /tmp/rp -name '*counter_collection.csv' | head -1)
-  done
-} > $out/${tag}_pmc_hbm_traffic.txt
+
+# ---- 4. VALU issue micro-benchmark + the counters' calibration on it ----------------------------------------------
+$root/scripts/bin/valu_peak 8 > $out/valu_peak_raw.json 2> $out/valu_peak.err
+rm -rf /tmp/rp; rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d /tmp/rp -o t -- $root/scripts/bin/valu_peak 8 > /dev/null 2>&1
+python - $(find /tmp/rp -name '*counter_collection.csv' | head -1) > $out/${tag}_pmc_valu_peak.txt <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("# rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -- scripts/bin/valu_peak 8   (last launch of each kernel)")
+for k, v in agg.items():
+    if not k.startswith("k_"):
+        continue
+    i, a = v["SQ_INSTS_VALU"][-1], v["SQ_ACTIVE_INST_VALU"][-1]
+    print("%-34s SQ_INSTS_VALU %.4g  SQ_ACTIVE_INST_VALU %.4g  ratio %.3f" % (k.split("(")[0], i, a, a / i if i else 0))
+PY
 cd $root
-python - "$out/${tag}_pmc_hbm_traffic.txt" "$out/hbm_traffic.json" "$tag" <<'PY'
-import json, re, sys
-txt = open(sys.argv[1]).read()
-def grab(section):
-    part = txt.split("## " + section)[1]
-    m = re.search(r"tile_kernel<false, false>[^\n]*\n\s+%s\s+avg ([0-9.e+]+)" % section, part)
-    return float(m.group(1))
-f, w = grab("FETCH_SIZE"), grab("WRITE_SIZE")
-json.dump({"kernel": "tile_kernel<fused>", "mode": "fused", "streams": 256, "width": 640, "height": 480, "triangles": 250388,
-           "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
-           "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section): fetch bytes = 2 x FETCH_SIZE x 1024; write bytes = WRITE_SIZE x 1024",
-           "hbm_bytes_per_launch": int(2 * f * 1024 + w * 1024),
-           "source": "profiles/%s_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, python bench.py --steps 20 --warmup 3)" % sys.argv[3]},
-          open(sys.argv[2], "w"), indent=1)
+python scripts/pmc_to_json.py $out $tag > $out/pmc_to_json.log 2>&1
+(timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5) > $out/${tag}_gpu_tests.txt
+ls -la $out; cat $out/pmc_to_json.log; tail -c 400 $out/bench.err
+for f in $out/${tag}_bench*.json; do python - $f <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r = d["roofline"]
+    print("%-44s %9.0f frames/s  %.4f ms/step  %s %.1f us frac %.3f  parity %s" % (sys.argv[1].split("/")[-1], d["value"], d["ms_per_step"], r["kernel"], r["avg_launch_ms"] * 1e3, r["frac"], d["parity"]["mismatching_values"]))
+except Exception as e:
+    print(sys.argv[1], "unreadable:", e)
 PY
-bash scripts/pmc_kernels.sh SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES > $out/pmc_sq.body 2>&1
-{ echo "# rocprofv3 --kernel-trace --pmc <4 SQ counters per pass>, command: python bench.py --steps 10 --warmup 2 --cpu-seconds 0 --check-frames 0 (scripts/pmc_kernels.sh)"
-  echo "# values are per launch, averaged over the launches of the run (MI355X, gfx950, ROCm 7.2); SQ_INSTS_* count wave64 instructions"
-  cat $out/pmc_sq.body; } > $out/${tag}_pmc_sq.txt; rm -f $out/pmc_sq.body
-python - "$out/${tag}_pmc_sq.txt" "$out/valu_counts.json" "$tag" <<'PY'
-import json, re, sys
-txt = open(sys.argv[1]).read()
-def grab(kernel):
-    m = re.search(re.escape(kernel) + r"[^\n]*\n(?:\s+SQ_\w+\s+avg [0-9.e+]+[^\n]*\n)*?\s+SQ_INSTS_VALU\s+avg ([0-9.e+]+)", txt)
-    return float(m.group(1)) if m else None
-json.dump({"streams": 256, "width": 640, "height": 480, "triangles": 250388,
-           "wave64_valu_instructions_per_launch": {"tile_kernel<fused>": grab("tile_kernel<false, false>"), "setup_kernel": grab("setup_kernel<false>")},
-           "peak_G_per_s": 614.4, "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
-           "source": "profiles/%s_pmc_sq.txt (rocprofv3 --pmc SQ_INSTS_VALU ..., python bench.py --steps 10 --warmup 2)" % sys.argv[3]},
-          open(sys.argv[2], "w"), indent=1)
-PY
-ls -la $out; tail -c 600 $out/${tag}_bench.json; cat $out/${tag}_kernel_stats.csv | head -12; cat $out/hbm_traffic.json
+done

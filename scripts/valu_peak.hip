@@ -74,6 +74,25 @@ KERNEL(cmp_gt_i32_plus_cndmask, int, "v_cmp_gt_i32 vcc, %1, %0\n\tv_cndmask_b32 
 KERNEL(cmp_lt_f32_plus_cndmask, float, "v_cmp_lt_f32 vcc, %1, %0\n\tv_cndmask_b32 %0, %0, %2, vcc")   // 2 instructions
 KERNEL(fma_f32_then_mul_i24, int, "v_fma_f32 %0, %1, %2, %0\n\tv_mul_i32_i24 %0, %1, %0")               // 2 instructions: float / integer alternating
 KERNEL(add_then_min_then_mul24, int, "v_add_u32 %0, %1, %0\n\tv_min_i32 %0, %2, %0\n\tv_mul_i32_i24 %0, %1, %0")     // 3 instructions: integer mix
+KERNEL(v_lshrrev_b32, unsigned, "v_lshrrev_b32 %0, 1, %0")
+KERNEL(v_xor_b32, unsigned, "v_xor_b32 %0, %1, %0")
+KERNEL(v_bcnt_u32_b32, unsigned, "v_bcnt_u32_b32 %0, %1, %0")
+KERNEL(v_mbcnt_lo_u32_b32, unsigned, "v_mbcnt_lo_u32_b32 %0, %1, %0")
+KERNEL(v_mad_u32_u24, unsigned, "v_mad_u32_u24 %0, %1, %2, %0")
+KERNEL(v_fmac_f32, float, "v_fmac_f32 %0, %1, %2")
+KERNEL(v_mul_hi_i32_i24, int, "v_mul_hi_i32_i24 %0, %1, %0")
+KERNEL(v_bfe_i32, int, "v_bfe_i32 %0, %0, 3, 20")
+KERNEL(v_alignbit_b32, unsigned, "v_alignbit_b32 %0, %0, %1, 8")
+KERNEL(v_add_lshl_u32, unsigned, "v_add_lshl_u32 %0, %0, %1, 1")
+KERNEL(v_med3_i32, int, "v_med3_i32 %0, %1, %2, %0")
+KERNEL(v_lshl_add_u64, unsigned long long, "v_lshl_add_u64 %0, %0, 1, %1")
+KERNEL(v_cmp_lt_i32_to_vcc, int, "v_cmp_lt_i32 vcc, %1, %0")          // result unused: measures the compare alone
+KERNEL(v_cmp_gt_f32_to_vcc, float, "v_cmp_gt_f32 vcc, %1, %0")
+KERNEL(v_cmp_lt_i32_to_sgpr_e64, int, "v_cmp_lt_i32 s[20:21], %1, %0")
+KERNEL(v_cndmask_b32_e64_sgpr_mask, unsigned, "v_cndmask_b32 %0, %0, %1, s[20:21]")
+KERNEL(v_readlane_b32, unsigned, "v_readlane_b32 s20, %0, 5")          // VALU -> SGPR broadcast (result unused)
+KERNEL(v_readfirstlane_b32, unsigned, "v_readfirstlane_b32 s20, %0")
+KERNEL(min_of_three_edges_then_cmp, int, "v_min3_i32 %0, %1, %2, %0\n\tv_cmp_lt_i32 vcc, 0, %0")      // 2 instructions: the lane walk's coverage test
 // 64-bit operands
 KERNEL(v_fma_f64, double, "v_fma_f64 %0, %1, %2, %0")
 KERNEL(v_mul_f64, double, "v_mul_f64 %0, %1, %0")
@@ -153,6 +172,11 @@ int main(int argc, char** argv)
   RUN(v_rcp_f32, float, 1, 0, 0); RUN(v_mov_b32, unsigned, 1, 7, 0); RUN(v_cndmask_b32, unsigned, 1, 7, 0);
   RUN(cmp_gt_i32_plus_cndmask, int, 2, 5, 9); RUN(cmp_lt_f32_plus_cndmask, float, 2, 5.0f, 9.0f);
   RUN(fma_f32_then_mul_i24, int, 2, 3, 5); RUN(add_then_min_then_mul24, int, 3, 3, 1 << 20);
+  RUN(v_lshrrev_b32, unsigned, 1, 0, 0); RUN(v_xor_b32, unsigned, 1, 5, 0); RUN(v_bcnt_u32_b32, unsigned, 1, 5, 0); RUN(v_mbcnt_lo_u32_b32, unsigned, 1, 5, 0);
+  RUN(v_mad_u32_u24, unsigned, 1, 3, 5); RUN(v_fmac_f32, float, 1, 1e-9f, 1.0f); RUN(v_mul_hi_i32_i24, int, 1, 3, 0); RUN(v_bfe_i32, int, 1, 0, 0);
+  RUN(v_alignbit_b32, unsigned, 1, 5, 0); RUN(v_add_lshl_u32, unsigned, 1, 5, 0); RUN(v_med3_i32, int, 1, 5, 9); RUN(v_lshl_add_u64, unsigned long long, 1, 5, 0);
+  RUN(v_cmp_lt_i32_to_vcc, int, 1, 5, 0); RUN(v_cmp_gt_f32_to_vcc, float, 1, 5, 0); RUN(v_cmp_lt_i32_to_sgpr_e64, int, 1, 5, 0); RUN(v_cndmask_b32_e64_sgpr_mask, unsigned, 1, 5, 0);
+  RUN(v_readlane_b32, unsigned, 1, 0, 0); RUN(v_readfirstlane_b32, unsigned, 1, 0, 0); RUN(min_of_three_edges_then_cmp, int, 2, 1 << 30, 1 << 29);
   RUN(v_fma_f64, double, 1, 1.0000001, 1e-9); RUN(v_mul_f64, double, 1, 1.0000001, 0); RUN(v_add_f64, double, 1, 1e-9, 0);
   RUN(v_pk_fma_f32, double, 1, 1.0, 1e-9); RUN(v_pk_mul_f32, double, 1, 1.0, 0); RUN(v_pk_add_f32, double, 1, 1e-9, 0);
   RUN(v_lshlrev_b64, unsigned long long, 1, 0, 0); RUN(v_mad_u64_u32, unsigned long long, 1, 3, 0);
