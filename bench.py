@@ -125,16 +125,11 @@ def main():
         p.flags |= R.FLAG_TWO_KERNEL
     p.flags |= args.debug_flags
     P = max(1, args.pipelines)
-    ctxs, shares = [], []
-    for i in range(P):
-        c = R.Context(W, H, n, local_rank, p)
-        sh = share if i == 0 else CF.build(args.workload, job_world, rank, streams=args.streams, triangles=args.triangles, variants=args.variants,
-                                           width=args.width, height=args.height, urdfs=args.urdfs)
-        sh.load(c, on_device_fk=not args.host_poses)
-        c.enable_timing(2)       # HIP events around the big kernels only (each event costs stream time)
-        ctxs.append(c)
-        shares.append(sh)
-    ctx = ctxs[0]
+    p.pipelines = P if P > 1 else 0          # rtuf_params.pipelines: the library alternates the batches between P internal pipelines
+    ctx = R.Context(W, H, n, local_rank, p)
+    share.load(ctx, on_device_fk=not args.host_poses)
+    ctx.enable_timing(2)         # HIP events around the big kernels only (each event costs stream time)
+    ctxs = [ctx]
     V = share.n_variants()
 
     d_depth = []
@@ -153,23 +148,22 @@ def main():
     ptrs = [(d_masked_set[i].data_ptr(), d_mask_set[i].data_ptr() if d_mask_set[i] is not None else 0) for i in range(n_sets)]
     dptr = [d.data_ptr() for d in d_depth]
 
-    def stage_into(ci, k):
-        shares[ci].stage(ctxs[ci], k)       # joint angles in (forward kinematics on the GPU), or host matrices with --host-poses
+    def stage_into(k):
+        share.stage(ctx, k)       # joint angles in (forward kinematics on the GPU), or host matrices with --host-poses
 
-    def submit(ci, k):
-        c = ctxs[ci]
-        (c.filter_batch_device_u16 if args.u16 else c.filter_batch_device)(n, dptr[k % V], ptrs[k % n_sets][0], ptrs[k % n_sets][1])
+    def submit(k):
+        (ctx.filter_batch_device_u16 if args.u16 else ctx.filter_batch_device)(n, dptr[k % V], ptrs[k % n_sets][0], ptrs[k % n_sets][1])
 
     def enqueue(k):
-        # one step = one batch through the hot path: enqueue it on pipeline k mod P, then stage the NEXT batch's
-        # joint positions (host memory only) while the GPU works.  Each context keeps up to two batches in
-        # flight and retires its oldest when a third arrives; nothing in the loop waits for the GPU otherwise.
-        submit(k % P, k)
-        stage_into((k + 1) % P, k + 1)
+        # one step = one batch through the hot path: enqueue it, then stage the NEXT batch's joint positions (host
+        # memory only) while the GPU works.  The context keeps up to two batches per pipeline in flight and retires
+        # the oldest when another arrives; nothing in the loop waits for the GPU otherwise.
+        submit(k)
+        stage_into(k + 1)
 
     def isolated_step(k):
-        stage_into(0, k)
-        submit(0, k)
+        stage_into(k)
+        submit(k)
         ctx.sync()
 
     def barrier():
@@ -179,14 +173,14 @@ def main():
     k0 = args.warmup * P
     t_w = time.perf_counter()
     for k in range(k0):            # every pipeline warms up (first batch: bin sizing) with one batch in flight
-        stage_into(k % P, k)
-        submit(k % P, k)
-        ctxs[k % P].sync()
+        stage_into(k)
+        submit(k)
+        ctx.sync()
     torch.cuda.synchronize()
     # how often the --steps steps are repeated so that the timed region is at least --min-seconds long: from the
     # time of a few pipelined steps after the warm-up (agreed between the ranks: the slowest decides)
     probe = max(2, min(args.steps, 8))
-    stage_into(k0 % P, k0)
+    stage_into(k0)
     t_p = time.perf_counter()
     for k in range(k0, k0 + probe):
         enqueue(k)
@@ -206,7 +200,7 @@ def main():
     barrier()
     for c in ctxs:
         c.enable_timing(3)       # (re)starts the library's event sums: set-up, tile (and compare) kernels of every fourth batch (an event costs ~5 us of stream time)
-    stage_into(k0 % P, k0)
+    stage_into(k0)
     t0 = time.perf_counter()
     for k in range(k0, k0 + timed_steps):
         enqueue(k)

@@ -34,6 +34,22 @@ int main(int argc, char** argv)
                 rd.renderables_.empty() ? "-" : rd.renderables_[0]->name.c_str());
     return 0;
   }
+  if (argc >= 3 && std::string(argv[1]) == "--fk") {
+    // CPU-only: forward kinematics of a URDF for joint positions given as name=value (mimic joints resolved)
+    const rtuf_host::UrdfModel model = rtuf_host::UrdfModel::from_string(slurp(argv[2]));
+    std::map<std::string, double> q;
+    for (int i = 3; i < argc; i++) {
+      const std::string a = argv[i];
+      const size_t eq = a.find('=');
+      if (eq != std::string::npos) q[a.substr(0, eq)] = std::atof(a.c_str() + eq + 1);
+    }
+    for (const auto& kv : rtuf_host::forward_kinematics(model, q)) {
+      std::printf("%s", kv.first.c_str());
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) std::printf(" %.17g", kv.second.m[r][c]);
+      std::printf(" %.17g %.17g %.17g\n", kv.second.o.x, kv.second.o.y, kv.second.o.z);
+    }
+    return 0;
+  }
   if (argc != 12) { std::fprintf(stderr, "usage: %s urdf depth.f32 W H fx fy cx cy replace out_masked out_mask\n", argv[0]); return 2; }
   const std::string xml = slurp(argv[1]);
   const int W = std::atoi(argv[3]), H = std::atoi(argv[4]);

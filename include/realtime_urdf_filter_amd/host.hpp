@@ -252,6 +252,9 @@ struct UrdfJoint {
   std::string name, type, parent, child;
   Vec3 xyz, rpy, axis{1, 0, 0};
   double lower = 0, upper = 0;
+  // <mimic joint multiplier offset>: position = multiplier * position(mimic_joint) + offset (urdfdom defaults 1, 0)
+  std::string mimic_joint;
+  double mimic_multiplier = 1, mimic_offset = 0;
 };
 
 inline Vec3 parse_vec3(const std::string& s, const Vec3& dflt)
@@ -300,6 +303,11 @@ struct UrdfModel {
         if (const XmlNode* o = le.child("origin")) { j.xyz = parse_vec3(o->get("xyz"), Vec3()); j.rpy = parse_vec3(o->get("rpy"), Vec3()); }
         if (const XmlNode* a = le.child("axis")) j.axis = parse_vec3(a->get("xyz"), Vec3{1, 0, 0});
         if (const XmlNode* l = le.child("limit")) { j.lower = std::stod(l->get("lower", "0")); j.upper = std::stod(l->get("upper", "0")); }
+        if (const XmlNode* mm = le.child("mimic")) {
+          j.mimic_joint = mm->get("joint");
+          j.mimic_multiplier = std::stod(mm->get("multiplier", "1"));
+          j.mimic_offset = std::stod(mm->get("offset", "0"));
+        }
         const XmlNode* p = le.child("parent");
         const XmlNode* c = le.child("child");
         if (!p || !c) throw std::runtime_error("URDF joint " + j.name + " lacks parent/child");
@@ -339,9 +347,36 @@ inline Transform joint_motion(const UrdfJoint& j, double q)
   return Transform();
 }
 
-// root <- link for every link (replaces the per-link TF lookups of update_link_transforms)
-inline std::map<std::string, Transform> forward_kinematics(const UrdfModel& m, const std::map<std::string, double>& q = {})
+// Joint positions with every <mimic> joint filled in from the joint it follows (chains followed, explicit positions
+// kept, a cycle throws): what joint_state_publisher does before robot_state_publisher makes the TF frames the reference
+// looks up (src/urdf_renderer.cpp:173-190).  The PR2's gripper fingers are mimic joints.
+inline std::map<std::string, double> resolve_mimic(const UrdfModel& m, std::map<std::string, double> q)
 {
+  for (const auto& kv : m.joints) {
+    if (kv.second.mimic_joint.empty() || q.count(kv.first)) continue;
+    // walk the chain up to a joint with a known position (or no mimic), then fill it back down
+    std::vector<const UrdfJoint*> chain;
+    const UrdfJoint* j = &kv.second;
+    while (j && !j->mimic_joint.empty() && !q.count(j->name)) {
+      if (chain.size() > m.joints.size()) throw std::runtime_error("URDF: mimic cycle through joint " + kv.first);
+      chain.push_back(j);
+      auto it = m.joints.find(j->mimic_joint);
+      j = it == m.joints.end() ? nullptr : &it->second;
+    }
+    double v = 0.0;
+    if (j) { auto it = q.find(j->name); v = it == q.end() ? 0.0 : it->second; }
+    for (size_t i = chain.size(); i-- > 0;) {
+      v = chain[i]->mimic_multiplier * v + chain[i]->mimic_offset;
+      q[chain[i]->name] = v;
+    }
+  }
+  return q;
+}
+
+// root <- link for every link (replaces the per-link TF lookups of update_link_transforms)
+inline std::map<std::string, Transform> forward_kinematics(const UrdfModel& m, const std::map<std::string, double>& q_in = {})
+{
+  const std::map<std::string, double> q = resolve_mimic(m, q_in);
   std::map<std::string, std::vector<const UrdfJoint*>> by_parent;
   for (const auto& j : m.joints) by_parent[j.second.parent].push_back(&j.second);
   std::map<std::string, Transform> out;

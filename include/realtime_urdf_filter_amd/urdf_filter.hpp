@@ -89,7 +89,8 @@ class URDFRenderer {
     for (auto& r : renderables_) {
       Transform looked;
       if (tf_.lookup(fixed_frame_, r->name, looked)) t = looked;
-      r->link_to_fixed = t;
+      // tf::Transform(t.getRotation(), t.getOrigin()) (src/urdf_renderer.cpp:187): matrix -> quaternion -> matrix, in double
+      r->link_to_fixed = Transform::from_quaternion(t.rotation(), t.o);
     }
   }
   std::vector<std::shared_ptr<Renderable>> renderables_;

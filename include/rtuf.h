@@ -73,7 +73,14 @@ typedef struct {
   uint32_t bin_capacity;            /* triangles per (stream, screen tile) bin; 0 = automatic */
   uint32_t max_inflight_streams;    /* streams rasterised per internal launch group; 0 = automatic: up to 1024,
                                        fewer if the bins would exceed a third of the free device memory */
-  uint32_t reserved[5];
+  uint32_t pipelines;               /* 0 / 1: one raster pipeline.  2..4: that many complete pipelines (HIP streams, bins,
+                                       staging, geometry copy) inside the context; batches alternate between them, so the
+                                       small and low-occupancy kernels of one batch (pose stage, cull, clip, kernel tails)
+                                       run underneath another batch's set-up / tile kernels (+10 % frames/s with 2 on the
+                                       256-stream VGA workload).  Setters apply to all pipelines; up to 2 x pipelines batches
+                                       may be in flight; rtuf_filter() and the debug read-backs use the first / the last-used
+                                       pipeline.  Fixed at rtuf_create. */
+  uint32_t reserved[4];
 } rtuf_params;
 
 void rtuf_default_params(rtuf_params *p);
@@ -206,6 +213,30 @@ int rtuf_filter_batch_async(rtuf_context *ctx, int n_streams, const float *const
                             float *const *masked_out, uint8_t *const *mask_out);
 int rtuf_filter_batch_u16_async(rtuf_context *ctx, int n_streams, const uint16_t *const *depth_mm_in,
                                 uint16_t *const *masked_mm_out, uint8_t *const *mask_out);
+/* ---- mask-only output, one bit per pixel -----------------------------------------------------------------
+ * The reference publishes the mask on its own topic (src/urdf_filter.cpp:321-329) and the masked depth is a pure
+ * function of sensor plane and mask: masked = mask ? filter_replace_value : sensor (tests check this bit for bit on
+ * every full-plane result).  These calls return ONLY the mask, packed: pixel (x, y) of a stream is bit x % 32 of
+ * 32-bit word y * ceil(width / 32) + x / 32 (rtuf_mask_bits_words() words per stream).  Device-to-host traffic per
+ * VGA frame drops from 1.54 MB to 38 KB, which turns the PCIe-bound host-plane path from download-bound into
+ * upload-bound; rtuf_expand_mask_bits() rebuilds masked depth and/or the byte mask of a frame on the host where and
+ * when a consumer needs them.  Fused mode only; width must be a multiple of 4.  Exactness: the identity above holds
+ * wherever the background quad covers the image -- every getProjectionMatrix() camera.  For a projection where it
+ * does not (pixels the reference leaves at the GL clear colour 0), retiring the batch fails with RTUF_ERR_STATE
+ * instead of returning bits that would expand to something else. */
+size_t rtuf_mask_bits_words(int width, int height);
+int rtuf_filter_batch_bits_async(rtuf_context *ctx, int n_streams, const float *const *depth_in, uint32_t *const *bits_out);
+int rtuf_filter_batch_bits_u16_async(rtuf_context *ctx, int n_streams, const uint16_t *const *depth_mm_in,
+                                     uint32_t *const *bits_out);
+/* device-resident planes: depth [n][H][W], bits [n][rtuf_mask_bits_words()] */
+int rtuf_filter_batch_device_bits(rtuf_context *ctx, int n_streams, const float *d_depth, uint32_t *d_bits);
+int rtuf_filter_batch_device_bits_u16(rtuf_context *ctx, int n_streams, const uint16_t *d_depth_mm, uint32_t *d_bits);
+/* Host helper (no GPU, no context): one frame's masked depth (float32, or uint16 millimetres with the reference's
+ * convertTo arithmetic when is_u16) and/or 0/255 byte mask from its sensor plane and mask bits.  Either output may
+ * be NULL. */
+int rtuf_expand_mask_bits(const void *depth_in, int is_u16, const uint32_t *bits, int width, int height,
+                          float replace_value, void *masked_out, uint8_t *mask_out);
+
 /* Waits for the oldest batch in flight (device or host planes); its outputs are complete afterwards.
  * RTUF_OK when nothing is pending. */
 int rtuf_wait_oldest(rtuf_context *ctx);

@@ -1,4 +1,4 @@
 """MI355X-native realtime URDF depth self-filter (hot path of blodow/realtime_urdf_filter)."""
 from ._capi import (Context, Params, RtufError, default_params, load_library,  # noqa: F401
                     projection_from_intrinsics, OP_NONE, OP_SCALE, OP_TRANSLATE,
-                    FLAG_TWO_KERNEL, ABI_VERSION)
+                    FLAG_TWO_KERNEL, ABI_VERSION, expand_mask_bits)

@@ -27,6 +27,8 @@ SYMBOLS = [
     "rtuf_filter_batch_device", "rtuf_filter_batch_u16", "rtuf_filter_batch_device_u16", "rtuf_filter", "rtuf_get_masked_depth", "rtuf_get_mask", "rtuf_sync",
     "rtuf_stream", "rtuf_get_stats", "rtuf_enable_timing", "rtuf_debug_read_zsurface",
     "rtuf_filter_batch_async", "rtuf_filter_batch_u16_async", "rtuf_wait_oldest", "rtuf_host_alloc", "rtuf_host_free",
+    "rtuf_mask_bits_words", "rtuf_filter_batch_bits_async", "rtuf_filter_batch_bits_u16_async", "rtuf_filter_batch_device_bits",
+    "rtuf_filter_batch_device_bits_u16", "rtuf_expand_mask_bits",
 ]
 
 
@@ -34,7 +36,7 @@ class Params(ctypes.Structure):
     _fields_ = [("near_plane", ctypes.c_float), ("far_plane", ctypes.c_float),
                 ("depth_distance_threshold", ctypes.c_float), ("filter_replace_value", ctypes.c_float),
                 ("flags", ctypes.c_uint32), ("bin_capacity", ctypes.c_uint32),
-                ("max_inflight_streams", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 5)]
+                ("max_inflight_streams", ctypes.c_uint32), ("pipelines", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 4)]
 
 
 class Stats(ctypes.Structure):
@@ -141,6 +143,13 @@ def load_library(path=None):
     lib.rtuf_wait_oldest.argtypes = [vp]
     lib.rtuf_host_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     lib.rtuf_host_free.argtypes = [vp, vp]
+    lib.rtuf_mask_bits_words.argtypes = [ci, ci]
+    lib.rtuf_mask_bits_words.restype = ctypes.c_size_t
+    lib.rtuf_filter_batch_bits_async.argtypes = [vp, ci, vp, vp]
+    lib.rtuf_filter_batch_bits_u16_async.argtypes = [vp, ci, vp, vp]
+    lib.rtuf_filter_batch_device_bits.argtypes = [vp, ci, vp, vp]
+    lib.rtuf_filter_batch_device_bits_u16.argtypes = [vp, ci, vp, vp]
+    lib.rtuf_expand_mask_bits.argtypes = [vp, ci, vp, ci, ci, ctypes.c_float, vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -330,6 +339,27 @@ class Context:
         fn = self._lib.rtuf_filter_batch_u16_async if u16 else self._lib.rtuf_filter_batch_async
         self._check(fn(self._h, n, din, mout, kout))
 
+    # mask-only output, one bit per pixel
+    def mask_bits_words(self):
+        return int(self._lib.rtuf_mask_bits_words(self.width, self.height))
+
+    def filter_batch_bits_async(self, depth, bits):
+        """Enqueue only: depth [n,H,W] float32 or uint16 host array, bits [n, mask_bits_words()] uint32 host array
+        (pinned for overlap); retire with wait_oldest() / sync()."""
+        n = depth.shape[0]
+        u16 = depth.dtype == np.uint16
+        assert depth.flags.c_contiguous and depth.dtype in (np.float32, np.uint16) and depth.shape == (n, self.height, self.width)
+        assert bits.flags.c_contiguous and bits.dtype == np.uint32 and bits.shape == (n, self.mask_bits_words())
+        PP = ctypes.c_void_p * n
+        din = PP(*[depth[i].ctypes.data for i in range(n)])
+        bout = PP(*[bits[i].ctypes.data for i in range(n)])
+        fn = self._lib.rtuf_filter_batch_bits_u16_async if u16 else self._lib.rtuf_filter_batch_bits_async
+        self._check(fn(self._h, n, din, bout))
+
+    def filter_batch_device_bits(self, n, d_depth, d_bits, u16=False):
+        fn = self._lib.rtuf_filter_batch_device_bits_u16 if u16 else self._lib.rtuf_filter_batch_device_bits
+        self._check(fn(self._h, n, ctypes.c_void_p(d_depth), ctypes.c_void_p(d_bits)))
+
     def wait_oldest(self):
         self._check(self._lib.rtuf_wait_oldest(self._h))
 
@@ -371,3 +401,18 @@ class Context:
         out = np.empty((n, self.height, self.width), np.float32)
         self._check(self._lib.rtuf_debug_read_zsurface(self._h, n, _ptr(out)))
         return out
+
+
+def expand_mask_bits(depth, bits, replace_value, want_masked=True, want_mask=True):
+    """Host helper rtuf_expand_mask_bits for one frame: depth [H,W] float32 or uint16, bits [mask_bits_words] uint32
+    -> (masked like depth or None, mask u8 [H,W] or None)."""
+    d = np.ascontiguousarray(depth)
+    assert d.dtype in (np.float32, np.uint16) and d.ndim == 2
+    H, W = d.shape
+    b = np.ascontiguousarray(bits, np.uint32)
+    masked = np.empty_like(d) if want_masked else None
+    mask = np.empty((H, W), np.uint8) if want_mask else None
+    rc = load_library().rtuf_expand_mask_bits(_ptr(d), 1 if d.dtype == np.uint16 else 0, _ptr(b), W, H, float(replace_value), _ptr(masked), _ptr(mask))
+    if rc != RTUF_OK:
+        raise RtufError(rc, "rtuf_expand_mask_bits failed")
+    return masked, mask

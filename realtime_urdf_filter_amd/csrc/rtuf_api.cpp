@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <string>
 #include <vector>
@@ -109,6 +110,7 @@ struct rtuf_context {
   struct Batch {
     bool active = false;
     int n = 0; const float* depth = nullptr; float* masked = nullptr; uint8_t* mask = nullptr; bool u16 = false;
+    uint32_t* bits = nullptr;                // mask-only output (1 bit per pixel) instead of masked / mask
     Counters* h_counters = nullptr;          // pinned; filled by the copy that ends the batch
     hipEvent_t done = nullptr;               // recorded after that copy
     std::vector<hipEvent_t> events;          // stage timing
@@ -127,7 +129,8 @@ struct rtuf_context {
     // events that order upload -> kernels -> download across the copy streams.
     bool host_io = false;
     float* st_depth = nullptr; float* st_masked = nullptr; uint8_t* st_mask = nullptr; size_t st_streams = 0;
-    std::vector<void*> h_masked, h_mask;
+    uint32_t* st_bits = nullptr; size_t st_bits_streams = 0;
+    std::vector<void*> h_masked, h_mask, h_bits;
     hipEvent_t uploaded = nullptr, downloaded = nullptr;
   };
   Batch batch[kMaxInflight];
@@ -139,6 +142,14 @@ struct rtuf_context {
   bool dirty_mask = true;
   int mask_uploaded_streams = 0;
   int last_slot = 0;                         // slot of the most recently enqueued batch (debug read-back)
+
+  // rtuf_params.pipelines > 1: this context is only a front; `kids` are complete contexts (own streams, bins, staging,
+  // geometry copy) that the batches alternate between, so one batch's small / low-occupancy kernels (pose stage, cull,
+  // clip, kernel tails) overlap another batch's set-up and tile kernels.  Every setter goes to all kids (state is
+  // replicated), every filter call to the next kid in turn; `order` lists the kids of the batches in flight, oldest first.
+  std::vector<rtuf_context*> kids;
+  int next_kid = 0, last_kid = 0;
+  std::deque<int> order;
 
   rtuf_stats stats{};
   int timing = 0;            // 0 off, 1 every stage, 2 only around the tile (and compare) kernel, 3 = 2 on every fourth batch
@@ -165,6 +176,40 @@ struct rtuf_context {
 // Setters whose staging buffers the batch in flight may still be reading (or would re-read on a bin
 // regrowth) wait for it; rtuf_set_joint_positions alone is double-buffered and never waits.
 #define WAIT_IF_PENDING(c) do { if ((c)->pending) { const int rc_ = rtuf_sync(c); if (rc_ != RTUF_OK) return rc_; } } while (0)
+
+// ---- pipelines: forwarding from the front context to its kids -------------------------------------------------
+#define KIDS_ALL(c, expr)                                                                  \
+  if ((c) && !(c)->kids.empty()) {                                                         \
+    int rc_ = RTUF_OK;                                                                     \
+    for (rtuf_context* k : (c)->kids) { rc_ = (expr); if (rc_ < 0) { (c)->error = k->error; return rc_; } } \
+    return rc_;                                                                            \
+  }
+#define KIDS_ONE(c, which, expr)                                                           \
+  if ((c) && !(c)->kids.empty()) {                                                         \
+    rtuf_context* k = (c)->kids[which];                                                    \
+    const int rc_ = (expr);                                                                \
+    if (rc_ < 0) (c)->error = k->error;                                                    \
+    return rc_;                                                                            \
+  }
+// the kid that takes the next batch; keeps `order` in step with what that kid will retire on its own
+static rtuf_context* take_next_kid(rtuf_context* c)
+{
+  const int j = c->next_kid;
+  const int limit = (c->params.flags & RTUF_FLAG_TWO_KERNEL) ? 1 : kMaxInflight;
+  if ((int)std::count(c->order.begin(), c->order.end(), j) >= limit)
+    c->order.erase(std::find(c->order.begin(), c->order.end(), j));      // the kid retires its oldest itself when it is full
+  c->order.push_back(j);
+  c->last_kid = j;
+  c->next_kid = (j + 1) % (int)c->kids.size();
+  return c->kids[j];
+}
+#define KIDS_NEXT(c, expr)                                                                 \
+  if ((c) && !(c)->kids.empty()) {                                                         \
+    rtuf_context* k = take_next_kid(c);                                                    \
+    const int rc_ = (expr);                                                                \
+    if (rc_ < 0) { (c)->error = k->error; (c)->order.pop_back(); }                         \
+    return rc_;                                                                            \
+  }
 
 extern "C" {
 
@@ -219,6 +264,17 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
     delete c;
     return RTUF_ERR_HIP;
   }
+  if (c->params.pipelines > 1) {
+    if (c->params.pipelines > 4) { snprintf(g_create_error, sizeof g_create_error, "pipelines = %u: at most 4", c->params.pipelines); rtuf_destroy(c); return RTUF_ERR_INVALID; }
+    rtuf_params kp = c->params;
+    kp.pipelines = 0;
+    for (uint32_t i = 0; i < c->params.pipelines; i++) {
+      rtuf_context* k = nullptr;
+      const int rc = rtuf_create(&k, device_id, width, height, max_streams, &kp);
+      if (rc != RTUF_OK) { rtuf_destroy(c); return rc; }
+      c->kids.push_back(k);
+    }
+  }
   *out = c;
   return RTUF_OK;
 }
@@ -231,7 +287,7 @@ static void free_frame_buffers(rtuf_context* c)
   dfree(c->d_model_mask);
   for (auto& b : c->batch) { dfree(b.d_cams); dfree(b.d_link_tf); dfree(b.d_mvp); dfree(b.d_bg); dfree(b.d_items); dfree(b.d_counters); }
   dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_zsurface);
-  for (auto& b : c->batch) { dfree(b.st_depth); dfree(b.st_masked); dfree(b.st_mask); b.st_streams = 0; }
+  for (auto& b : c->batch) { dfree(b.st_depth); dfree(b.st_masked); dfree(b.st_mask); b.st_streams = 0; dfree(b.st_bits); b.st_bits_streams = 0; }
   hfree(c->h_cams); hfree(c->h_link_tf); hfree(c->h_model_mask);
   for (auto& b : c->batch) hfree(b.h_counters);
 }
@@ -239,6 +295,8 @@ static void free_frame_buffers(rtuf_context* c)
 void rtuf_destroy(rtuf_context* c)
 {
   if (!c) return;
+  for (rtuf_context* k : c->kids) rtuf_destroy(k);
+  c->kids.clear();
   hipSetDevice(c->device);
   if (c->side) hipStreamSynchronize(c->side);
   if (c->stream) hipStreamSynchronize(c->stream);
@@ -274,15 +332,25 @@ int rtuf_set_params(rtuf_context* c, const rtuf_params* p)
 {
   if (!c || !p) return RTUF_ERR_INVALID;
   if (!flags_valid(p->flags)) return c->fail(RTUF_ERR_INVALID, "unknown rtuf_params.flags bits 0x%x", p->flags & ~kKnownFlags);
+  if (!c->kids.empty()) {
+    rtuf_params kp = *p;
+    kp.pipelines = 0;
+    for (rtuf_context* k : c->kids) { const int rc = rtuf_set_params(k, &kp); if (rc < 0) { c->error = k->error; return rc; } }
+    const uint32_t keep = c->params.pipelines;
+    c->params = c->kids[0]->params;
+    c->params.pipelines = keep;
+    return RTUF_OK;
+  }
   WAIT_IF_PENDING(c);
   // the background quad's geometry (0.99 * far, src/urdf_filter.cpp:591-596) is built by rtuf_finalize_models
   if (c->finalized && p->far_plane != c->params.far_plane)
     return c->fail(RTUF_ERR_STATE, "far_plane is fixed once the models are finalized (was %g)", (double)c->params.far_plane);
-  const uint32_t keep_cap = c->params.bin_capacity, keep_inf = c->params.max_inflight_streams;
+  const uint32_t keep_cap = c->params.bin_capacity, keep_inf = c->params.max_inflight_streams, keep_pipes = c->params.pipelines;
   const bool two_before = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
   c->params = *p;
   c->params.bin_capacity = keep_cap;
   c->params.max_inflight_streams = keep_inf;
+  c->params.pipelines = keep_pipes;
   const bool two_now = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
   if (c->finalized && two_now && !two_before && !c->d_zsurface) {
     hipSetDevice(c->device);
@@ -294,6 +362,7 @@ int rtuf_set_params(rtuf_context* c, const rtuf_params* p)
 // ---- geometry -------------------------------------------------------------------------
 int rtuf_add_model(rtuf_context* c)
 {
+  KIDS_ALL(c, rtuf_add_model(k));
   if (!c) return RTUF_ERR_INVALID;
   if (c->finalized) return c->fail(RTUF_ERR_STATE, "models already finalised");
   if (c->models.size() >= 64) return c->fail(RTUF_ERR_INVALID, "at most 64 models per context");
@@ -303,6 +372,7 @@ int rtuf_add_model(rtuf_context* c)
 
 int rtuf_add_link(rtuf_context* c, int model)
 {
+  KIDS_ALL(c, rtuf_add_link(k, model));
   if (!c) return RTUF_ERR_INVALID;
   if (c->finalized) return c->fail(RTUF_ERR_STATE, "models already finalised");
   if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
@@ -313,6 +383,7 @@ int rtuf_add_link(rtuf_context* c, int model)
 int rtuf_add_draw(rtuf_context* c, int model, int link, int pre_op, const float op_xyz[3],
                   const float* vertices_xyz, int n_vertices, const uint32_t* triangles, int n_triangles)
 {
+  KIDS_ALL(c, rtuf_add_draw(k, model, link, pre_op, op_xyz, vertices_xyz, n_vertices, triangles, n_triangles));
   if (!c) return RTUF_ERR_INVALID;
   if (c->finalized) return c->fail(RTUF_ERR_STATE, "models already finalised");
   if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
@@ -334,11 +405,12 @@ int rtuf_add_draw(rtuf_context* c, int model, int link, int pre_op, const float 
 
 int rtuf_num_links(const rtuf_context* c, int model)
 {
+  if (c && !c->kids.empty()) return rtuf_num_links(c->kids[0], model);
   if (!c || model < 0 || model >= (int)c->models.size()) return RTUF_ERR_INVALID;
   return (int)c->models[model].links.size();
 }
 
-int64_t rtuf_num_triangles(const rtuf_context* c) { return c ? c->n_tris : 0; }
+int64_t rtuf_num_triangles(const rtuf_context* c) { return c ? (c->kids.empty() ? c->n_tris : c->kids[0]->n_tris) : 0; }
 
 static int alloc_frame_buffers(rtuf_context* c)
 {
@@ -406,6 +478,7 @@ static int alloc_frame_buffers(rtuf_context* c)
 
 int rtuf_finalize_models(rtuf_context* c)
 {
+  KIDS_ALL(c, rtuf_finalize_models(k));
   if (!c) return RTUF_ERR_INVALID;
   if (c->finalized) return c->fail(RTUF_ERR_STATE, "models already finalised");
   hipSetDevice(c->device);
@@ -552,6 +625,7 @@ int rtuf_finalize_models(rtuf_context* c)
 
 int rtuf_set_stream_models(rtuf_context* c, int stream, const int* model_ids, int n_models)
 {
+  KIDS_ALL(c, rtuf_set_stream_models(k, stream, model_ids, n_models));
   if (!c) return RTUF_ERR_INVALID;
   WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
@@ -570,6 +644,7 @@ int rtuf_set_stream_models(rtuf_context* c, int stream, const int* model_ids, in
 int rtuf_set_camera(rtuf_context* c, int stream, const double projection[16], const double camera_offset_inv[16],
                     const double camera_tf[16])
 {
+  KIDS_ALL(c, rtuf_set_camera(k, stream, projection, camera_offset_inv, camera_tf));
   if (!c) return RTUF_ERR_INVALID;
   WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
@@ -601,6 +676,7 @@ void rtuf_projection_from_intrinsics(double fx, double fy, double cx, double cy,
 
 int rtuf_set_link_poses(rtuf_context* c, int stream, int model, const double* link_tf, int n_links)
 {
+  KIDS_ALL(c, rtuf_set_link_poses(k, stream, model, link_tf, n_links));
   if (!c || !link_tf) return RTUF_ERR_INVALID;
   WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
@@ -618,6 +694,7 @@ int rtuf_set_link_poses(rtuf_context* c, int stream, int model, const double* li
 int rtuf_set_cameras(rtuf_context* c, int first, int n, const double* projection, const double* offset_inv,
                      const double* cam_tf)
 {
+  KIDS_ALL(c, rtuf_set_cameras(k, first, n, projection, offset_inv, cam_tf));
   if (!c) return RTUF_ERR_INVALID;
   WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
@@ -634,6 +711,7 @@ int rtuf_set_cameras(rtuf_context* c, int first, int n, const double* projection
 
 int rtuf_set_camera_shift(rtuf_context* c, int first, int n, const double* camera_tx, const double* camera_ty)
 {
+  KIDS_ALL(c, rtuf_set_camera_shift(k, first, n, camera_tx, camera_ty));
   if (!c) return RTUF_ERR_INVALID;
   WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
@@ -648,6 +726,7 @@ int rtuf_set_camera_shift(rtuf_context* c, int first, int n, const double* camer
 
 int rtuf_set_link_poses_batch(rtuf_context* c, int first, int n, int model, const double* link_tf, int n_links)
 {
+  KIDS_ALL(c, rtuf_set_link_poses_batch(k, first, n, model, link_tf, n_links));
   if (!c || !link_tf) return RTUF_ERR_INVALID;
   WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
@@ -678,6 +757,7 @@ int rtuf_set_kinematics(rtuf_context* c, int model, int n_frames, const int32_t*
                         const double* joint_origin, const double* joint_axis, const int32_t* link_frame,
                         const double* link_offset, int n_links)
 {
+  KIDS_ALL(c, rtuf_set_kinematics(k, model, n_frames, parent, joint_type, joint_origin, joint_axis, link_frame, link_offset, n_links));
   if (!c || !parent || !joint_type || !joint_origin || !joint_axis || !link_frame || !link_offset) return RTUF_ERR_INVALID;
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
   if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
@@ -730,6 +810,7 @@ int rtuf_set_kinematics(rtuf_context* c, int model, int n_frames, const int32_t*
 
 int rtuf_set_joint_positions(rtuf_context* c, int first, int n, int model, const double* q, const double* root_tf, int camera_frame)
 {
+  KIDS_ALL(c, rtuf_set_joint_positions(k, first, n, model, q, root_tf, camera_frame));
   if (!c || !q) return RTUF_ERR_INVALID;
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
   if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
@@ -772,6 +853,7 @@ int rtuf_set_joint_positions(rtuf_context* c, int first, int n, int model, const
 
 int rtuf_debug_read_poses(rtuf_context* c, int n, double* link_tf_out, double* cam_tf_out)
 {
+  KIDS_ONE(c, c->last_kid, rtuf_debug_read_poses(k, n, link_tf_out, cam_tf_out));
   if (!c) return RTUF_ERR_INVALID;
   if (!c->finalized || n <= 0 || n > c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad arguments");
   hipSetDevice(c->device);
@@ -928,10 +1010,11 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     ta.max_diff = c->params.depth_distance_threshold; ta.replace_value = c->params.filter_replace_value;
     ta.sc_num = sc_num; ta.sc_off = sc_off;
     ta.io_u16 = io_u16 ? 1 : 0;
+    ta.bits = b.bits;
     if (b.timing) hipEventRecord(get_event(b, ev++), st);
     launch_tile(ta, two, st);
     if (b.timing) hipEventRecord(get_event(b, ev++), st);
-    if (two) {
+    if (two && !b.bits) {
       CompareArgs ca{};
       ca.depth = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_depth) + (size_t)base * plane * esz); ca.zsurface = c->d_zsurface;
       ca.masked = reinterpret_cast<float*>(reinterpret_cast<char*>(d_masked) + (size_t)base * plane * esz);
@@ -956,6 +1039,17 @@ static int enqueue_download(rtuf_context* c, rtuf_context::Batch& b)
   const size_t plane = (size_t)c->width * c->height;
   const size_t esz = b.u16 ? sizeof(uint16_t) : sizeof(float);
   HIP_TRY(c, hipStreamWaitEvent(c->d2h, b.done, 0));
+  if (b.bits) {
+    const size_t words = (size_t)c->height * (size_t)((c->width + 31) / 32);
+    for (int s = 0; s < b.n;) {
+      int e = s + 1;
+      while (e < b.n && (char*)b.h_bits[e] == (char*)b.h_bits[e - 1] + words * 4) e++;
+      HIP_TRY(c, hipMemcpyAsync(b.h_bits[s], b.st_bits + (size_t)s * words, (size_t)(e - s) * words * 4, hipMemcpyDeviceToHost, c->d2h));
+      s = e;
+    }
+    HIP_TRY(c, hipEventRecord(b.downloaded, c->d2h));
+    return RTUF_OK;
+  }
   for (int s = 0; s < b.n;) {
     int e = s + 1;
     while (e < b.n && (char*)b.h_masked[e] == (char*)b.h_masked[e - 1] + plane * esz) e++;
@@ -981,13 +1075,13 @@ static int retire_oldest(rtuf_context* c)
     rtuf_context::Batch& b = c->batch[c->oldest];
     if (!c->pending || !b.active) { c->pending = 0; return RTUF_OK; }
     HIP_TRY(c, hipEventSynchronize(b.done));
-    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0; unsigned max_bin_fill = 0, max_fbin_fill = 0, clip_overflow = 0; } k;
+    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0; unsigned max_bin_fill = 0, max_fbin_fill = 0, clip_overflow = 0, uncovered = 0; } k;
     c->items_hint = b.h_counters->work.n_items;      // sizes the next batches' set-up grid
     for (int i = 0; i < kCounterShards; i++) {
       const CounterShard& sh = b.h_counters->shard[i];
       k.tris_binned += sh.tris_binned; k.bin_entries += sh.bin_entries; k.clip_count += sh.clip_count;
       k.max_bin_fill = std::max(k.max_bin_fill, sh.max_bin_fill); k.clip_overflow |= sh.clip_overflow;
-      k.max_fbin_fill = std::max(k.max_fbin_fill, sh.max_fbin_fill); k.frags += sh.frags;
+      k.max_fbin_fill = std::max(k.max_fbin_fill, sh.max_fbin_fill); k.frags += sh.frags; k.uncovered |= sh.uncovered;
     }
     c->stats.triangles_submitted = (uint64_t)c->n_tris * (uint64_t)b.n;
     c->stats.triangles_binned = k.tris_binned;
@@ -1040,6 +1134,9 @@ static int retire_oldest(rtuf_context* c)
       b.active = false;
       c->oldest = (c->oldest + 1) % kMaxInflight;
       c->pending--;
+      if (b.bits && k.uncovered)
+        return c->fail(RTUF_ERR_STATE, "mask bits: a stream's background quad does not cover its whole image (non-standard projection), so "
+                                       "masked depth != select(bit, replace, sensor) there; use the full-plane calls for this camera");
       return RTUF_OK;
     }
     // overflow: wait for the later batches too, enlarge, and run everything in flight again in order
@@ -1067,7 +1164,7 @@ static int retire_oldest(rtuf_context* c)
   return c->fail(RTUF_ERR_CAPACITY, "tile bins still overflow after regrowth");
 }
 
-static int submit_batch(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask, bool u16)
+static int submit_batch(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask, bool u16, uint32_t* d_bits = nullptr)
 {
   if (c->broken) return c->fail(RTUF_ERR_STATE, "context unusable: a bin regrowth failed (%s)", c->error.c_str());
   hipSetDevice(c->device);
@@ -1077,7 +1174,7 @@ static int submit_batch(rtuf_context* c, int n, const float* d_depth, float* d_m
   const int limit = (c->params.flags & RTUF_FLAG_TWO_KERNEL) ? 1 : kMaxInflight;
   while (c->pending >= limit) { const int rc = retire_oldest(c); if (rc != RTUF_OK) return rc; }
   rtuf_context::Batch& b = c->batch[(c->oldest + c->pending) % kMaxInflight];
-  b.n = n; b.depth = d_depth; b.masked = d_masked; b.mask = d_mask; b.u16 = u16; b.host_io = false;
+  b.n = n; b.depth = d_depth; b.masked = d_masked; b.mask = d_mask; b.u16 = u16; b.host_io = false; b.bits = d_bits;
   const int rc = enqueue_batch(c, b, false);
   if (rc == RTUF_OK) { b.active = true; c->pending++; }
   return rc;
@@ -1085,6 +1182,7 @@ static int submit_batch(rtuf_context* c, int n, const float* d_depth, float* d_m
 
 int rtuf_filter_batch_device(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask)
 {
+  KIDS_NEXT(c, rtuf_filter_batch_device(k, n, d_depth, d_masked, d_mask));
   if (!c) return RTUF_ERR_INVALID;
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
   if (n <= 0 || n > c->max_streams || !d_depth || !d_masked) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
@@ -1093,6 +1191,7 @@ int rtuf_filter_batch_device(rtuf_context* c, int n, const float* d_depth, float
 
 int rtuf_filter_batch_device_u16(rtuf_context* c, int n, const uint16_t* d_depth, uint16_t* d_masked, uint8_t* d_mask)
 {
+  KIDS_NEXT(c, rtuf_filter_batch_device_u16(k, n, d_depth, d_masked, d_mask));
   if (!c) return RTUF_ERR_INVALID;
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
   if (n <= 0 || n > c->max_streams || !d_depth || !d_masked) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
@@ -1100,16 +1199,91 @@ int rtuf_filter_batch_device_u16(rtuf_context* c, int n, const uint16_t* d_depth
   return submit_batch(c, n, reinterpret_cast<const float*>(d_depth), reinterpret_cast<float*>(d_masked), d_mask, true);
 }
 
+static int check_bits_call(rtuf_context* c, int n, const void* in, const void* out)
+{
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  if (n <= 0 || n > c->max_streams || !in || !out) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
+  if (c->width & 3) return c->fail(RTUF_ERR_INVALID, "mask-bits output needs a width that is a multiple of 4");
+  if (c->params.flags & RTUF_FLAG_TWO_KERNEL) return c->fail(RTUF_ERR_INVALID, "mask-bits output exists in fused mode only (RTUF_FLAG_TWO_KERNEL is set)");
+  return RTUF_OK;
+}
+
+size_t rtuf_mask_bits_words(int width, int height)
+{
+  return (width > 0 && height > 0) ? (size_t)height * (size_t)((width + 31) / 32) : 0;
+}
+
+int rtuf_filter_batch_device_bits(rtuf_context* c, int n, const float* d_depth, uint32_t* d_bits)
+{
+  KIDS_NEXT(c, rtuf_filter_batch_device_bits(k, n, d_depth, d_bits));
+  if (!c) return RTUF_ERR_INVALID;
+  const int rc = check_bits_call(c, n, d_depth, d_bits);
+  return rc != RTUF_OK ? rc : submit_batch(c, n, d_depth, nullptr, nullptr, false, d_bits);
+}
+
+int rtuf_filter_batch_device_bits_u16(rtuf_context* c, int n, const uint16_t* d_depth, uint32_t* d_bits)
+{
+  KIDS_NEXT(c, rtuf_filter_batch_device_bits_u16(k, n, d_depth, d_bits));
+  if (!c) return RTUF_ERR_INVALID;
+  const int rc = check_bits_call(c, n, d_depth, d_bits);
+  return rc != RTUF_OK ? rc : submit_batch(c, n, reinterpret_cast<const float*>(d_depth), nullptr, nullptr, true, d_bits);
+}
+
+// Host side of the mask-bits calls: masked depth / byte mask of one frame from its sensor plane and its mask bits,
+// with the arithmetic of the kernels (a pure select; for 16UC1 the reference's two convertTo roundings, see
+// metres_to_u16 in rtuf_kernels.hip).  No GPU involved.
+int rtuf_expand_mask_bits(const void* depth_in, int is_u16, const uint32_t* bits, int width, int height, float replace_value,
+                          void* masked_out, uint8_t* mask_out)
+{
+  if (!depth_in || !bits || width <= 0 || height <= 0 || (!masked_out && !mask_out)) return RTUF_ERR_INVALID;
+  const int row_words = (width + 31) / 32;
+  uint16_t rep16 = 0;
+  if (is_u16) {
+    const float v = replace_value * 1000.0f;
+    if (v >= -2147483648.0f && v < 2147483648.0f) { const long r = lrintf(v); rep16 = (uint16_t)(r < 0 ? 0 : (r > 65535 ? 65535 : r)); }
+  }
+  for (int y = 0; y < height; y++) {
+    const uint32_t* wrow = bits + (size_t)y * row_words;
+    const size_t o = (size_t)y * width;
+    for (int x = 0; x < width; x++) {
+      const bool f = (wrow[x >> 5] >> (x & 31)) & 1u;
+      if (mask_out) mask_out[o + x] = f ? 255 : 0;
+      if (!masked_out) continue;
+      if (is_u16) {
+        const uint16_t u = static_cast<const uint16_t*>(depth_in)[o + x];
+        uint16_t r = rep16;
+        if (!f) {                              // float(u) * 0.001f * 1000.0f, rounded half to even and saturated, like the kernels
+          const float m = (float)u * 0.001f;
+          const float v = m * 1000.0f;
+          const long q = lrintf(v);
+          r = (uint16_t)(q < 0 ? 0 : (q > 65535 ? 65535 : q));
+        }
+        static_cast<uint16_t*>(masked_out)[o + x] = r;
+      } else {
+        static_cast<float*>(masked_out)[o + x] = f ? replace_value : static_cast<const float*>(depth_in)[o + x];
+      }
+    }
+  }
+  return RTUF_OK;
+}
+
 int rtuf_sync(rtuf_context* c)
 {
   if (!c) return RTUF_ERR_INVALID;
+  if (!c->kids.empty()) {
+    // every kid is synchronised even if one fails (the first failure is reported)
+    int first_rc = RTUF_OK;
+    c->order.clear();
+    for (rtuf_context* k : c->kids) { const int rc = rtuf_sync(k); if (rc < 0 && first_rc == RTUF_OK) { first_rc = rc; c->error = k->error; } }
+    return first_rc;
+  }
   hipSetDevice(c->device);
   while (c->pending) { const int rc = retire_oldest(c); if (rc != RTUF_OK) return rc; }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return RTUF_OK;
 }
 
-void* rtuf_stream(rtuf_context* c) { return c ? (void*)c->stream : nullptr; }
+void* rtuf_stream(rtuf_context* c) { return c ? (void*)(c->kids.empty() ? c->stream : c->kids[0]->stream) : nullptr; }
 
 // ---- host planes -----------------------------------------------------------------------------------
 // The reference's filter() takes a host buffer and leaves host results (src/urdf_filter.cpp:233-234,
@@ -1117,13 +1291,14 @@ void* rtuf_stream(rtuf_context* c) { return c ? (void*)c->stream : nullptr; }
 // batches in flight the transfers of one overlap the kernels of the other; every slot has its own
 // device staging.
 static int submit_host_batch(rtuf_context* c, int n, const void* const* depth_in, void* const* masked_out,
-                             void* const* mask_out, bool u16)
+                             void* const* mask_out, bool u16, uint32_t* const* bits_out = nullptr)
 {
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
-  if (n <= 0 || n > c->max_streams || !depth_in || !masked_out) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
+  if (n <= 0 || n > c->max_streams || !depth_in || (!masked_out && !bits_out)) return c->fail(RTUF_ERR_INVALID, "bad batch arguments (n=%d)", n);
   if (u16 && (c->width & 3)) return c->fail(RTUF_ERR_INVALID, "16UC1 path needs a width that is a multiple of 4");
+  if (bits_out) { const int rc = check_bits_call(c, n, depth_in, bits_out); if (rc != RTUF_OK) return rc; }
   for (int s = 0; s < n; s++)
-    if (!depth_in[s] || !masked_out[s]) return c->fail(RTUF_ERR_INVALID, "null plane for stream %d", s);
+    if (!depth_in[s] || (bits_out ? !bits_out[s] : !masked_out[s])) return c->fail(RTUF_ERR_INVALID, "null plane for stream %d", s);
   hipSetDevice(c->device);
   if (!c->h2d) HIP_TRY(c, hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking));
   if (!c->d2h) HIP_TRY(c, hipStreamCreateWithFlags(&c->d2h, hipStreamNonBlocking));
@@ -1139,6 +1314,12 @@ static int submit_host_batch(rtuf_context* c, int n, const void* const* depth_in
     HIP_TRY(c, hipMalloc(&b.st_mask, (size_t)n * plane));
     b.st_streams = (size_t)n;
   }
+  if (bits_out && b.st_bits_streams < (size_t)n) {
+    if (b.st_bits) { hipFree(b.st_bits); b.st_bits = nullptr; }
+    b.st_bits_streams = 0;
+    HIP_TRY(c, hipMalloc(&b.st_bits, (size_t)n * rtuf_mask_bits_words(c->width, c->height) * sizeof(uint32_t)));
+    b.st_bits_streams = (size_t)n;
+  }
   if (!b.uploaded) HIP_TRY(c, hipEventCreateWithFlags(&b.uploaded, hipEventDisableTiming));
   if (!b.downloaded) HIP_TRY(c, hipEventCreateWithFlags(&b.downloaded, hipEventDisableTiming));
   const size_t esz = u16 ? sizeof(uint16_t) : sizeof(float);
@@ -1151,10 +1332,15 @@ static int submit_host_batch(rtuf_context* c, int n, const void* const* depth_in
   HIP_TRY(c, hipEventRecord(b.uploaded, c->h2d));
   HIP_TRY(c, hipStreamWaitEvent(c->stream, b.uploaded, 0));
   bool any_mask = false;
-  b.h_masked.assign(masked_out, masked_out + n);
-  b.h_mask.assign((size_t)n, nullptr);
-  if (mask_out) for (int s = 0; s < n; s++) { b.h_mask[s] = mask_out[s]; any_mask |= mask_out[s] != nullptr; }
-  int rc = submit_batch(c, n, b.st_depth, b.st_masked, any_mask ? b.st_mask : nullptr, u16);
+  b.h_bits.clear();
+  if (bits_out) {
+    b.h_bits.assign(reinterpret_cast<void* const*>(bits_out), reinterpret_cast<void* const*>(bits_out) + n);
+  } else {
+    b.h_masked.assign(masked_out, masked_out + n);
+    b.h_mask.assign((size_t)n, nullptr);
+    if (mask_out) for (int s = 0; s < n; s++) { b.h_mask[s] = mask_out[s]; any_mask |= mask_out[s] != nullptr; }
+  }
+  int rc = submit_batch(c, n, b.st_depth, b.st_masked, any_mask ? b.st_mask : nullptr, u16, bits_out ? b.st_bits : nullptr);
   if (rc != RTUF_OK) return rc;
   b.host_io = true;
   return enqueue_download(c, b);
@@ -1163,6 +1349,7 @@ static int submit_host_batch(rtuf_context* c, int n, const void* const* depth_in
 int rtuf_filter_batch_async(rtuf_context* c, int n, const float* const* depth_in, float* const* masked_out,
                             uint8_t* const* mask_out)
 {
+  KIDS_NEXT(c, rtuf_filter_batch_async(k, n, depth_in, masked_out, mask_out));
   if (!c) return RTUF_ERR_INVALID;
   return submit_host_batch(c, n, reinterpret_cast<const void* const*>(depth_in), reinterpret_cast<void* const*>(masked_out),
                            reinterpret_cast<void* const*>(mask_out), false);
@@ -1171,9 +1358,24 @@ int rtuf_filter_batch_async(rtuf_context* c, int n, const float* const* depth_in
 int rtuf_filter_batch_u16_async(rtuf_context* c, int n, const uint16_t* const* depth_in, uint16_t* const* masked_out,
                                 uint8_t* const* mask_out)
 {
+  KIDS_NEXT(c, rtuf_filter_batch_u16_async(k, n, depth_in, masked_out, mask_out));
   if (!c) return RTUF_ERR_INVALID;
   return submit_host_batch(c, n, reinterpret_cast<const void* const*>(depth_in), reinterpret_cast<void* const*>(masked_out),
                            reinterpret_cast<void* const*>(mask_out), true);
+}
+
+int rtuf_filter_batch_bits_async(rtuf_context* c, int n, const float* const* depth_in, uint32_t* const* bits_out)
+{
+  KIDS_NEXT(c, rtuf_filter_batch_bits_async(k, n, depth_in, bits_out));
+  if (!c) return RTUF_ERR_INVALID;
+  return submit_host_batch(c, n, reinterpret_cast<const void* const*>(depth_in), nullptr, nullptr, false, bits_out);
+}
+
+int rtuf_filter_batch_bits_u16_async(rtuf_context* c, int n, const uint16_t* const* depth_in, uint32_t* const* bits_out)
+{
+  KIDS_NEXT(c, rtuf_filter_batch_bits_u16_async(k, n, depth_in, bits_out));
+  if (!c) return RTUF_ERR_INVALID;
+  return submit_host_batch(c, n, reinterpret_cast<const void* const*>(depth_in), nullptr, nullptr, true, bits_out);
 }
 
 int rtuf_filter_batch(rtuf_context* c, int n, const float* const* depth_in, float* const* masked_out,
@@ -1193,12 +1395,21 @@ int rtuf_filter_batch_u16(rtuf_context* c, int n, const uint16_t* const* depth_i
 int rtuf_wait_oldest(rtuf_context* c)
 {
   if (!c) return RTUF_ERR_INVALID;
+  if (!c->kids.empty()) {
+    if (c->order.empty()) return RTUF_OK;
+    rtuf_context* k = c->kids[c->order.front()];
+    c->order.pop_front();
+    const int rc = rtuf_wait_oldest(k);
+    if (rc < 0) c->error = k->error;
+    return rc;
+  }
   hipSetDevice(c->device);
   return c->pending ? retire_oldest(c) : RTUF_OK;
 }
 
 int rtuf_host_alloc(rtuf_context* c, size_t bytes, void** out)
 {
+  KIDS_ONE(c, 0, rtuf_host_alloc(k, bytes, out));
   if (!c || !out || !bytes) return RTUF_ERR_INVALID;
   hipSetDevice(c->device);
   void* p = nullptr;
@@ -1211,6 +1422,12 @@ int rtuf_host_alloc(rtuf_context* c, size_t bytes, void** out)
 int rtuf_host_free(rtuf_context* c, void* p)
 {
   if (!c) return RTUF_ERR_INVALID;
+  if (!c->kids.empty()) {
+    if (!p) return RTUF_OK;
+    const int rc = rtuf_sync(c);           // no transfer of any pipeline may still target the block
+    if (rc < 0) return rc;
+    KIDS_ONE(c, 0, rtuf_host_free(k, p));
+  }
   if (!p) return RTUF_OK;
   hipSetDevice(c->device);
   auto it = std::find(c->pinned.begin(), c->pinned.end(), p);
@@ -1224,6 +1441,11 @@ int rtuf_host_free(rtuf_context* c, void* p)
 
 int rtuf_filter(rtuf_context* c, const unsigned char* buffer, const double* projection, int width, int height)
 {
+  if (c && !c->kids.empty()) {
+    // the single-stream call runs on the first pipeline; its projection is a setter like any other (all pipelines)
+    if (projection) { const int rc_ = rtuf_set_camera(c, 0, projection, nullptr, nullptr); if (rc_ < 0) return rc_; }
+    KIDS_ONE(c, 0, rtuf_filter(k, buffer, nullptr, width, height));
+  }
   if (!c || !buffer) return RTUF_ERR_INVALID;
   if (width != c->width || height != c->height)
     return c->fail(RTUF_ERR_INVALID, "image size %dx%d differs from the context's %dx%d (the reference re-runs initGL here; create a new context instead)",
@@ -1238,12 +1460,25 @@ int rtuf_filter(rtuf_context* c, const unsigned char* buffer, const double* proj
   return rtuf_filter_batch(c, 1, &in, &mo, &mk);
 }
 
-const float* rtuf_get_masked_depth(const rtuf_context* c) { return (c && !c->single_masked.empty()) ? c->single_masked.data() : nullptr; }
-const uint8_t* rtuf_get_mask(const rtuf_context* c) { return (c && !c->single_mask.empty()) ? c->single_mask.data() : nullptr; }
+const float* rtuf_get_masked_depth(const rtuf_context* c) { if (c && !c->kids.empty()) c = c->kids[0]; return (c && !c->single_masked.empty()) ? c->single_masked.data() : nullptr; }
+const uint8_t* rtuf_get_mask(const rtuf_context* c) { if (c && !c->kids.empty()) c = c->kids[0]; return (c && !c->single_mask.empty()) ? c->single_mask.data() : nullptr; }
 
 int rtuf_get_stats(rtuf_context* c, rtuf_stats* out)
 {
   if (!c || !out) return RTUF_ERR_INVALID;
+  if (!c->kids.empty()) {
+    // counters and last-batch times of the pipeline that ran last; event sums and regrowths over all pipelines
+    *out = c->kids[c->last_kid]->stats;
+    out->bin_capacity = c->kids[c->last_kid]->capacity;
+    out->regrowths = 0; out->timed_batches = 0;
+    out->sum_ms_pose = out->sum_ms_setup = out->sum_ms_raster = out->sum_ms_compare = out->sum_ms_total = 0;
+    for (const rtuf_context* k : c->kids) {
+      out->regrowths += k->stats.regrowths; out->timed_batches += k->stats.timed_batches;
+      out->sum_ms_pose += k->stats.sum_ms_pose; out->sum_ms_setup += k->stats.sum_ms_setup; out->sum_ms_raster += k->stats.sum_ms_raster;
+      out->sum_ms_compare += k->stats.sum_ms_compare; out->sum_ms_total += k->stats.sum_ms_total;
+    }
+    return RTUF_OK;
+  }
   *out = c->stats;
   out->bin_capacity = c->capacity;
   return RTUF_OK;
@@ -1251,6 +1486,7 @@ int rtuf_get_stats(rtuf_context* c, rtuf_stats* out)
 
 int rtuf_enable_timing(rtuf_context* c, int on)
 {
+  KIDS_ALL(c, rtuf_enable_timing(k, on));
   if (!c) return RTUF_ERR_INVALID;
   c->timing = on < 0 ? 0 : (on > 3 ? 1 : on);
   c->timing_seq = 0;
@@ -1261,6 +1497,7 @@ int rtuf_enable_timing(rtuf_context* c, int on)
 
 int rtuf_debug_read_zsurface(rtuf_context* c, int n, float* host_out)
 {
+  KIDS_ONE(c, c->last_kid, rtuf_debug_read_zsurface(k, n, host_out));
   if (!c || !host_out) return RTUF_ERR_INVALID;
   if (!(c->params.flags & RTUF_FLAG_TWO_KERNEL) || !c->d_zsurface) return c->fail(RTUF_ERR_STATE, "z-surface exists only in two-kernel mode");
   if (n <= 0 || n > c->group) return c->fail(RTUF_ERR_INVALID, "z-surface holds the last in-flight group (%d streams)", c->group);

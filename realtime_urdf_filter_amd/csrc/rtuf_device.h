@@ -144,7 +144,8 @@ struct alignas(128) CounterShard {
   unsigned int clip_overflow;
   unsigned int max_fbin_fill;
   unsigned long long frags;
-  unsigned int pad[22];
+  unsigned int uncovered;       // mask-bits output only: some pixel was reached by no fragment (see rtuf_filter_batch_bits*)
+  unsigned int pad[21];
 };
 static_assert(sizeof(CounterShard) == 128, "CounterShard must be one 128-byte line");
 struct alignas(128) WorkCount { unsigned int n_items; unsigned int pad[31]; };
@@ -235,6 +236,7 @@ struct TileArgs {
   const float* depth;            // [n][H][W]   (f32 metres) or, with io_u16, uint16 millimetres
   float* masked;                 // [n][H][W]   same element type as depth
   uint8_t* mask;                 // [n][H][W] or nullptr
+  uint32_t* bits;                // mask-only output: [n][H][ceil(W/32)] words, pixel x = bit x % 32 of word x / 32; masked / mask unused
   float* zsurface;               // [G][H][W]  (two-kernel mode)
   const BgInfo* bg;              // [n]
   Counters* counters;

@@ -1684,7 +1684,7 @@ __device__ __forceinline__ float shade(float sensor, float z, const ShadeConsts&
   return filt ? k.replace_value : sensor;
 }
 
-template <bool TWO_KERNEL, bool U16>
+template <bool TWO_KERNEL, bool U16, bool BITS>
 __device__ __forceinline__ void tile_body(const TileArgs& a)
 {
   __shared__ unsigned long long keys[kTileW * kTileH];
@@ -1775,7 +1775,10 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
 
   // resolve: kLanesPerRow lanes x 4 pixels per tile row, kRowsPerPass rows per pass.  `finish` turns four
   // window depths (or "nothing drawn") and their compare thresholds into the outputs.
-  auto finish = [&](int ps, const float (&z)[4], const float (&thr)[4], const bool (&frag)[4]) {
+  // With BITS the only output is one mask bit per pixel: `finish` returns the lane's four mask flags (bit j = pixel j)
+  // and stores nothing; the caller packs the flags of 8 neighbouring lanes into one 32-bit word.
+  bool uncovered = false;                              // BITS: a pixel no fragment reached (its masked depth would be the clear colour, not the sensor value)
+  auto finish = [&](int ps, const float (&z)[4], const float (&thr)[4], const bool (&frag)[4]) -> uint32_t {
     const int r_ly = r_ly0 + ps * kRowsPerPass, py = y_base + r_ly, px = r_px;
     const size_t gofs = (size_t)stream * ((size_t)a.height * a.width) + (uint32_t)(__mul24(py, a.width) + px);
     const int nvalid = min(4, a.width - px);
@@ -1787,7 +1790,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       for (int j = 0; j < 4; j++) zz[j] = frag[j] ? z[j] : __uint_as_float(0x7fc00000u);
       if (vec) *reinterpret_cast<float4*>(a.zsurface + zofs) = make_float4(zz[0], zz[1], zz[2], zz[3]);
       else for (int j = 0; j < nvalid; j++) a.zsurface[zofs + j] = zz[j];
-      return;
+      return 0u;
     }
     float s[4];
     if (vec) {
@@ -1802,9 +1805,10 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
     for (int j = 0; j < 4; j++) {
       bool f = s[j] > thr[j];
       o[j] = f ? sc.replace_value : s[j];
-      if (!frag[j]) { o[j] = 0.0f; f = false; }     // GL clear colour
-      if (f) mbits |= 0xffu << (8 * j);
+      if (!frag[j]) { o[j] = 0.0f; f = false; if (BITS) uncovered = true; }     // GL clear colour
+      if (f) mbits |= (BITS ? 1u : 0xffu) << ((BITS ? 1 : 8) * j);
     }
+    if (BITS) return mbits;
     if (vec) {
       if (U16) {
         store_stream4(reinterpret_cast<uint16_t*>(a.masked) + gofs, metres_to_u16(o[0]), metres_to_u16(o[1]), metres_to_u16(o[2]), metres_to_u16(o[3]));
@@ -1819,6 +1823,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
         if (a.mask) a.mask[gofs + j] = (uint8_t)(mbits >> (8 * j));
       }
     }
+    return mbits;
   };
   // Most pixels of a frame see only the background plane, whose depth is one value per stream: its compare
   // threshold (one IEEE division) is computed once per lane.  Same operations on the same values as per pixel.
@@ -1827,35 +1832,55 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
 #pragma unroll
   for (int ps = 0; ps < kPasses; ps++) {
     const int r_ly = r_ly0 + ps * kRowsPerPass;
-    if (!(r_ly < kTileH && y_base + r_ly < a.height && r_px < a.width)) continue;
-    if (empty) {                                   // tile without geometry: a streaming compare against the plane
-      finish(ps, bg_z4, bg_thr4, bg_frag4);
-      continue;
-    }
-    float z[4], thr[4];
-    bool frag[4];
+    const bool valid = r_ly < kTileH && y_base + r_ly < a.height && r_px < a.width;
+    uint32_t flags4 = 0;
+    if (valid) {
+      if (empty) {                                   // tile without geometry: a streaming compare against the plane
+        flags4 = finish(ps, bg_z4, bg_thr4, bg_frag4);
+      } else {
+        float z[4], thr[4];
+        bool frag[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const unsigned long long k = keys[r_ly * kTileW + r_lx + j];
-      frag[j] = true;
-      thr[j] = thr_bg;
-      if (k == bgkey) { z[j] = bgz; frag[j] = analytic_bg; }
-      else {                                        // the per-pixel division only runs where something was drawn
-        z[j] = (k & kResolvedBit) ? __uint_as_float((uint32_t)k) : __fmul_rn((float)((uint32_t)(k >> 32) + 1u), 5.9604644775390625e-08f);
-        if (!TWO_KERNEL) thr[j] = shade_threshold(z[j], sc);
+        for (int j = 0; j < 4; j++) {
+          const unsigned long long k = keys[r_ly * kTileW + r_lx + j];
+          frag[j] = true;
+          thr[j] = thr_bg;
+          if (k == bgkey) { z[j] = bgz; frag[j] = analytic_bg; }
+          else {                                        // the per-pixel division only runs where something was drawn
+            z[j] = (k & kResolvedBit) ? __uint_as_float((uint32_t)k) : __fmul_rn((float)((uint32_t)(k >> 32) + 1u), 5.9604644775390625e-08f);
+            if (!TWO_KERNEL) thr[j] = shade_threshold(z[j], sc);
+          }
+        }
+        flags4 = finish(ps, z, thr, frag);
       }
     }
-    finish(ps, z, thr, frag);
+    if (BITS) {
+      // 8 neighbouring lanes hold the 32 pixels of one output word (pixel x -> bit x % 32 of word x / 32 of its row):
+      // OR their nibbles together (all lanes take part, invalid ones with 0) and let the group's first lane store
+      uint32_t word = flags4 << (4 * (tid & 7));
+      word |= (uint32_t)__shfl_xor((int)word, 1);
+      word |= (uint32_t)__shfl_xor((int)word, 2);
+      word |= (uint32_t)__shfl_xor((int)word, 4);
+      if (valid && (tid & 7) == 0) {
+        const int row_words = (a.width + 31) >> 5;
+        const size_t wofs = ((size_t)stream * a.height + (size_t)(y_base + r_ly)) * (size_t)row_words + (size_t)(r_px >> 5);
+        __builtin_nontemporal_store(word, a.bits + wofs);
+      }
+    }
   }
+  if (BITS && __syncthreads_or(uncovered) && tid == 0) a.counters->shard[bin % kCounterShards].uncovered = 1u;
 }
 
 // (fused variants: held at 6 waves/SIMD = 80 VGPRs; left alone the compiler takes 84 = 5 waves/SIMD)
 template <bool TWO_KERNEL, bool U16>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6))) void tile_kernel(TileArgs a) { tile_body<TWO_KERNEL, U16>(a); }
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6))) void tile_kernel(TileArgs a) { tile_body<TWO_KERNEL, U16, false>(a); }
+// mask-only output, one bit per pixel (rtuf_filter_batch_bits*): 4 (2) B/pixel in, 1/8 B/pixel out
+template <bool U16>
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6))) void tile_bits_kernel(TileArgs a) { tile_body<false, U16, true>(a); }
 // two-kernel mode writes the z-surface instead of resolving the compare: one register over 64 VGPRs without
 // the hint, i.e. 7 instead of 8 waves/SIMD (+10 % kernel time)
 template <>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(8))) void tile_kernel<true, false>(TileArgs a) { tile_body<true, false>(a); }
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(8))) void tile_kernel<true, false>(TileArgs a) { tile_body<true, false, false>(a); }
 
 // ---------------------------------------------------------------------------------------
 // compare_kernel (two-kernel mode): streaming, 13 B/pixel (4 sensor + 4 z + 4 masked + 1 mask)
@@ -1979,7 +2004,10 @@ void launch_clip(const SetupArgs& a, hipStream_t st)
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st)
 {
   const dim3 grid(a.tiles_x, a.tiles_y, a.group_size);
-  if (two_kernel) hipLaunchKernelGGL((tile_kernel<true, false>), grid, dim3(kTileThreads), 0, st, a);
+  if (a.bits) {
+    if (a.io_u16) hipLaunchKernelGGL((tile_bits_kernel<true>), grid, dim3(kTileThreads), 0, st, a);
+    else hipLaunchKernelGGL((tile_bits_kernel<false>), grid, dim3(kTileThreads), 0, st, a);
+  } else if (two_kernel) hipLaunchKernelGGL((tile_kernel<true, false>), grid, dim3(kTileThreads), 0, st, a);
   else if (a.io_u16) hipLaunchKernelGGL((tile_kernel<false, true>), grid, dim3(kTileThreads), 0, st, a);
   else hipLaunchKernelGGL((tile_kernel<false, false>), grid, dim3(kTileThreads), 0, st, a);
 }

@@ -149,7 +149,9 @@ class URDFRenderer:
                 t = tf.lookup_transform(self.fixed_frame_, r.name, timestamp)
             except Exception as e:                  # noqa: BLE001 - ROS_DEBUG
                 log.debug("%s", e)
-            r.link_to_fixed = Transform(t.basis, t.origin)
+            # tf::Transform(t.getRotation(), t.getOrigin()) (src/urdf_renderer.cpp:187): the rotation goes through a
+            # quaternion and back, in double -- kept, because the last bits of the matrix decide float32 roundings
+            r.link_to_fixed = Transform.from_quaternion(t.get_rotation(), t.origin)
 
     def link_matrices(self):
         return np.stack([r.gl_matrix() for r in self.renderables_]) if self.renderables_ else np.zeros((0, 16))

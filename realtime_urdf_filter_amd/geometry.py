@@ -238,3 +238,36 @@ def write_binary_stl(verts, tris, header=b"binary stl"):
     ln = np.linalg.norm(nn, axis=1, keepdims=True)
     rec["n"] = np.where(ln > 0, nn / np.maximum(ln, 1e-30), 0)
     return header.ljust(80, b"\0")[:80] + struct.pack("<I", n) + rec.tobytes()
+
+
+class PackageResolver:
+    """mesh_loader for URDFRenderer / RealtimeURDFFilter: resolves the mesh URIs a URDF carries --
+    `package://<pkg>/<path>` against a list of package search roots (ROS_PACKAGE_PATH semantics: a root either IS the
+    package directory `<pkg>` or contains it), `file://<path>` and plain paths -- and loads the file.  Replaces the
+    resource_retriever + Assimp pair of the reference (src/renderable.cpp:306-322).  STL only (binary, incl. the
+    "solid" header quirk, and ASCII): Collada / OBJ visual meshes are not supported and raise."""
+
+    def __init__(self, search_paths=None):
+        import os
+        paths = list(search_paths) if search_paths is not None else [p for p in os.environ.get("ROS_PACKAGE_PATH", "").split(":") if p]
+        self.search_paths = paths
+
+    def path_of(self, uri):
+        import os
+        if uri.startswith("package://"):
+            pkg, _, rel = uri[len("package://"):].partition("/")
+            for root in self.search_paths:
+                for cand in (os.path.join(root, pkg, rel), os.path.join(root, rel) if os.path.basename(os.path.normpath(root)) == pkg else None):
+                    if cand and os.path.isfile(cand):
+                        return cand
+            raise IOError("package %r of %r not found under %r" % (pkg, uri, self.search_paths))
+        if uri.startswith("file://"):
+            return uri[len("file://"):]
+        return uri
+
+    def __call__(self, uri):
+        path = self.path_of(uri)
+        if not path.lower().endswith(".stl"):
+            raise IOError("mesh %r: only STL meshes are supported (the reference imports anything Assimp reads)" % uri)
+        with open(path, "rb") as f:
+            return load_stl(f.read())

@@ -188,8 +188,13 @@ class Model:
             lim = je.find("limit")
             lower = float(lim.get("lower", 0.0)) if lim is not None else 0.0
             upper = float(lim.get("upper", 0.0)) if lim is not None else 0.0
+            mim = je.find("mimic")
+            mimic = None
+            if mim is not None and mim.get("joint"):
+                # <mimic joint="other" multiplier="m" offset="o">: position = m * position(other) + o  (urdfdom defaults 1, 0)
+                mimic = (mim.get("joint"), float(mim.get("multiplier", 1.0)), float(mim.get("offset", 0.0)))
             j = Joint(je.get("name"), je.get("type"), je.find("parent").get("link"), je.find("child").get("link"),
-                      xyz, rpy, axis, lower, upper)
+                      xyz, rpy, axis, lower, upper, mimic)
             m.joints[j.name] = j
         return m
 
@@ -203,6 +208,31 @@ class Model:
         if len(roots) != 1:
             raise ValueError("URDF must have exactly one root link, found %r" % roots)
         return roots[0]
+
+
+def resolve_mimic(model, joint_positions):
+    """{joint: position} with every <mimic> joint filled in from the joint it follows (multiplier * position + offset;
+    chains are followed, a cycle raises).  This is what joint_state_publisher does before robot_state_publisher turns
+    joint states into the TF frames the reference looks up (src/urdf_renderer.cpp:173-190): the PR2's gripper fingers
+    are mimic joints.  Positions given explicitly for a mimic joint are kept."""
+    q = dict(joint_positions or {})
+
+    def value(name, seen):
+        if name in q:
+            return float(q[name])
+        j = model.joints.get(name)
+        if j is None or j.mimic is None:
+            return 0.0
+        if name in seen:
+            raise ValueError("mimic cycle through joint %r" % name)
+        src, mult, off = j.mimic
+        q[name] = mult * value(src, seen | {name}) + off
+        return q[name]
+
+    for name, j in model.joints.items():
+        if j.mimic is not None:
+            value(name, frozenset())
+    return q
 
 
 def joint_motion(joint, q):
@@ -223,7 +253,7 @@ def forward_kinematics(model, joint_positions=None, root_transform=None):
     """{link name: Transform root<-link}.  The 'fixed frame' of the reference is whatever TF frame
     the caller names; with the root link as fixed frame this replaces the per-link lookupTransform
     calls of URDFRenderer::update_link_transforms."""
-    q = joint_positions or {}
+    q = resolve_mimic(model, joint_positions)
     by_parent = {}
     for j in model.joints.values():
         by_parent.setdefault(j.parent, []).append(j)
@@ -264,7 +294,8 @@ def kinematic_arrays(model, link_names, link_offsets):
     link_names: for every renderable (in upload order) the URDF link it is attached to;
     link_offsets: their Renderable.link_offset transforms.
     Returns dict(parent, joint_type, joint_origin [F,16], joint_axis [F,3], link_frame, link_offset [L,16],
-    frame_index {link name: index}, joint_of_frame [joint name or None per frame])."""
+    frame_index {link name: index}, joint_of_frame [joint name or None per frame], mimic {joint: (source joint,
+    multiplier, offset)} for joint_vector)."""
     by_parent = {}
     for j in model.joints.values():
         by_parent.setdefault(j.parent, []).append(j)
@@ -289,9 +320,26 @@ def kinematic_arrays(model, link_names, link_offsets):
             "joint_origin": np.stack(origin), "joint_axis": np.asarray(axis, np.float64),
             "link_frame": np.asarray([index[n] for n in link_names], np.int32),
             "link_offset": np.stack([t.opengl_matrix() for t in link_offsets]) if link_offsets else np.zeros((0, 16)),
-            "frame_index": index, "joint_of_frame": jname}
+            "frame_index": index, "joint_of_frame": jname,
+            "mimic": {j.name: j.mimic for j in model.joints.values() if j.mimic is not None}}
 
 
 def joint_vector(kin, joint_positions):
-    """q vector (one entry per frame) from a {joint name: position} dict."""
-    return np.asarray([float(joint_positions.get(j, 0.0)) if j else 0.0 for j in kin["joint_of_frame"]], np.float64)
+    """q vector for rtuf_set_joint_positions (one entry per frame) from a {joint name: position} dict.  <mimic> joints
+    are resolved here, on the host (multiplier * source + offset, chains followed): the device's forward kinematics
+    takes one position per frame and needs no notion of mimicry."""
+    q = dict(joint_positions)
+    mimic = kin.get("mimic", {})
+
+    def value(name, depth=0):
+        if name in q:
+            return float(q[name])
+        if name not in mimic:
+            return 0.0
+        if depth > len(mimic):
+            raise ValueError("mimic cycle through joint %r" % name)
+        src, mult, off = mimic[name]
+        q[name] = mult * value(src, depth + 1) + off
+        return q[name]
+
+    return np.asarray([value(j) if j else 0.0 for j in kin["joint_of_frame"]], np.float64)

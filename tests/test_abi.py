@@ -95,3 +95,29 @@ print(len(libs), libs)
         out = subprocess.run([sys.executable, "-c", code, order], cwd=root, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         assert out.stdout.split()[0] == "1", (order, out.stdout)
+
+
+def test_expand_mask_bits_host_helper():
+    """rtuf_expand_mask_bits (no GPU): select(bit, replace, sensor) for 32FC1; for 16UC1 the reference's two
+    convertTo roundings, i.e. exactly what filter.py's host conversions give."""
+    import numpy as np
+    from realtime_urdf_filter_amd.filter import depth_f32_to_u16, depth_u16_to_f32
+    rng = np.random.default_rng(1)
+    for W, H in ((64, 5), (100, 7), (33, 3)):
+        rw = (W + 31) // 32
+        flags = rng.random((H, W)) < 0.4
+        packed = np.zeros((H, rw * 32), np.uint8)
+        packed[:, :W] = flags
+        bits = np.packbits(packed, axis=1, bitorder="little").view(np.uint32).reshape(-1)
+        assert bits.size == R.load_library().rtuf_mask_bits_words(W, H)
+        d = rng.uniform(0.3, 9.0, (H, W)).astype(np.float32)
+        d[0, 0], d[0, 1], d[1, 0] = np.nan, np.inf, 0.0
+        masked, mask = R.expand_mask_bits(d, bits, 5.0)
+        assert np.array_equal(mask, np.where(flags, 255, 0).astype(np.uint8))
+        assert np.array_equal(masked.view(np.uint32), np.where(flags, np.float32(5.0), d).view(np.uint32))
+        u = rng.integers(0, 65536, (H, W)).astype(np.uint16)
+        masked16, mask16 = R.expand_mask_bits(u, bits, 5.0)
+        expect = depth_f32_to_u16(np.where(flags, np.float32(5.0), depth_u16_to_f32(u)))
+        assert np.array_equal(masked16, expect) and np.array_equal(mask16, mask)
+        only_mask = R.expand_mask_bits(d, bits, 5.0, want_masked=False)
+        assert only_mask[0] is None and np.array_equal(only_mask[1], mask)

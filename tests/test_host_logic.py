@@ -204,3 +204,77 @@ def test_kinematic_arrays_reproduce_forward_kinematics():
         T[i] = T[p] @ O4 @ M
     for name, idx in kin["frame_index"].items():
         assert np.allclose(T[idx][:3, :3], fk[name].basis, atol=1e-12) and np.allclose(T[idx][:3, 3], fk[name].origin, atol=1e-12)
+
+
+def test_mimic_joints_follow_their_source_on_host_and_in_the_device_vector():
+    """<mimic joint multiplier offset> (the PR2's gripper fingers): resolved on the host, for the host FK and for the
+    joint vector handed to the GPU's forward kinematics; chains are followed, explicit positions win, cycles raise."""
+    xml = """<robot name="g"><link name="palm"/><link name="f1"/><link name="f2"/><link name="tip"/>
+      <joint name="drive" type="revolute"><origin xyz="0 0.1 0"/><parent link="palm"/><child link="f1"/><axis xyz="0 0 1"/></joint>
+      <joint name="follow" type="revolute"><origin xyz="0 -0.1 0"/><parent link="palm"/><child link="f2"/><axis xyz="0 0 1"/>
+        <mimic joint="drive" multiplier="-1" offset="0.25"/></joint>
+      <joint name="tipj" type="prismatic"><origin xyz="0.1 0 0"/><parent link="f2"/><child link="tip"/><axis xyz="1 0 0"/>
+        <mimic joint="follow" multiplier="2"/></joint></robot>"""
+    m = urdf.Model.from_string(xml)
+    assert m.joints["follow"].mimic == ("drive", -1.0, 0.25) and m.joints["tipj"].mimic == ("follow", 2.0, 0.0)
+    q = urdf.resolve_mimic(m, {"drive": 0.4})
+    assert abs(q["follow"] - (-0.15)) < 1e-15 and abs(q["tipj"] - (-0.3)) < 1e-15
+    fk = urdf.forward_kinematics(m, {"drive": 0.4})
+    fk_explicit = urdf.forward_kinematics(m, {"drive": 0.4, "follow": q["follow"], "tipj": q["tipj"]})
+    for name in fk:
+        assert np.array_equal(fk[name].basis, fk_explicit[name].basis) and np.array_equal(fk[name].origin, fk_explicit[name].origin)
+    assert not np.allclose(fk["f2"].basis, np.eye(3))                       # the follower really moved
+    kin = urdf.kinematic_arrays(m, sorted(m.links), [urdf.Transform() for _ in m.links])
+    qv = urdf.joint_vector(kin, {"drive": 0.4})
+    by_joint = dict(zip(kin["joint_of_frame"], qv))
+    assert by_joint["drive"] == 0.4 and by_joint["follow"] == q["follow"] and by_joint["tipj"] == q["tipj"]
+    assert dict(zip(kin["joint_of_frame"], urdf.joint_vector(kin, {"drive": 0.4, "follow": 1.0})))["tipj"] == 2.0     # explicit wins
+    cyc = urdf.Model.from_string(xml.replace('<axis xyz="0 0 1"/></joint>\n      <joint name="follow"', '<axis xyz="0 0 1"/><mimic joint="tipj"/></joint>\n      <joint name="follow"'))
+    with pytest.raises(ValueError):
+        urdf.resolve_mimic(cyc, {})
+
+
+def test_package_resolver_finds_stl_meshes(tmp_path):
+    from realtime_urdf_filter_amd import geometry as G
+    pkg = tmp_path / "ws" / "my_robot_description"
+    (pkg / "meshes").mkdir(parents=True)
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    t = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    (pkg / "meshes" / "part.stl").write_bytes(G.write_binary_stl(v, t, header=b"solid looks like ascii"))
+    (pkg / "meshes" / "part.dae").write_text("<COLLADA/>")
+    for roots in ([str(tmp_path / "ws")], [str(pkg)]):               # root contains the package / root is the package
+        r = G.PackageResolver(roots)
+        vv, tt = r("package://my_robot_description/meshes/part.stl")
+        assert vv.shape == (6, 3) and tt.shape == (2, 3)
+    vv, tt = G.PackageResolver([])("file://" + str(pkg / "meshes" / "part.stl"))
+    assert tt.shape == (2, 3)
+    with pytest.raises(IOError):
+        G.PackageResolver([str(tmp_path / "ws")])("package://other_pkg/meshes/part.stl")
+    with pytest.raises(IOError):
+        G.PackageResolver([str(tmp_path / "ws")])("package://my_robot_description/meshes/part.dae")     # Collada: unsupported
+
+
+def test_cpp_host_forward_kinematics_with_mimic_joints_matches_python(tmp_path):
+    """The C++ twin (include/realtime_urdf_filter_amd/host.hpp) resolves <mimic> joints like the Python mirror."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "bin", "example_filter")
+    subprocess.check_call([os.path.join(root, "realtime_urdf_filter_amd", "csrc", "build_facade.sh")])
+    xml = """<robot name="g"><link name="palm"/><link name="f1"/><link name="f2"/><link name="tip"/>
+      <joint name="drive" type="revolute"><origin xyz="0 0.1 0" rpy="0.1 0.2 0.3"/><parent link="palm"/><child link="f1"/><axis xyz="0 0 1"/></joint>
+      <joint name="follow" type="revolute"><origin xyz="0 -0.1 0"/><parent link="palm"/><child link="f2"/><axis xyz="0 1 1"/>
+        <mimic joint="drive" multiplier="-1" offset="0.25"/></joint>
+      <joint name="tipj" type="prismatic"><origin xyz="0.1 0 0"/><parent link="f2"/><child link="tip"/><axis xyz="1 0 0"/>
+        <mimic joint="follow" multiplier="2"/></joint></robot>"""
+    f = tmp_path / "g.urdf"
+    f.write_text(xml)
+    out = subprocess.check_output([exe, "--fk", str(f), "drive=0.4"]).decode().strip().splitlines()
+    fk = urdf.forward_kinematics(urdf.Model.from_string(xml), {"drive": 0.4})
+    assert len(out) == 4
+    for line in out:
+        parts = line.split()
+        t = fk[parts[0]]
+        v = np.array([float(x) for x in parts[1:]])
+        assert np.allclose(v[:9].reshape(3, 3), t.basis, atol=1e-15) and np.allclose(v[9:], t.origin, atol=1e-15), parts[0]
+    assert not np.allclose(fk["tip"].origin, urdf.forward_kinematics(urdf.Model.from_string(xml), {})["tip"].origin)

@@ -900,3 +900,169 @@ def test_fused_16uc1_io(two_kernel):
         assert np.array_equal(out16[s][ok == 0], mm[s][ok == 0])          # unfiltered pixels round-trip exactly
         assert (out16[s][ok > 0] == 5000).all()
     ctx.close()
+
+
+def unpack_bits(bits, W, H):
+    """[words] uint32 -> [H, W] bool (pixel x = bit x % 32 of word y * ceil(W/32) + x / 32)."""
+    rw = (W + 31) // 32
+    b = np.unpackbits(np.ascontiguousarray(bits, np.uint32).reshape(H, rw).view(np.uint8), axis=1, bitorder="little")
+    return b[:, :W].astype(bool)
+
+
+@pytest.mark.parametrize("size", [(640, 480), (324, 100), (1280, 720)])
+def test_mask_bits_output_equals_full_planes(size):
+    """rtuf_filter_batch_bits*: 1 bit per pixel instead of masked depth + byte mask.  The bits must be the byte mask
+    of the full-plane call, rtuf_expand_mask_bits must rebuild both full planes bit for bit (32FC1 and 16UC1), for
+    host planes (asynchronous, two batches in flight) and device planes; widths that are not a multiple of 32 / 64
+    (partial words, partial tiles) included."""
+    import torch
+    W, H = size
+    n = 5
+    wl = WL.pr2_workload(n, W, H, total_triangles=12000, first_state_seed=77, walls=(W == 1280))
+    ctx = R.Context(W, H, n, 0, params(wl.replace_value, wl.max_diff))
+    ids = wl.load_into(ctx)
+    wl.stage(ctx, ids)
+    depth = wl.depth_batch()
+    masked, mask = ctx.filter_batch(depth)
+    words = ctx.mask_bits_words()
+    assert words == H * ((W + 31) // 32)
+    # host planes, two batches in flight
+    pin_in = ctx.host_alloc((n, H, W), np.float32)
+    pin_bits = [ctx.host_alloc((n, words), np.uint32) for _ in range(2)]
+    pin_in[...] = depth
+    for b in pin_bits:
+        b[...] = 0xdeadbeef
+        ctx.filter_batch_bits_async(pin_in, b)
+    ctx.sync()
+    assert np.array_equal(pin_bits[0], pin_bits[1])
+    for s in range(n):
+        assert np.array_equal(unpack_bits(pin_bits[0][s], W, H), mask[s] > 0), s
+        m2, k2 = R.expand_mask_bits(depth[s], pin_bits[0][s], wl.replace_value)
+        assert bits_equal(m2, masked[s]) and np.array_equal(k2, mask[s])
+    # device planes
+    dev = torch.device("cuda:0")
+    d_depth = torch.from_numpy(depth).to(dev)
+    d_bits = torch.zeros((n, words), dtype=torch.int32, device=dev)
+    ctx.filter_batch_device_bits(n, d_depth.data_ptr(), d_bits.data_ptr())
+    ctx.sync()
+    assert np.array_equal(d_bits.cpu().numpy().view(np.uint32), pin_bits[0])
+    # 16UC1 in
+    mm = depth_f32_to_u16(np.nan_to_num(depth, nan=0.0, posinf=0.0))
+    masked16, mask16 = ctx.filter_batch_u16(mm)
+    u_in = ctx.host_alloc((n, H, W), np.uint16)
+    u_in[...] = mm
+    ctx.filter_batch_bits_async(u_in, pin_bits[1])
+    ctx.sync()
+    for s in range(n):
+        assert np.array_equal(unpack_bits(pin_bits[1][s], W, H), mask16[s] > 0), s
+        m2, k2 = R.expand_mask_bits(mm[s], pin_bits[1][s], wl.replace_value)
+        assert np.array_equal(m2, masked16[s]) and np.array_equal(k2, mask16[s])
+    # errors: two-kernel mode has no bits output
+    p2 = params(wl.replace_value, wl.max_diff, two_kernel=True)
+    ctx.set_params(p2)
+    with pytest.raises(R.RtufError):
+        ctx.filter_batch_bits_async(pin_in, pin_bits[0])
+    ctx.close()
+
+
+def test_mask_bits_refused_when_the_background_quad_does_not_cover_the_image():
+    """With a projection whose background quad leaves pixels uncovered the reference's masked depth there is the GL
+    clear colour, not the sensor value: the mask bits would not expand to the reference's result, so retiring such
+    a batch fails loudly (the full-plane call handles the case)."""
+    W, H = 320, 240
+    P = S.projection(262.5, 262.5, 159.5, 119.5, W, H)
+    P[12] = 160.0          # x translation in clip space: the +-100 m quad no longer covers the left part of the image
+    ctx = R.Context(W, H, 1, 0, params())
+    m = ctx.add_model()
+    l = ctx.add_link(m)
+    ctx.add_draw(m, l, np.array([[0, 0, 0], [0.1, 0, 0], [0, 0.1, 0]], np.float32), np.array([[0, 1, 2]], np.uint32))
+    ctx.finalize_models()
+    T = np.eye(4)
+    T[2, 3] = 2.0
+    ctx.set_camera(0, P, None, None)
+    ctx.set_link_poses(0, m, S.gl(T)[None])
+    depth = S.sensor_depth(W, H, 0.5)[None]
+    masked, mask = ctx.filter_batch(depth)
+    om, ok = O.filter_frame(depth[0], P, [(S.gl(T), 0, (0, 0, 0), np.array([[0, 0, 0], [0.1, 0, 0], [0, 0.1, 0]], np.float32), np.array([[0, 1, 2]], np.uint32))], replace_value=5.0)
+    assert (ok != mask[0]).sum() == 0 and bits_equal(om, masked[0])
+    uncovered = (masked[0] == 0) & (depth[0] != 0) & (mask[0] == 0)
+    assert uncovered.any()                    # the scene really has clear-colour pixels
+    bits = np.zeros((1, ctx.mask_bits_words()), np.uint32)
+    ctx.filter_batch_bits_async(np.ascontiguousarray(depth), bits)
+    with pytest.raises(R.RtufError) as e:
+        ctx.sync()
+    assert "background quad" in str(e.value)
+    masked2, mask2 = ctx.filter_batch(depth)          # the context stays usable
+    assert bits_equal(masked2, masked[0][None])
+    ctx.close()
+
+
+@pytest.mark.parametrize("pipes", [2, 3])
+def test_pipelines_inside_one_context(pipes):
+    """rtuf_params.pipelines: one context, several internal raster pipelines; batches alternate between them and up to
+    2 x pipelines are in flight.  Every batch (new joint state + sensor planes each) must be the oracle's result,
+    through device planes and through asynchronous host planes; setters reach all pipelines; wait_oldest retires in
+    submission order; the single-stream rtuf_filter() and the stats work on the front context."""
+    import torch
+    n, W, H = 4, 320, 240
+    wls = [WL.pr2_workload(n, W, H, total_triangles=8000, first_state_seed=seed) for seed in (1000, 2000, 3000)]
+    A = wls[0]
+    p = params(A.replace_value, A.max_diff, pipelines=pipes)
+    ctx = R.Context(W, H, n, 0, p)
+    ids = A.load_into(ctx)
+    A.load_kinematics(ctx, ids)
+    assert ctx.num_triangles() == A.n_triangles()
+    steps = 2 * pipes + 3
+    depths = [A.depth_batch(first=5 * k) for k in range(steps)]
+    dev = torch.device("cuda:0")
+    d_in = [torch.from_numpy(d).to(dev) for d in depths]
+    outs = [(torch.empty((n, H, W), dtype=torch.float32, device=dev), torch.empty((n, H, W), dtype=torch.uint8, device=dev)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    ctx.enable_timing(2)
+    for k in range(steps):                     # nothing waits in between: up to 2 x pipes batches in flight
+        wls[k % 3].stage_joint_positions(ctx, ids, first_call=(k == 0))
+        ctx.filter_batch_device(n, d_in[k].data_ptr(), outs[k][0].data_ptr(), outs[k][1].data_ptr())
+    ctx.sync()
+
+    def oracle(wl, depth, s):
+        return O.filter_frame(depth[s], wl.projection[s], wl.oracle_draws(s), wl.offset_inv[s], wl.cam_tf[s],
+                              max_diff=wl.max_diff, replace_value=wl.replace_value)
+    for k in range(steps):
+        for s in (0, n - 1):
+            om, ok = oracle(wls[k % 3], depths[k], s)
+            assert np.array_equal(ok, outs[k][1][s].cpu().numpy()) and bits_equal(om, outs[k][0][s].cpu().numpy()), (k, s)
+    st = ctx.stats()
+    assert st["timed_batches"] == steps and st["sum_ms_raster"] > 0 and st["triangles_submitted"] == A.n_triangles() * n
+    # asynchronous host planes, retired one by one in submission order
+    pin_in = [ctx.host_alloc((n, H, W), np.float32) for _ in range(pipes + 1)]
+    pin_out = [ctx.host_alloc((n, H, W), np.float32) for _ in range(pipes + 1)]
+    pin_mask = [ctx.host_alloc((n, H, W), np.uint8) for _ in range(pipes + 1)]
+    for i in range(pipes + 1):
+        pin_in[i][...] = depths[i]
+        pin_out[i][...] = -1.0
+        wls[(i + 1) % 3].stage_joint_positions(ctx, ids, first_call=False)
+        ctx.filter_batch_async(pin_in[i], pin_out[i], pin_mask[i])
+    for i in range(pipes + 1):
+        ctx.wait_oldest()
+        om, ok = oracle(wls[(i + 1) % 3], depths[i], 1)
+        assert np.array_equal(ok, pin_mask[i][1]) and bits_equal(om, pin_out[i][1]), i      # complete as soon as it is retired
+    ctx.wait_oldest()                          # nothing pending: no-op
+    # a setter reaches every pipeline: new threshold, then one batch per pipeline
+    p2 = params(A.replace_value, 0.2, pipelines=pipes)
+    ctx.set_params(p2)
+    wls[0].stage_joint_positions(ctx, ids, first_call=False)
+    for k in range(pipes):
+        ctx.filter_batch_device(n, d_in[0].data_ptr(), outs[k][0].data_ptr(), outs[k][1].data_ptr())
+    ctx.sync()
+    om, ok = O.filter_frame(depths[0][2], A.projection[2], A.oracle_draws(2), A.offset_inv[2], A.cam_tf[2], max_diff=0.2, replace_value=A.replace_value)
+    for k in range(pipes):
+        assert np.array_equal(ok, outs[k][1][2].cpu().numpy()) and bits_equal(om, outs[k][0][2].cpu().numpy()), k
+    # single-stream shape on the front context (host poses: forward kinematics switched off for stream 0)
+    ctx.set_camera(0, None, None, A.cam_tf[0])
+    ctx.set_link_poses(0, ids[0], A.link_tf[0][0])
+    md, mk = ctx.filter(depths[1][0], A.projection[0])
+    om, ok = O.filter_frame(depths[1][0], A.projection[0], A.oracle_draws(0), A.offset_inv[0], A.cam_tf[0], max_diff=0.2, replace_value=A.replace_value)
+    assert np.array_equal(ok, mk) and bits_equal(om, md)
+    ctx.close()
+    with pytest.raises(R.RtufError):
+        R.Context(W, H, n, 0, params(pipelines=9))
