@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--triangles", type=int, default=250000, help="triangle budget of the PR2-like model")
     ap.add_argument("--variants", type=int, default=2, help="distinct input batches rotated through the steps")
     ap.add_argument("--pipelines", type=int, default=1, help="contexts (HIP stream + bins each) per GPU that the batches alternate between: with 2 or 3, one batch's small and low-occupancy kernels overlap another's heavy ones, but kernels then share the GPU and per-launch times (roofline) no longer describe one kernel; default 1")
+    ap.add_argument("--overlap-pipelines", type=int, default=2, help="after the main measurement (one pipeline, clean per-kernel roofline) time the same steps once more on a second context with rtuf_params.pipelines = this, reported as `overlapped` (N=1 only; 0 disables)")
     ap.add_argument("--two-kernel", action="store_true", help="rasteriser + separate compare kernel")
     ap.add_argument("--host-poses", action="store_true", help="stage explicit link matrices from the host instead of joint positions + on-device forward kinematics")
     ap.add_argument("--u16", action="store_true", help="16UC1 depth in/out (uint16 millimetres) with the conversions fused into the kernels")
@@ -179,11 +180,12 @@ def main():
     torch.cuda.synchronize()
     # how often the --steps steps are repeated so that the timed region is at least --min-seconds long: from the
     # time of a few pipelined steps after the warm-up (agreed between the ranks: the slowest decides)
-    probe = max(2, min(args.steps, 8))
     stage_into(k0)
     t_p = time.perf_counter()
-    for k in range(k0, k0 + probe):
-        enqueue(k)
+    probe = 0
+    while probe < 8 or (time.perf_counter() - t_p < 0.05 and probe < 4096):
+        enqueue(k0 + probe)
+        probe += 1
     for c in ctxs:
         c.sync()
     est_step = (time.perf_counter() - t_p) / probe
@@ -211,8 +213,9 @@ def main():
     elapsed = time.perf_counter() - t0
     sts = [c.stats() for c in ctxs]
     timed = sum(st["timed_batches"] for st in sts)
-    assert timed >= 1 and timed >= timed_steps // 4, ([st["timed_batches"] for st in sts], timed_steps)
-    setup_ms = sum(st["sum_ms_setup"] for st in sts) / timed
+    assert timed >= 1 and timed >= timed_steps // 8, ([st["timed_batches"] for st in sts], timed_steps)
+    setup_ms = sum(st["sum_ms_setup"] for st in sts) / timed          # set-up kernel alone
+    clip_ms = sum(st["sum_ms_clip"] for st in sts) / timed
     raster_ms = sum(st["sum_ms_raster"] for st in sts) / timed
     compare_ms = sum(st["sum_ms_compare"] for st in sts) / timed
     # stage-by-stage breakdown: a few extra steps on one pipeline, one batch in flight, every stage bracketed
@@ -228,7 +231,15 @@ def main():
         for key in acc:
             acc[key] += st[key]
     breakdown = {key: v / extra for key, v in acc.items()}
-    k_last = k_after + extra - 1
+    # ... and the raster stage's kernels one by one under the same conditions (timing mode 2)
+    ctx.enable_timing(2)
+    iso = {"ms_setup": 0.0, "ms_clip": 0.0, "ms_raster": 0.0, "ms_compare": 0.0}
+    for j in range(extra):
+        isolated_step(k_after + extra + j)
+        st = ctx.stats()
+        for key in iso:
+            iso[key] += st[key] / extra
+    k_last = k_after + 2 * extra - 1
     groups_per_batch = 1
     frames_rank = n * timed_steps
     if dist is not None:
@@ -295,12 +306,13 @@ def main():
         mask_b = 0 if args.no_mask else 1
         kernels = {}
         if two:
-            kernels["tile_kernel<two_kernel>"] = (raster_ms, per["ms_raster"], 4 * px * n)
-            kernels["compare_kernel"] = (compare_ms, per["ms_compare"], ((6 if args.u16 else 12) + mask_b) * px * n)
+            kernels["tile_kernel<two_kernel>"] = (raster_ms, iso["ms_raster"], 4 * px * n, "valu-issue / LDS atomics (rasteriser: neither HBM nor MFMA, SURVEY.md 8d); HBM figure for context")
+            kernels["compare_kernel"] = (compare_ms, iso["ms_compare"], ((6 if args.u16 else 12) + mask_b) * px * n, "hbm")
         else:
-            kernels["tile_kernel<fused>"] = (raster_ms, per["ms_raster"], ((4 if args.u16 else 8) + mask_b) * px * n)
+            kernels["tile_kernel<fused>"] = (raster_ms, iso["ms_raster"], ((4 if args.u16 else 8) + mask_b) * px * n, "hbm")
         geo_bytes = sum(12 * g.variants[0].n_vertices() + 16 * g.variants[0].n_triangles() for g in share.groups)
-        kernels["setup_kernel+clip_kernel"] = (setup_ms, per["ms_setup"], geo_bytes)
+        kernels["setup_kernel"] = (setup_ms, iso["ms_setup"], geo_bytes, "valu-issue (triangle set-up: neither HBM nor MFMA, SURVEY.md 8d); HBM figure for context")
+        kernels["clip_kernel"] = (clip_ms, iso["ms_clip"], 0, "latency / divergent scalar code at LDS-limited occupancy; no algorithmic HBM traffic of its own")
         peak = 8000.0
         # Off-line counter data of this same command (rocprofv3 --pmc passes cannot run inside the timed region):
         # used only when the committed measurement is of this exact workload, and labelled as such.
@@ -317,9 +329,9 @@ def main():
             valu_peak = None
 
         def kernel_entry(name):
-            dur_ms, iso_ms, alg_bytes = kernels[name]
+            dur_ms, iso_ms, alg_bytes, bound = kernels[name]
             achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
-            e = {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+            e = {"kernel": name, "bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                  "traffic": None, "avg_launch_ms": dur_ms, "algorithmic_bytes_per_launch": alg_bytes,
                  "isolated": {"avg_launch_ms": iso_ms, "frac": (alg_bytes / (iso_ms * 1e-3) / 1e9 / peak) if iso_ms > 0 else None,
                               "note": "same kernel(s) with nothing else on the GPU (extra steps after the timed region)"}}
@@ -332,17 +344,26 @@ def main():
                     g = cnt / (dur_ms * 1e-3) / 1e9
                     vi = {"wave64_instructions_per_launch": cnt, "instructions_source": e["traffic_source"], "achieved_G_per_s": g}
                     if valu_peak:
-                        pk = valu_peak.get("mix_peak_G_per_s", {}).get(name) or valu_peak.get("peak_G_per_s")
+                        # two measured reference rates: the 4-cycle instruction class (most integer / compare / convert
+                        # instructions: a lower bound of the mix's peak) and the kernel's own STATIC instruction mix
+                        # (scripts/valu_mix.py: harmonic mean over the disassembly's VALU opcodes; an estimate, the
+                        # dynamic mix is not observable: SQ_ACTIVE_INST_VALU does not separate the classes)
+                        pk = valu_peak.get("peak_G_per_s")
                         if pk:
-                            vi.update({"peak_G_per_s": pk, "frac": g / pk, "peak_source": "OFFLINE: profiles/valu_peak.json (scripts/valu_peak.hip micro-benchmark on this GPU model: measured wave64 issue rate of the kernel's instruction mix)"})
+                            vi.update({"peak_G_per_s": pk, "frac": g / pk, "peak_source": "OFFLINE: profiles/valu_peak.json (scripts/valu_peak.hip on this GPU model: measured issue rate of the 4-cycle instruction class; the 2-cycle class runs at %.0f G/s)" % valu_peak.get("fast_class_G_per_s", 0)})
+                        mp = (valu_peak.get("static_mix_peak_G_per_s") or {}).get(name)
+                        if mp:
+                            vi.update({"static_mix_peak_G_per_s": mp, "frac_of_static_mix_peak": g / mp})
                     e["valu_issue"] = vi
             return e
 
         entries = [kernel_entry(k) for k in kernels]
         dom = max(entries, key=lambda e: e["avg_launch_ms"])       # the dominant kernel: longest average launch, no exclusions
+        if dom["bound"] != "hbm":
+            dom = dict(dom, bound_note=dom["bound"], bound="hbm")   # (the contract's vocabulary; the note says what really limits it)
         roof = dict(dom)
         roof.update({"launches_per_step": groups_per_batch, "timed_launches": timed,
-                     "all_kernels": [e for e in entries if e is not dom]})
+                     "all_kernels": [e for e in entries if e["kernel"] != dom["kernel"]]})
         out = {
             "metric": "filtered depth frames/sec (640x480, PR2 URDF)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -355,7 +376,7 @@ def main():
                        "parallelism": ("stream-sharded x%d" % world) + (" (shares of a %d-GPU job)" % job_world if args.shard_of else ""), "pipelines_per_gpu": P,
                        "host_threads_pinned_to_gpu_numa_node": pinned_cpus},
             "per_stream_fps": value / max(sum(x["streams"] for x in per_rank), 1),
-            "kernel_ms_per_step": dict(per, note="stage breakdown from %d extra steps after the timed region: one pipeline, one batch in flight, every stage bracketed by HIP events (ms_setup there = cull + set-up + clip + waiting for the pose stage); roofline.avg_launch_ms is measured inside the timed region" % extra),
+            "kernel_ms_per_step": dict(per, note="stage breakdown from %d extra steps after the timed region: one batch in flight, every stage bracketed by HIP events (ms_setup there = cull + set-up + clip + waiting for the pose stage); roofline.avg_launch_ms is measured inside the timed region" % extra),
             "rasteriser": {"triangles_per_s": float(share.triangles_per_stream().sum()) / (setup_ms * 1e-3) if setup_ms > 0 else None,
                            "binned_triangles_per_s": st["triangles_binned"] / (raster_ms * 1e-3) if raster_ms > 0 else None,
                            "triangles_submitted": int(share.triangles_per_stream().sum()), "triangles_binned": st["triangles_binned"],
@@ -367,6 +388,56 @@ def main():
         }
         if fk_err is not None:
             out["fk"] = {"on_device": True, "max_abs_diff_vs_host_fk": fk_err}
+        # ---- the same steps with the library's internal pipelines overlapping (rtuf_params.pipelines) ----------
+        if world == 1 and P == 1 and args.overlap_pipelines > 1 and not args.debug_flags:
+            PO = args.overlap_pipelines
+            p2 = R.default_params()
+            p2.filter_replace_value, p2.depth_distance_threshold, p2.flags, p2.pipelines = p.filter_replace_value, p.depth_distance_threshold, p.flags, PO
+            ctx.sync()
+            ctx2 = R.Context(W, H, n, local_rank, p2)
+            share2 = CF.build(args.workload, job_world, rank, streams=args.streams, triangles=args.triangles, variants=args.variants,
+                              width=args.width, height=args.height, urdfs=args.urdfs)
+            share2.load(ctx2, on_device_fk=not args.host_poses)
+            sets2 = [(torch.empty_like(d_masked_set[0]), None if args.no_mask else torch.empty_like(d_mask_set[0])) for _ in range(2 * PO)]
+
+            def submit2(k):
+                m, kk = sets2[k % len(sets2)]
+                (ctx2.filter_batch_device_u16 if args.u16 else ctx2.filter_batch_device)(n, dptr[k % V], m.data_ptr(), kk.data_ptr() if kk is not None else 0)
+
+            for k in range(max(args.warmup, 2) * PO):
+                share2.stage(ctx2, k)
+                submit2(k)
+                ctx2.sync()
+            kb = args.warmup * PO + ((-args.warmup * PO) % V)
+            share2.stage(ctx2, kb)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for k in range(kb, kb + timed_steps):
+                submit2(k)
+                share2.stage(ctx2, k + 1)
+            ctx2.sync()
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t2
+            # parity of its last batch (same checker)
+            k2_last = kb + timed_steps - 1
+            m2, kk2 = sets2[k2_last % len(sets2)]
+            l2, c2 = (None, None) if args.host_poses else ctx2.read_poses(n, share2.n_links_total)
+            bad2 = 0
+            for s_ in check[:2]:
+                hd2 = d_depth[k2_last % V][s_].cpu().numpy()
+                hm2 = m2[s_].cpu().numpy()
+                if args.u16:
+                    hm2 = hm2.view(np.uint16)
+                    hd2 = depth_u16_to_f32(hd2.view(np.uint16))
+                proj, draws, off, cam = share2.oracle_frame(k2_last, s_, l2, c2)
+                om, ok = O.filter_frame(hd2, proj, draws, off, cam, max_diff=wl0.max_diff, replace_value=wl0.replace_value)
+                if kk2 is not None:
+                    bad2 += int((ok != kk2[s_].cpu().numpy()).sum())
+                bad2 += int((depth_f32_to_u16(om) != hm2).sum()) if args.u16 else int((om.view(np.uint32) != hm2.view(np.uint32)).sum())
+            out["overlapped"] = {"pipelines": PO, "value": n * timed_steps / el2, "unit": "frames/s", "ms_per_step": el2 / timed_steps * 1e3,
+                                 "timed_steps": timed_steps, "frames_checked": len(check[:2]), "mismatching_values": bad2,
+                                 "note": "same workload and step count on a context with rtuf_params.pipelines = %d: batches alternate between %d internal pipelines, so kernels of different batches share the GPU (higher throughput; per-launch kernel times, and with them a per-kernel roofline, no longer describe one kernel -- hence not the headline)" % (PO, PO)}
+            ctx2.close()
         # ---- CPU baseline: the oracle port on this box's host cores, on a bounded sample of the same batch ----
         if world == 1 and args.cpu_seconds > 0 and n > 0:
             cores = len(os.sched_getaffinity(0))
@@ -383,12 +454,9 @@ def main():
                 prepared[n1 % n_in].run()
                 n1 += 1
             t1 = time.perf_counter() - c0
-            # all cores: POSIX threads inside the oracle library (a shared counter hands out frames; no Python in the
-            # loop), sized from the single-thread rate for about --cpu-seconds of wall time if the cores scaled perfectly
-            repeat = max(1, int(np.ceil(n1 / t1 * args.cpu_seconds * cores / n_in)))
-            c0 = time.perf_counter()
-            nN = O.filter_throughput(prepared, repeat, cores)
-            tN = time.perf_counter() - c0
+            # all cores: POSIX threads inside the oracle library for --cpu-seconds (a shared counter hands out frames; no
+            # Python in the loop; per-thread scratch memory)
+            nN, tN = O.filter_throughput(prepared, args.cpu_seconds, cores)
             cb = {"value": n1 / t1, "unit": "frames/s", "cores": 1, "kind": "port",
                   "sample": "%d frames of the last batch (first %d streams, cycled) through oracle/rtuf_oracle.c, single thread, %.1f s" % (n1, n_in, t1),
                   "all_cores": {"value": nN / tN, "unit": "frames/s", "cores": cores,
@@ -398,6 +466,23 @@ def main():
                 cb["reference_llvmpipe"] = dict(lp.get("bench_workload", {}), source="OFFLINE: profiles/llvmpipe_baseline.json -- the reference's own GLSL on Mesa llvmpipe, timed in the development container (scripts/llvmpipe_baseline.py): the harness reads the reference's shaders from /root/reference at run time, which does not exist on the GPU box")
             except Exception:
                 pass
+            # the reference's CPU path itself, live on this box: its GL call sequence on Mesa llvmpipe through the test
+            # harness (oracle/_ref), with the repo-authored stand-in shaders (the reference's files do not exist here;
+            # the stand-ins are checked bit-for-bit against them in the development container)
+            try:
+                from oracle.ref_gl import harness as HN
+                if args.cpu_seconds >= 2 and HN.available("standin"):
+                    import subprocess
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "llvmpipe_baseline.py"), "--bench-leg", "--shaders", "standin",
+                                        "--seconds", str(min(args.cpu_seconds, 6.0)), "--frames", "8"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+                    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                    if r.returncode == 0 and line:
+                        cb["reference_llvmpipe_live"] = dict(json.loads(line[-1]), unit="frames/s",
+                                                             note="the reference's per-frame GL sequence (upload, render from static VBOs, two read-backs) on Mesa llvmpipe on THIS box, one stream per frame of the bench model; stand-in shaders = bit-identical re-statement of include/shaders/urdf_filter.{vert,frag} (tests/test_oracle_vs_llvmpipe.py)")
+                    else:
+                        cb["reference_llvmpipe_live"] = {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:      # noqa: BLE001 - a missing Mesa must not cost the bench line
+                cb["reference_llvmpipe_live"] = {"error": repr(e)}
             out["cpu_baseline"] = cb
         print(json.dumps(out))
     for c in ctxs:

@@ -270,15 +270,17 @@ typedef struct {
   uint32_t max_fbin_fill;           /* largest fragment bin of the last batch          */
   uint64_t fragments_binned;        /* covered pixels of small (<= 4x4 px box) triangles binned as fragments */
   float ms_pose, ms_setup, ms_raster, ms_compare, ms_total;   /* last timed batch       */
-  uint32_t reserved0;
+  float ms_clip;                    /* clip kernel alone (timing modes 2 / 3; in mode 1 it is part of ms_setup) */
   uint64_t timed_batches;           /* batches retired since rtuf_enable_timing, and the sums  */
   double sum_ms_pose, sum_ms_setup, sum_ms_raster, sum_ms_compare, sum_ms_total;   /* of their times */
+  double sum_ms_clip;
 } rtuf_stats;
 int rtuf_get_stats(rtuf_context *ctx, rtuf_stats *out);
 /* Per-kernel HIP-event timing (off by default: every event costs a few microseconds of stream
- * time).  on = 1: every stage (ms_pose, ms_setup, ms_raster, ms_compare, ms_total);  on = 2: only the raster
- * stage's big kernels: ms_setup (set-up + clip kernels), ms_raster (tile kernel), ms_compare (two-kernel mode);
- * on = 3: as 2, but only every fourth batch is timed (timed_batches and the sums count those). */
+ * time).  on = 1: every stage (ms_pose, ms_setup = cull .. clip, ms_raster, ms_compare, ms_total);  on = 2: the
+ * raster stage's kernels one by one: ms_setup (set-up kernel), ms_clip (clip kernel), ms_raster (tile kernel),
+ * ms_compare (two-kernel mode);  on = 3: as 2, but only every eighth batch is timed (timed_batches and the sums
+ * count those). */
 int rtuf_enable_timing(rtuf_context *ctx, int on);
 
 /* Debug / test access: copy the z-surface of the last batch (float window z of the winning

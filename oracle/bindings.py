@@ -51,7 +51,7 @@ def lib():
             build()
         _lib = ctypes.CDLL(_SO)
         _lib.rtuf_oracle_filter.argtypes = [ctypes.POINTER(Frame), ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Debug)]
-        _lib.rtuf_oracle_filter_throughput.argtypes = [ctypes.POINTER(Frame), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        _lib.rtuf_oracle_filter_throughput.argtypes = [ctypes.POINTER(Frame), ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         _lib.rtuf_oracle_filter_throughput.restype = ctypes.c_long
         _lib.rtuf_oracle_compose_mvp.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     return _lib
@@ -116,14 +116,15 @@ class PreparedFrame:
         return self.masked, self.mask
 
 
-def filter_throughput(prepared, repeat, n_threads):
-    """Runs the prepared frames `repeat` times on n_threads POSIX threads inside the C library (no Python in the
-    loop); returns the number of frames filtered.  bench.py's cpu_baseline.all_cores leg."""
+def filter_throughput(prepared, seconds, n_threads):
+    """Filters the prepared frames cyclically for `seconds` on n_threads POSIX threads inside the C library (no Python
+    in the loop); returns (frames filtered, elapsed seconds).  bench.py's cpu_baseline.all_cores leg."""
     arr = (Frame * len(prepared))(*[p.fr for p in prepared])
-    n = lib().rtuf_oracle_filter_throughput(arr, len(prepared), int(repeat), int(n_threads))
+    el = ctypes.c_double(0.0)
+    n = lib().rtuf_oracle_filter_throughput(arr, len(prepared), float(seconds), int(n_threads), ctypes.byref(el))
     if n < 0:
         raise RuntimeError("oracle throughput run failed: %d" % n)
-    return int(n)
+    return int(n), float(el.value)
 
 
 def filter_frame(depth, projection, draws, camera_offset_inv=None, camera_tf=None, z_near=0.1, z_far=8.0,

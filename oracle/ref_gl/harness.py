@@ -1,8 +1,13 @@
-"""ctypes wrapper of oracle/_ref/libllvmpipe_oracle.so (development container only).
+"""ctypes wrapper of oracle/_ref/libllvmpipe_oracle.so.
 
-Runs the reference's GLSL (read at run time from /root/reference/include/shaders) on Mesa
-llvmpipe with the reference's GL call sequence; used by tests/golden/generate_golden.py and by
-tests/test_oracle_vs_llvmpipe.py.  TEST INFRASTRUCTURE, never imported by the product package.
+Runs GLSL on Mesa llvmpipe with the reference's GL call sequence.  Two shader sets:
+  "reference"  the reference's own files, read at run time from /root/reference/include/shaders (development
+               container only): what tests/golden/generate_golden.py and tests/test_oracle_vs_llvmpipe.py use --
+               the definition of "the reference's result" in this project;
+  "standin"    oracle/ref_gl/standin_shaders/: a repo-authored re-statement of the same two tiny programs, checked
+               bit-for-bit against the reference set in the development container; it exists only so that the
+               timing leg of bench.py can run llvmpipe on the GPU box, where /root/reference does not exist.
+TEST INFRASTRUCTURE, never imported by the product package.
 """
 import ctypes
 import os
@@ -12,18 +17,31 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "..", "_ref", "libllvmpipe_oracle.so")
 SHADER_DIR = "/root/reference/include/shaders"
+STANDIN_DIR = os.path.join(_HERE, "standin_shaders")
+SWRAST = os.environ.get("RGO_SWRAST_DRI", "/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so")
 
 GL_TRIANGLES, GL_TRIANGLE_STRIP, GL_TRIANGLE_FAN, GL_QUADS, GL_QUAD_STRIP = 4, 5, 6, 7, 8
 
 
-def available():
-    return os.path.exists(_SO) and os.path.exists(os.path.join(SHADER_DIR, "urdf_filter.frag"))
+def available(shaders="reference"):
+    if not (os.path.exists(_SO) and os.path.exists(SWRAST)):
+        return False
+    if shaders == "standin":
+        return os.path.exists(os.path.join(STANDIN_DIR, "standin.frag"))
+    return os.path.exists(os.path.join(SHADER_DIR, "urdf_filter.frag"))
+
+
+def shader_paths(shaders="reference"):
+    if shaders == "standin":
+        return os.path.join(STANDIN_DIR, "standin.vert"), os.path.join(STANDIN_DIR, "standin.frag")
+    return os.path.join(SHADER_DIR, "urdf_filter.vert"), os.path.join(SHADER_DIR, "urdf_filter.frag")
 
 
 class Harness:
-    def __init__(self, width, height):
-        if not available():
-            raise RuntimeError("llvmpipe harness unavailable (needs oracle/_ref and /root/reference)")
+    def __init__(self, width, height, shaders="reference"):
+        if not available(shaders):
+            raise RuntimeError("llvmpipe harness unavailable (needs oracle/_ref, Mesa's swrast_dri.so and -- for the reference shader set -- /root/reference)")
+        self.shaders = shaders
         L = ctypes.CDLL(_SO)
         vp = ctypes.c_void_p
         L.rgo_last_error.restype = ctypes.c_char_p
@@ -36,11 +54,27 @@ class Harness:
         L.rgo_translate.argtypes = [ctypes.c_float] * 3
         L.rgo_draw_immediate_d.argtypes = [ctypes.c_int, vp, ctypes.c_int]
         L.rgo_now.restype = ctypes.c_double
-        rc = L.rgo_create(width, height, os.path.join(SHADER_DIR, "urdf_filter.vert").encode(),
-                          os.path.join(SHADER_DIR, "urdf_filter.frag").encode())
+        vs, fs = shader_paths(shaders)
+        rc = L.rgo_create(width, height, vs.encode(), fs.encode())
         if rc != 0:
             raise RuntimeError("rgo_create failed: %s" % L.rgo_last_error().decode())
         self.L, self.width, self.height = L, width, height
+
+    def use_shaders(self, shaders):
+        """Re-links the program of the live context from the other shader set (the GL context is per process)."""
+        vs, fs = shader_paths(shaders)
+        self.L.rgo_set_program_source.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        rc = self.L.rgo_set_program_source(open(vs, "rb").read(), open(fs, "rb").read())
+        if rc != 0:
+            raise RuntimeError("linking the %s shaders failed: %s" % (shaders, self.L.rgo_last_error().decode()))
+        self.shaders = shaders
+
+    def read_attachment(self, i):
+        """RGBA32F contents of colour attachment i of the last frame (0 sensor, 1 masked depth, 2 normals, 3 mask)."""
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self.L.rgo_read_attachment.argtypes = [ctypes.c_int, ctypes.c_void_p]
+        self.L.rgo_read_attachment(i, out.ctypes.data_as(ctypes.c_void_p))
+        return out
 
     def renderer(self):
         return self.L.rgo_renderer_string().decode()

@@ -390,6 +390,24 @@ static void clip_and_setup(frame *f, const vtx *t0, const vtx *t1, const vtx *t2
   for (int i = 2; i < n; i++) setup_tri(f, inlist[i - 1], inlist[i], inlist[0]);
 }
 
+/* Scratch memory of one frame (depth buffer, transformed vertices).  Normally malloc/free per call; the worker
+ * threads of rtuf_oracle_filter_throughput switch their thread to two grow-only buffers instead: hundreds of
+ * threads each mapping and unmapping megabytes per frame serialise on the process's address-space lock. */
+static __thread int tl_arena_on;
+static __thread void *tl_buf[2];
+static __thread size_t tl_cap[2];
+static void *scratch_get(int slot, size_t bytes)
+{
+  if (!tl_arena_on) return malloc(bytes);
+  if (tl_cap[slot] < bytes) {
+    free(tl_buf[slot]);
+    tl_buf[slot] = malloc(bytes);
+    tl_cap[slot] = tl_buf[slot] ? bytes : 0;
+  }
+  return tl_buf[slot];
+}
+static void scratch_put(void *p) { if (!tl_arena_on) free(p); }
+
 /* ------------------------------------------------------------------ */
 /* Public entry                                                       */
 /* ------------------------------------------------------------------ */
@@ -404,7 +422,7 @@ int rtuf_oracle_filter(const rtuf_oracle_frame *in, float *masked_depth, uint8_t
   f.z_near = in->z_near; f.z_far = in->z_far;
   f.max_diff = in->max_diff; f.replace_value = in->replace_value;
   f.masked = masked_depth; f.mask = mask;
-  f.z24 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)w * h);
+  f.z24 = (uint32_t *)scratch_get(0, sizeof(uint32_t) * (size_t)w * h);
   if (!f.z24) return -2;
   for (size_t i = 0; i < (size_t)w * h; i++) f.z24[i] = 0xffffffu;   /* glClear depth = 1.0 */
   /* glClear colour: (0,0,0,1); every pixel is overwritten by the background
@@ -458,8 +476,8 @@ int rtuf_oracle_filter(const rtuf_oracle_frame *in, float *masked_depth, uint8_t
     if (dr->pre_op == RTUF_ORACLE_OP_SCALE) mat_scale(m, dr->op[0], dr->op[1], dr->op[2]);
     else if (dr->pre_op == RTUF_ORACLE_OP_TRANSLATE) mat_translate(m, dr->op[0], dr->op[1], dr->op[2]);
     matmul4(mvp, proj, m);
-    vtx *tv = (vtx *)malloc(sizeof(vtx) * (size_t)(dr->nverts > 0 ? dr->nverts : 1));
-    if (!tv) { free(f.z24); return -2; }
+    vtx *tv = (vtx *)scratch_get(1, sizeof(vtx) * (size_t)(dr->nverts > 0 ? dr->nverts : 1));
+    if (!tv) { scratch_put(f.z24); return -2; }
     for (int i = 0; i < dr->nverts; i++) {
       vs_position(mvp, dr->verts + 3 * (size_t)i, tv[i].clip);
       tv[i].mask = clipmask_of(tv[i].clip);
@@ -471,10 +489,10 @@ int rtuf_oracle_filter(const rtuf_oracle_frame *in, float *masked_depth, uint8_t
       clip_and_setup(&f, &tv[ix[0]], &tv[ix[1]], &tv[ix[2]], scale, trans);
     }
     prim_base += dr->ntris;
-    free(tv);
+    scratch_put(tv);
   }
   if (dbg) { dbg->n_tris_in = f.n_tris_in; dbg->n_tris_setup = f.n_tris_setup; dbg->n_frags = f.n_frags; }
-  free(f.z24);
+  scratch_put(f.z24);
   return 0;
 }
 
@@ -501,11 +519,19 @@ void rtuf_oracle_compose_mvp(const double *projection, const double *camera_offs
 /* ------------------------------------------------------------------ */
 #include <pthread.h>
 #include <stdatomic.h>
+#include <time.h>
+
+static double tp_now(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 typedef struct {
   const rtuf_oracle_frame *frames;
   int n_frames;
-  long total;
+  double deadline;
   atomic_long *next;
   atomic_long *done;
   atomic_int *failed;
@@ -517,9 +543,9 @@ static void *tp_worker(void *arg)
   float *masked = NULL;
   uint8_t *mask = NULL;
   size_t cap = 0;
-  for (;;) {
+  tl_arena_on = 1;
+  while (tp_now() < j->deadline) {
     const long i = atomic_fetch_add(j->next, 1);
-    if (i >= j->total) break;
     const rtuf_oracle_frame *fr = &j->frames[i % j->n_frames];
     const size_t px = (size_t)fr->width * (size_t)fr->height;
     if (px > cap) {
@@ -533,15 +559,19 @@ static void *tp_worker(void *arg)
     atomic_fetch_add(j->done, 1);
   }
   free(masked); free(mask);
+  free(tl_buf[0]); free(tl_buf[1]);
+  tl_buf[0] = tl_buf[1] = NULL; tl_cap[0] = tl_cap[1] = 0;
+  tl_arena_on = 0;
   return NULL;
 }
 
-long rtuf_oracle_filter_throughput(const rtuf_oracle_frame *frames, int n_frames, int repeat, int n_threads)
+long rtuf_oracle_filter_throughput(const rtuf_oracle_frame *frames, int n_frames, double seconds, int n_threads, double *elapsed_out)
 {
-  if (!frames || n_frames <= 0 || repeat <= 0 || n_threads <= 0) return -1;
+  if (!frames || n_frames <= 0 || !(seconds > 0) || n_threads <= 0) return -1;
   atomic_long next = 0, done = 0;
   atomic_int failed = 0;
-  tp_job job = { frames, n_frames, (long)n_frames * repeat, &next, &done, &failed };
+  const double t0 = tp_now();
+  tp_job job = { frames, n_frames, t0 + seconds, &next, &done, &failed };
   pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
   if (!th) return -2;
   int started = 0;
@@ -551,6 +581,7 @@ long rtuf_oracle_filter_throughput(const rtuf_oracle_frame *frames, int n_frames
   }
   for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
   free(th);
+  if (elapsed_out) *elapsed_out = tp_now() - t0;
   if (started == 0 || atomic_load(&failed)) return -3;
   return atomic_load(&done);
 }

@@ -65,10 +65,12 @@ void rtuf_oracle_get_variants(rtuf_oracle_variants *v);
 int rtuf_oracle_filter(const rtuf_oracle_frame *in, float *masked_depth, uint8_t *mask,
                        rtuf_oracle_debug *dbg);
 
-/* Throughput leg of bench.py's cpu_baseline ("all cores"): runs the frames [0, n_frames) `repeat` times on n_threads
- * POSIX threads (a shared atomic counter hands out frames; every thread writes into private scratch planes, the
- * results are discarded).  Returns the number of frames filtered, or < 0 on failure. */
-long rtuf_oracle_filter_throughput(const rtuf_oracle_frame *frames, int n_frames, int repeat, int n_threads);
+/* Throughput leg of bench.py's cpu_baseline ("all cores"): n_threads POSIX threads filter the frames [0, n_frames)
+ * cyclically for `seconds` (a shared atomic counter hands out frames; every thread writes into private scratch
+ * planes, the results are discarded).  Returns the number of frames filtered (< 0 on failure); *elapsed_out gets the
+ * wall time including the last frames in flight at the deadline. */
+long rtuf_oracle_filter_throughput(const rtuf_oracle_frame *frames, int n_frames, double seconds, int n_threads,
+                                   double *elapsed_out);
 
 void rtuf_oracle_compose_mvp(const double *projection, const double *camera_offset_inv,
                              const double *camera_tf, const double *link_tf,

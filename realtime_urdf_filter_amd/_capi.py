@@ -45,9 +45,10 @@ class Stats(ctypes.Structure):
                 ("max_bin_fill", ctypes.c_uint32), ("bin_capacity", ctypes.c_uint32),
                 ("regrowths", ctypes.c_uint32), ("max_fbin_fill", ctypes.c_uint32), ("fragments_binned", ctypes.c_uint64),
                 ("ms_pose", ctypes.c_float), ("ms_setup", ctypes.c_float), ("ms_raster", ctypes.c_float),
-                ("ms_compare", ctypes.c_float), ("ms_total", ctypes.c_float), ("reserved0", ctypes.c_uint32),
+                ("ms_compare", ctypes.c_float), ("ms_total", ctypes.c_float), ("ms_clip", ctypes.c_float),
                 ("timed_batches", ctypes.c_uint64), ("sum_ms_pose", ctypes.c_double), ("sum_ms_setup", ctypes.c_double),
-                ("sum_ms_raster", ctypes.c_double), ("sum_ms_compare", ctypes.c_double), ("sum_ms_total", ctypes.c_double)]
+                ("sum_ms_raster", ctypes.c_double), ("sum_ms_compare", ctypes.c_double), ("sum_ms_total", ctypes.c_double),
+                ("sum_ms_clip", ctypes.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

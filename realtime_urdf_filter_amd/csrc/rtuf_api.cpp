@@ -123,6 +123,11 @@ struct rtuf_context {
     bool dirty_cams = true, dirty_link_tf = true;
     int uploaded_streams = 0;
     hipEvent_t posed = nullptr;              // recorded on the side stream after the pose stage
+    // small batches: captured launch sequences of this slot, keyed by the hash of the argument blocks they were
+    // captured with (a slot meets a few recurring sets: the ring of joint-position buffers, the caller's output sets)
+    static constexpr int kGraphs = 6;
+    struct { uint64_t hash = 0; hipGraphExec_t exec = nullptr; } graphs[kGraphs];
+    int graph_next = 0;
     uint32_t setup_grid = 0xffffffffu;       // work items the set-up launch covered (single-group batches)
     int timing = 0;                          // event timing of this batch: 0 none, 1 every stage, 2 tile/compare kernel only
     // Host-plane batches (rtuf_filter_batch*): device staging of this slot, the caller's planes, and the
@@ -135,6 +140,8 @@ struct rtuf_context {
   };
   Batch batch[kMaxInflight];
   hipStream_t side = nullptr;                // pose stages (see Batch)
+  hipEvent_t fork_ev = nullptr;              // graph capture: forks the side stream off the main stream
+  bool graphs_ok = true;                     // cleared when the runtime refuses stream capture / instantiation
   int oldest = 0;                            // ring index of the oldest batch in flight
   int pending = 0;                           // batches in flight
 
@@ -154,7 +161,7 @@ struct rtuf_context {
   rtuf_stats stats{};
   int timing = 0;            // 0 off, 1 every stage, 2 only around the tile (and compare) kernel, 3 = 2 on every fourth batch
   uint32_t timing_seq = 0;
-  double acc_ms[5] = {0, 0, 0, 0, 0};     // sums of ms_pose .. ms_total over the timed batches
+  double acc_ms[6] = {0, 0, 0, 0, 0, 0};  // sums of ms_pose .. ms_total, ms_clip over the timed batches
   uint64_t acc_batches = 0;
 
   int fail(int code, const char* fmt, ...)
@@ -317,9 +324,11 @@ void rtuf_destroy(rtuf_context* c)
     for (hipEvent_t ev : b.events) hipEventDestroy(ev);
     if (b.done) hipEventDestroy(b.done);
     if (b.posed) hipEventDestroy(b.posed);
+    for (auto& g : b.graphs) if (g.exec) hipGraphExecDestroy(g.exec);
     if (b.uploaded) hipEventDestroy(b.uploaded);
     if (b.downloaded) hipEventDestroy(b.downloaded);
   }
+  if (c->fork_ev) hipEventDestroy(c->fork_ev);
   for (void* p : c->pinned) hipHostFree(p);
   if (c->h2d) hipStreamDestroy(c->h2d);
   if (c->d2h) hipStreamDestroy(c->d2h);
@@ -905,6 +914,63 @@ static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
   return RTUF_OK;
 }
 
+// Everything one batch launches, as plain argument blocks: built first, then either enqueued kernel by kernel or --
+// for small batches, whose cost is the host's launch overhead, not GPU time -- captured once into a hipGraph per
+// batch slot and replayed with one call for as long as the blocks do not change (same buffers, sizes, parameters).
+struct BatchPlan {
+  std::vector<FkArgs> fks;
+  PoseArgs pa{};
+  struct Group { SetupArgs sa{}; TileArgs ta{}; CompareArgs ca{}; bool compare = false; };
+  std::vector<Group> groups;
+  uint64_t hash() const
+  {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](const void* p, size_t n) { const unsigned char* q = static_cast<const unsigned char*>(p); for (size_t i = 0; i < n; i++) { h ^= q[i]; h *= 1099511628211ull; } };
+    for (const FkArgs& f : fks) mix(&f, sizeof f);
+    mix(&pa, sizeof pa);
+    for (const Group& g : groups) { mix(&g.sa, sizeof g.sa); mix(&g.ta, sizeof g.ta); if (g.compare) mix(&g.ca, sizeof g.ca); }
+    return h ^ (uint64_t)fks.size() << 56 ^ (uint64_t)groups.size() << 48;
+  }
+};
+
+static constexpr int kGraphMaxStreams = 32;     // batches up to this size replay a captured hipGraph (timing off)
+
+// Enqueues the kernels of a plan: pose stage (forward kinematics, matrix stacks, cull of the first group) on `sp`,
+// raster stage on `st`, which waits for the pose stage through the batch's `posed` event.
+static int issue_plan(rtuf_context* c, rtuf_context::Batch& b, const BatchPlan& plan, hipStream_t sp, hipStream_t st, uint32_t items_hint, size_t& ev)
+{
+  const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
+  for (const FkArgs& fa : plan.fks) launch_fk(fa, sp);
+  launch_pose(plan.pa, sp);
+  if (b.timing == 1) hipEventRecord(get_event(b, ev++), sp);
+  const bool single_group = plan.groups.size() == 1;
+  for (size_t g = 0; g < plan.groups.size(); g++) {
+    const BatchPlan::Group& gr = plan.groups[g];
+    if (g > 0) launch_reset_clip(b.d_counters, st);          // the clip list is per group
+    // the first group's cull belongs to the pose stage; the raster kernels wait for that stage here
+    launch_cull(gr.sa, g == 0 ? sp : st);
+    if (g == 0) {
+      HIP_TRY(c, hipEventRecord(b.posed, sp));
+      HIP_TRY(c, hipStreamWaitEvent(st, b.posed, 0));
+    }
+    // a batch of one group reads its work-list length back with the counters: instead of sweeping the
+    // part of the list beyond the (estimated) grid with a second launch, it is run again if the estimate
+    // was too small (retire_oldest); batches of several groups reuse the counter, so they sweep
+    if (b.timing >= 2) hipEventRecord(get_event(b, ev++), st);     // (after the wait for the pose stage: set-up time only)
+    const uint32_t grid = launch_setup(gr.sa, items_hint, !single_group, st);
+    b.setup_grid = single_group ? grid : 0xffffffffu;
+    if (b.timing >= 2) hipEventRecord(get_event(b, ev++), st);
+    launch_clip(gr.sa, st);
+    if (b.timing) hipEventRecord(get_event(b, ev++), st);
+    launch_tile(gr.ta, two, st);
+    if (b.timing) hipEventRecord(get_event(b, ev++), st);
+    if (gr.compare) launch_compare(gr.ca, st);
+    if (b.timing == 1 || (b.timing == 2 && gr.compare)) hipEventRecord(get_event(b, ev++), st);
+  }
+  launch_publish_counters(b.d_counters, b.h_counters, st);
+  return RTUF_OK;
+}
+
 static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
 {
   const int n = b.n;
@@ -917,10 +983,13 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
   const size_t plane = (size_t)c->width * c->height;
   size_t ev = 0;
   if (!rerun) {
-    // mode 3 = mode 2 on every fourth batch only (each event costs ~5 us of stream time)
-    b.timing = c->timing == 3 ? ((c->timing_seq++ & 3u) == 0 ? 2 : 0) : c->timing;
+    // mode 3 = mode 2 on every eighth batch only (each event costs ~5 us of stream time)
+    b.timing = c->timing == 3 ? ((c->timing_seq++ & 7u) == 0 ? 2 : 0) : c->timing;
   }
-  hipStream_t sp = c->side;       // the pose stage of this batch: concurrent with the raster kernels of the batch before it
+  const bool use_graph = c->graphs_ok && !b.timing && n <= kGraphMaxStreams && n <= c->group;
+  // the pose stage of this batch runs on the side stream, concurrent with the raster kernels of the batch before it
+  // (graph replay: everything hangs off the main stream, the side stream is forked inside the graph)
+  hipStream_t sp = use_graph ? st : c->side;
   c->last_slot = (int)(&b - &c->batch[0]);
   if (b.timing == 1) hipEventRecord(get_event(b, ev++), sp);
   // only what the host changed since the last batch crosses the bus (with on-device forward
@@ -932,6 +1001,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
   b.dirty_cams = b.dirty_link_tf = c->dirty_mask = false;
   b.uploaded_streams = std::max(b.uploaded_streams, n);
   c->mask_uploaded_streams = std::max(c->mask_uploaded_streams, n);
+  BatchPlan plan;
   // on-device forward kinematics overwrites the link matrices (and camera) of the streams that use it
   for (HostModel& m : c->models) {
     Kinematics& k = m.kin;
@@ -955,15 +1025,17 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     }
     k.dirty_aux = false;
     k.aux_uploaded_streams = std::max(k.aux_uploaded_streams, n);
-    FkArgs fa{};
+    FkArgs fa;
+    memset(&fa, 0, sizeof fa);               // (padding too: the plan is hashed byte-wise)
     fa.parent = k.d_parent; fa.depth = k.d_depth; fa.max_depth = k.max_depth; fa.joint_type = k.d_type; fa.joint_origin = k.d_origin; fa.joint_axis = k.d_axis;
     fa.link_frame = k.d_link_frame; fa.link_offset = k.d_link_offset; fa.q = k.h_q[b.q_idx[mi]]; fa.root_tf = k.d_root;
     fa.enabled = k.d_enabled; fa.link_tf = b.d_link_tf; fa.cams = b.d_cams;
     fa.n_streams = n; fa.n_frames = k.n_frames; fa.n_links_model = (int)m.links.size(); fa.link_base = m.link_base;
     fa.n_links_total = (int)L; fa.camera_frame = k.camera_frame;
-    launch_fk(fa, sp);
+    plan.fks.push_back(fa);
   }
-  PoseArgs pa{};
+  PoseArgs& pa = plan.pa;
+  memset(&pa, 0, sizeof pa);
   pa.cams = b.d_cams; pa.link_tf = b.d_link_tf; pa.draws = c->d_draws; pa.mvp = b.d_mvp;
   // to_linear_depth's constants exactly as the shader evaluates them (include/shaders/urdf_filter.frag:14-17), in float
   const float zn = c->params.near_plane, zf = c->params.far_plane;
@@ -972,13 +1044,12 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
   pa.sc_num = sc_num; pa.sc_off = sc_off; pa.max_diff = c->params.depth_distance_threshold;
   pa.n_streams = n; pa.n_draws = c->n_draws; pa.n_links = (int)L; pa.z_far = c->params.far_plane;
   pa.width = c->width; pa.height = c->height;
-  launch_pose(pa, sp);
-  if (b.timing == 1) hipEventRecord(get_event(b, ev++), sp);
   for (int base = 0; base < n; base += c->group) {
     const int gs = std::min(c->group, n - base);
-    // clip list is per group
-    if (base > 0) launch_reset_clip(b.d_counters, st);
-    SetupArgs sa{};
+    plan.groups.emplace_back();
+    BatchPlan::Group& gr = plan.groups.back();
+    memset(&gr.sa, 0, sizeof gr.sa); memset(&gr.ta, 0, sizeof gr.ta); memset(&gr.ca, 0, sizeof gr.ca);
+    SetupArgs& sa = gr.sa;
     sa.cverts = c->d_cverts; sa.ctris = c->d_ctris; sa.corder = c->d_corder; sa.chunks = c->d_chunks; sa.mvp = b.d_mvp;
     sa.model_mask = c->d_model_mask; sa.bg = b.d_bg; sa.bins = c->d_bins; sa.bin_count = c->d_bin_count;
     sa.fbins = c->d_fbins; sa.fbin_count = c->d_fbin_count; sa.fcapacity = c->fcapacity;
@@ -986,21 +1057,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     sa.n_draws = c->n_draws; sa.width = c->width; sa.height = c->height; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
     sa.capacity = c->capacity; sa.clip_capacity = c->clip_capacity; sa.bg_chunk = c->bg_chunk;
     sa.items = b.d_items; sa.n_chunks = c->n_chunks; sa.flags = c->params.flags;
-    // the first group's cull belongs to the pose stage; the raster kernels wait for that stage here
-    launch_cull(sa, base == 0 ? sp : st);
-    if (base == 0) {
-      HIP_TRY(c, hipEventRecord(b.posed, sp));
-      HIP_TRY(c, hipStreamWaitEvent(st, b.posed, 0));
-    }
-    // a batch of one group reads its work-list length back with the counters: instead of sweeping the
-    // part of the list beyond the (estimated) grid with a second launch, it is run again if the estimate
-    // was too small (retire_oldest); batches of several groups reuse the counter, so they sweep
-    const bool single_group = n <= c->group;
-    if (b.timing >= 2) hipEventRecord(get_event(b, ev++), st);     // (after the wait for the pose stage: set-up + clip time only)
-    const uint32_t grid = launch_setup(sa, c->items_hint, !single_group, st);
-    b.setup_grid = single_group ? grid : 0xffffffffu;
-    launch_clip(sa, st);
-    TileArgs ta{};
+    TileArgs& ta = gr.ta;
     ta.bins = c->d_bins; ta.bin_count = c->d_bin_count;
     ta.fbins = c->d_fbins; ta.fbin_count = c->d_fbin_count; ta.fcapacity = c->fcapacity; ta.depth = d_depth; ta.masked = d_masked; ta.mask = d_mask;
     ta.zsurface = c->d_zsurface; ta.bg = b.d_bg; ta.counters = b.d_counters;
@@ -1011,22 +1068,61 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     ta.sc_num = sc_num; ta.sc_off = sc_off;
     ta.io_u16 = io_u16 ? 1 : 0;
     ta.bits = b.bits;
-    if (b.timing) hipEventRecord(get_event(b, ev++), st);
-    launch_tile(ta, two, st);
-    if (b.timing) hipEventRecord(get_event(b, ev++), st);
-    if (two && !b.bits) {
-      CompareArgs ca{};
+    gr.compare = two && !b.bits;
+    if (gr.compare) {
+      CompareArgs& ca = gr.ca;
       ca.depth = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_depth) + (size_t)base * plane * esz); ca.zsurface = c->d_zsurface;
       ca.masked = reinterpret_cast<float*>(reinterpret_cast<char*>(d_masked) + (size_t)base * plane * esz);
       ca.io_u16 = io_u16 ? 1 : 0; ca.mask = d_mask ? d_mask + (size_t)base * plane : nullptr;
       ca.n_pixels = (size_t)gs * plane;
       ca.z_near = ta.z_near; ca.z_far = ta.z_far; ca.max_diff = ta.max_diff; ca.replace_value = ta.replace_value;
       ca.sc_num = sc_num; ca.sc_off = sc_off;
-      launch_compare(ca, st);
     }
-    if (b.timing == 1 || (b.timing == 2 && two)) hipEventRecord(get_event(b, ev++), st);
   }
-  launch_publish_counters(b.d_counters, b.h_counters, st);
+  bool launched = false;
+  if (use_graph) {
+    // Small batch: its ~8 launches, two event operations and the cross-stream wait cost the host more than the GPU
+    // spends on the kernels.  Capture them once per batch slot (pose stage forked onto the side stream inside the
+    // graph; the set-up grid is the worst case, so no list-length estimate is baked in) and replay with one call.
+    const uint64_t h = plan.hash();
+    hipGraphExec_t exec = nullptr;
+    for (auto& g : b.graphs) if (g.exec && g.hash == h) exec = g.exec;
+    if (!exec) {
+      hipGraph_t graph = nullptr;
+      hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+      if (e == hipSuccess) {
+        if (!c->fork_ev) hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
+        hipEventRecord(c->fork_ev, st);
+        hipStreamWaitEvent(c->side, c->fork_ev, 0);
+        const int rc = issue_plan(c, b, plan, c->side, st, 0u, ev);
+        e = hipStreamEndCapture(st, &graph);
+        if (rc != RTUF_OK) e = hipErrorUnknown;
+      }
+      if (e == hipSuccess && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (graph) hipGraphDestroy(graph);
+      if (e != hipSuccess || !exec) {
+        // no graphs on this runtime: fall back to plain launches for the life of the context
+        (void)hipGetLastError();
+        exec = nullptr;
+        c->graphs_ok = false;
+      } else {
+        auto& slot = b.graphs[b.graph_next];
+        b.graph_next = (b.graph_next + 1) % rtuf_context::Batch::kGraphs;
+        if (slot.exec) hipGraphExecDestroy(slot.exec);       // (not in flight: a slot's batches are retired before it is reused)
+        slot.exec = exec;
+        slot.hash = h;
+      }
+    }
+    if (exec) {
+      HIP_TRY(c, hipGraphLaunch(exec, st));
+      b.setup_grid = 0xffffffffu;          // worst-case grid: the work list always fits
+      launched = true;
+    }
+  }
+  if (!launched) {
+    const int rc = issue_plan(c, b, plan, use_graph ? st : sp, st, c->items_hint, ev);
+    if (rc != RTUF_OK) return rc;
+  }
   HIP_TRY(c, hipEventRecord(b.done, st));
   HIP_TRY(c, hipGetLastError());
   return RTUF_OK;
@@ -1100,7 +1196,7 @@ static int retire_oldest(rtuf_context* c)
       if (b.timing == 1 && b.events.size() >= 2) {
         // events: [start, pose_end, (setup_end, tile_end, compare_end) per group ...]
         float ms = 0;
-        c->stats.ms_pose = c->stats.ms_setup = c->stats.ms_raster = c->stats.ms_compare = 0;
+        c->stats.ms_pose = c->stats.ms_setup = c->stats.ms_clip = c->stats.ms_raster = c->stats.ms_compare = 0;
         hipEventElapsedTime(&ms, b.events[0], b.events[1]); c->stats.ms_pose = ms;
         size_t e = 1;
         for (int base = 0; base < b.n; base += c->group) {
@@ -1110,26 +1206,27 @@ static int retire_oldest(rtuf_context* c)
           e += 3;
         }
         hipEventElapsedTime(&ms, b.events[0], b.events[e]); c->stats.ms_total = ms;
-      } else if (b.timing == 2 && b.events.size() >= 3) {
-        // events: (setup_begin, tile_begin, tile_end[, compare_end]) per group
-        const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
+      } else if (b.timing == 2 && b.events.size() >= 4) {
+        // events: (setup_begin, clip_begin, tile_begin, tile_end[, compare_end]) per group
+        const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0 && !b.bits;
         float ms = 0;
-        c->stats.ms_pose = c->stats.ms_setup = c->stats.ms_raster = c->stats.ms_compare = c->stats.ms_total = 0;
+        c->stats.ms_pose = c->stats.ms_setup = c->stats.ms_clip = c->stats.ms_raster = c->stats.ms_compare = c->stats.ms_total = 0;
         size_t e = 0;
         for (int base = 0; base < b.n; base += c->group) {
           hipEventElapsedTime(&ms, b.events[e], b.events[e + 1]); c->stats.ms_setup += ms;
-          hipEventElapsedTime(&ms, b.events[e + 1], b.events[e + 2]); c->stats.ms_raster += ms;
-          if (two) { hipEventElapsedTime(&ms, b.events[e + 2], b.events[e + 3]); c->stats.ms_compare += ms; }
-          e += two ? 4 : 3;
+          hipEventElapsedTime(&ms, b.events[e + 1], b.events[e + 2]); c->stats.ms_clip += ms;
+          hipEventElapsedTime(&ms, b.events[e + 2], b.events[e + 3]); c->stats.ms_raster += ms;
+          if (two) { hipEventElapsedTime(&ms, b.events[e + 3], b.events[e + 4]); c->stats.ms_compare += ms; }
+          e += two ? 5 : 4;
         }
       }
       if (b.timing) {
         c->acc_ms[0] += c->stats.ms_pose; c->acc_ms[1] += c->stats.ms_setup; c->acc_ms[2] += c->stats.ms_raster;
-        c->acc_ms[3] += c->stats.ms_compare; c->acc_ms[4] += c->stats.ms_total;
+        c->acc_ms[3] += c->stats.ms_compare; c->acc_ms[4] += c->stats.ms_total; c->acc_ms[5] += c->stats.ms_clip;
         c->acc_batches++;
         c->stats.timed_batches = c->acc_batches;
         c->stats.sum_ms_pose = c->acc_ms[0]; c->stats.sum_ms_setup = c->acc_ms[1]; c->stats.sum_ms_raster = c->acc_ms[2];
-        c->stats.sum_ms_compare = c->acc_ms[3]; c->stats.sum_ms_total = c->acc_ms[4];
+        c->stats.sum_ms_compare = c->acc_ms[3]; c->stats.sum_ms_total = c->acc_ms[4]; c->stats.sum_ms_clip = c->acc_ms[5];
       }
       b.active = false;
       c->oldest = (c->oldest + 1) % kMaxInflight;
@@ -1471,11 +1568,11 @@ int rtuf_get_stats(rtuf_context* c, rtuf_stats* out)
     *out = c->kids[c->last_kid]->stats;
     out->bin_capacity = c->kids[c->last_kid]->capacity;
     out->regrowths = 0; out->timed_batches = 0;
-    out->sum_ms_pose = out->sum_ms_setup = out->sum_ms_raster = out->sum_ms_compare = out->sum_ms_total = 0;
+    out->sum_ms_pose = out->sum_ms_setup = out->sum_ms_raster = out->sum_ms_compare = out->sum_ms_total = out->sum_ms_clip = 0;
     for (const rtuf_context* k : c->kids) {
       out->regrowths += k->stats.regrowths; out->timed_batches += k->stats.timed_batches;
       out->sum_ms_pose += k->stats.sum_ms_pose; out->sum_ms_setup += k->stats.sum_ms_setup; out->sum_ms_raster += k->stats.sum_ms_raster;
-      out->sum_ms_compare += k->stats.sum_ms_compare; out->sum_ms_total += k->stats.sum_ms_total;
+      out->sum_ms_compare += k->stats.sum_ms_compare; out->sum_ms_total += k->stats.sum_ms_total; out->sum_ms_clip += k->stats.sum_ms_clip;
     }
     return RTUF_OK;
   }

@@ -45,12 +45,12 @@ def build_workload(name, frames):
     raise SystemExit("unknown workload " + name)
 
 
-def child(name, frames, seconds):
+def child(name, frames, seconds, shaders="reference"):
     import numpy as np
     from oracle.ref_gl import harness as HN
     from oracle import bindings as O
     wl, n_states = build_workload(name, frames)
-    h = HN.Harness(wl.width, wl.height)
+    h = HN.Harness(wl.width, wl.height, shaders)
     L = h.L
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     # static geometry once: one VBO/IBO per draw call (src/renderable.cpp:167-169, :343-349)
@@ -98,8 +98,41 @@ def child(name, frames, seconds):
         n += 1
     el = time.perf_counter() - t0
     print(json.dumps({"workload": name, "description": WORKLOADS[name], "width": wl.width, "height": wl.height, "triangles": wl.n_triangles(),
-                      "threads": int(os.environ.get("LP_NUM_THREADS", "0")), "renderer": h.renderer(),
+                      "threads": int(os.environ.get("LP_NUM_THREADS", "0")), "renderer": h.renderer(), "shaders": shaders,
                       "frames": n, "seconds": el, "frames_per_s": n / el, "ms_per_frame": el / n * 1e3, "equals_oracle": same}))
+
+
+def run_children(name, frames, seconds, shaders, threads, procs):
+    """`procs` concurrent processes (one GL context each, like one reference node per camera) with `threads` llvmpipe
+    threads each; returns the list of their result dicts."""
+    env = dict(os.environ, LP_NUM_THREADS=str(threads))
+    cmd = [sys.executable, os.path.abspath(__file__), "--child", name, "--frames", str(frames), "--seconds", str(seconds), "--shaders", shaders]
+    ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT) for _ in range(procs)]
+    out = []
+    for pr in ps:
+        so, se = pr.communicate(timeout=1200)
+        line = [l for l in so.splitlines() if l.startswith("{")]
+        out.append(json.loads(line[-1]) if (pr.returncode == 0 and line) else {"error": (se or so)[-300:]})
+    return out
+
+
+def bench_leg(args):
+    """The llvmpipe figures bench.py embeds in cpu_baseline: the bench workload (C2/C3 model), one stream per frame."""
+    cores = len(os.sched_getaffinity(0))
+    lp_max = min(16, cores)                    # llvmpipe caps its rasteriser threads (LP_MAX_THREADS = 16 in Mesa 23)
+    procs = max(1, cores // lp_max)
+    res = {"cpu": cpu_model(), "cores_available": cores, "shaders": args.shaders, "seconds_per_configuration": args.seconds}
+    legs = [("one_process_1_thread", 1, 1), ("one_process_%d_threads" % lp_max, lp_max, 1)]
+    if procs > 1:
+        legs.append(("%d_processes_x_%d_threads" % (procs, lp_max), lp_max, procs))
+    res["configurations"] = [l[0] for l in legs]
+    for label, threads, np_ in legs:
+        rs = run_children("C2/C3", args.frames, args.seconds, args.shaders, threads, np_)
+        good = [r for r in rs if "frames_per_s" in r]
+        res[label] = {"frames_per_s": sum(r["frames_per_s"] for r in good), "processes": np_, "threads_per_process": threads,
+                      "processes_failed": len(rs) - len(good), "equals_oracle": all(r.get("equals_oracle") for r in good) if good else None,
+                      "renderer": good[0]["renderer"] if good else None, "error": None if good else rs[0].get("error")}
+    print(json.dumps(res))
 
 
 def cpu_model():
@@ -118,9 +151,15 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="distinct joint states / sensor frames cycled through")
     ap.add_argument("--seconds", type=float, default=6.0, help="timed seconds per (workload, thread count)")
     ap.add_argument("--threads", type=int, nargs="*", default=None)
+    ap.add_argument("--shaders", choices=["reference", "standin"], default="reference",
+                    help="reference: the reference's own GLSL from /root/reference (development container); standin: oracle/ref_gl/standin_shaders (bit-identical re-statement, for machines without /root/reference)")
+    ap.add_argument("--bench-leg", action="store_true", help="bench.py's cpu_baseline leg: the bench workload only, 1 thread / one process at llvmpipe's thread limit / the whole box")
     args = ap.parse_args()
     if args.child:
-        child(args.child, args.frames, args.seconds)
+        child(args.child, args.frames, args.seconds, args.shaders)
+        return
+    if args.bench_leg:
+        bench_leg(args)
         return
     cores = len(os.sched_getaffinity(0))
     threads = args.threads or sorted({1, min(8, cores), cores})
