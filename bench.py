@@ -441,6 +441,12 @@ def main():
         # ---- CPU baseline: the oracle port on this box's host cores, on a bounded sample of the same batch ----
         if world == 1 and args.cpu_seconds > 0 and n > 0:
             cores = len(os.sched_getaffinity(0))
+            quota = None
+            try:        # a container's CPU quota (cgroup v2): the cores the threads below can really use at once
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                quota = None if q == "max" else float(q) / float(per)
+            except Exception:
+                quota = None
             # inputs: the first streams of the last batch (exactly what the GPU just filtered), prepared once
             n_in = min(n, 64)
             inputs = []
@@ -459,7 +465,7 @@ def main():
             nN, tN = O.filter_throughput(prepared, args.cpu_seconds, cores)
             cb = {"value": n1 / t1, "unit": "frames/s", "cores": 1, "kind": "port",
                   "sample": "%d frames of the last batch (first %d streams, cycled) through oracle/rtuf_oracle.c, single thread, %.1f s" % (n1, n_in, t1),
-                  "all_cores": {"value": nN / tN, "unit": "frames/s", "cores": cores,
+                  "all_cores": {"value": nN / tN, "unit": "frames/s", "cores": cores, "cgroup_cpu_quota_cores": quota,
                                 "sample": "%d frames of the same set on %d POSIX threads inside the oracle library, %.1f s" % (nN, cores, tN)}}
             try:
                 lp = json.load(open(os.path.join(ROOT, "profiles", "llvmpipe_baseline.json")))

@@ -141,7 +141,12 @@ struct rtuf_context {
   Batch batch[kMaxInflight];
   hipStream_t side = nullptr;                // pose stages (see Batch)
   hipEvent_t fork_ev = nullptr;              // graph capture: forks the side stream off the main stream
-  bool graphs_ok = true;                     // cleared when the runtime refuses stream capture / instantiation
+  // Small batches of a context that is one of several pipelines replay a captured hipGraph (one launch call instead of
+  // ~12 API calls: there the host's launch cost is the limit, and the pipelines provide the overlap between batches).
+  // A single-pipeline context keeps plain launches: its pose stage runs on the side stream underneath the previous
+  // batch's raster kernels, which a graph on the main stream would serialise (batch = 1: 75 us plain, 94 us as a graph).
+  // Cleared when the runtime refuses stream capture / instantiation.
+  bool graphs_ok = false;
   int oldest = 0;                            // ring index of the oldest batch in flight
   int pending = 0;                           // batches in flight
 
@@ -279,6 +284,7 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
       rtuf_context* k = nullptr;
       const int rc = rtuf_create(&k, device_id, width, height, max_streams, &kp);
       if (rc != RTUF_OK) { rtuf_destroy(c); return rc; }
+      k->graphs_ok = true;
       c->kids.push_back(k);
     }
   }

@@ -1066,3 +1066,108 @@ def test_pipelines_inside_one_context(pipes):
     ctx.close()
     with pytest.raises(R.RtufError):
         R.Context(W, H, n, 0, params(pipelines=9))
+
+
+def test_fk_camera_shift_and_reverting_to_the_host_camera():
+    """A camera posed by on-device forward kinematics (camera_frame >= 0) gets the camera_tx_/camera_ty_ origin shift of
+    src/urdf_filter.cpp:607-611 through rtuf_set_camera_shift; going back to camera_frame = -1, or handing explicit link
+    matrices for a stream, brings back the camera transform the host set (both batch slots)."""
+    n = 4
+    wl = WL.pr2_workload(n, 320, 240, total_triangles=8000, first_state_seed=31)
+    ctx = R.Context(320, 240, n, 0, params(wl.replace_value, wl.max_diff))
+    ids = wl.load_into(ctx)
+    depth = wl.depth_batch()
+    wl.load_kinematics(ctx, ids)
+    L = wl.link_tf[0].shape[1]
+    host_cam = np.stack([S.gl(np.array([[1, 0, 0, 0.01 * s], [0, 1, 0, 0.02], [0, 0, 1, 0.03], [0, 0, 0, 1.0]])) for s in range(n)])
+    ctx.set_cameras(0, wl.projection, wl.offset_inv, host_cam)
+
+    def check(cam_expected, tol):
+        for _ in range(2):                               # both batch slots
+            masked, mask = ctx.filter_batch(depth)
+            tf, cam = ctx.read_poses(n, L)
+            assert np.abs(cam - cam_expected).max() <= tol
+            for s in (0, n - 1):
+                draws = [(tf[s, li], d.pre_op, d.op, d.verts, d.tris) for li, dl in enumerate(wl.models[0]) for d in dl]
+                om, ok = O.filter_frame(depth[s], wl.projection[s], draws, wl.offset_inv[s], cam[s], max_diff=wl.max_diff, replace_value=wl.replace_value)
+                assert (ok != mask[s]).sum() == 0 and bits_equal(om, masked[s])
+
+    # 1. robot-mounted camera, no shift: inverse(fixed <- camera frame)
+    ctx.set_joint_positions(0, ids[0], wl.joint_q, None, wl.camera_frame_index)
+    check(wl.cam_tf, 1e-12)
+    # 2. with the stereo-baseline shift: origin + right * tx + down * ty, right / down = columns 0 / 1 of the rotation
+    tx, ty = np.linspace(0.01, 0.07, n), np.linspace(-0.02, 0.02, n)
+    ctx.set_camera_shift(0, tx, ty)
+    shifted = wl.cam_tf.copy().reshape(n, 4, 4)          # GL column-major: [col][row]
+    for s in range(n):
+        shifted[s, 3, :3] += shifted[s, 0, :3] * tx[s] + shifted[s, 1, :3] * ty[s]
+    check(shifted.reshape(n, 16), 1e-12)
+    assert np.abs(shifted.reshape(n, 16) - wl.cam_tf).max() > 1e-3
+    # 3. camera_frame = -1: the host-set camera transforms again (the FK kernel had overwritten the device copies)
+    ctx.set_joint_positions(0, ids[0], wl.joint_q, None, -1)
+    check(host_cam, 0.0)
+    # 4. robot camera again, then explicit link matrices for every stream: forward kinematics off, host camera back
+    ctx.set_joint_positions(0, ids[0], wl.joint_q, None, wl.camera_frame_index)
+    check(shifted.reshape(n, 16), 1e-12)
+    ctx.set_link_poses_batch(0, ids[0], wl.link_tf[0])
+    check(host_cam, 0.0)
+    ctx.close()
+
+
+def test_general_forward_kinematics_kernel_for_trees_of_more_than_256_frames():
+    """Kinematic trees that do not fit the tree-sweep kernel's LDS (more than 256 frames) take the general per-frame
+    kernel: 300 frames (50 six-joint limbs on a base), matrices against the host forward kinematics, image against the
+    oracle fed the device matrices."""
+    rng = np.random.default_rng(12)
+    limbs, per = 50, 6
+    xml = ['<robot name="hydra"><link name="base"/>']
+    for a in range(limbs):
+        parent = "base"
+        for k in range(per):
+            name = "l%d_%d" % (a, k)
+            geo = '<visual><geometry><box size="0.05 0.03 0.12"/></geometry></visual>' if k == per - 1 else ""
+            xml.append('<link name="%s">%s</link>' % (name, geo))
+            jt = ("revolute", "prismatic", "fixed")[(a + k) % 3]
+            xml.append('<joint name="j%d_%d" type="%s"><origin xyz="%.3f %.3f %.3f" rpy="%.3f %.3f %.3f"/><parent link="%s"/><child link="%s"/><axis xyz="%.3f %.3f %.3f"/><limit lower="-1" upper="1"/></joint>'
+                       % (a, k, jt, *rng.uniform(-0.08, 0.08, 3), *rng.uniform(-0.5, 0.5, 3), parent, name, *rng.normal(size=3)))
+            parent = name
+    xml.append("</robot>")
+    xml = "".join(xml)
+    model = urdf.Model.from_string(xml)
+    assert len(model.links) == 1 + limbs * per > 256
+    n, W, H = 3, 160, 120
+    from realtime_urdf_filter_amd.filter import URDFRenderer
+    tf0 = urdf.StaticTransformProvider()
+    rd = URDFRenderer(xml, "", "base", "base", tf0, "visual", 1.0, [])
+    strip = lambda nm: nm[1:] if nm.startswith("/") else nm
+    kin = urdf.kinematic_arrays(model, [strip(r.name) for r in rd.renderables_], [r.link_offset for r in rd.renderables_])
+    assert len(kin["parent"]) == 301
+    ctx = R.Context(W, H, n, 0, params())
+    m = ctx.add_model()
+    for r in rd.renderables_:
+        l = ctx.add_link(m)
+        for d in r.draws:
+            ctx.add_draw(m, l, d.verts, d.tris, d.pre_op, d.op)
+    ctx.finalize_models()
+    ctx.set_kinematics(m, kin["parent"], kin["joint_type"], kin["joint_origin"], kin["joint_axis"], kin["link_frame"], kin["link_offset"])
+    P = S.projection(131.25, 131.25, 79.5, 59.5, W, H)
+    root = np.eye(4)
+    root[:3, 3] = (0.0, 0.0, 1.2)                       # the hydra one metre in front of the camera
+    qs, expect = [], []
+    for s in range(n):
+        q = {j: float(rng.uniform(-0.6, 0.6)) for j in model.joints}
+        qs.append(urdf.joint_vector(kin, q))
+        fk = urdf.forward_kinematics(model, q, urdf.Transform(root[:3, :3], root[:3, 3]))
+        expect.append(np.stack([(fk[strip(r.name)] * r.link_offset).opengl_matrix() for r in rd.renderables_]))
+    ctx.set_cameras(0, np.tile(P, (n, 1)), np.tile(np.eye(4).reshape(16), (n, 1)), np.tile(np.eye(4).reshape(16), (n, 1)))
+    ctx.set_joint_positions(0, m, np.stack(qs), np.tile(S.gl(root), (n, 1)), -1)
+    depth = np.stack([S.sensor_depth(W, H, 0.3 * s) for s in range(n)])
+    masked, mask = ctx.filter_batch(depth)
+    tf, cam = ctx.read_poses(n, len(rd.renderables_))
+    assert np.abs(tf - np.stack(expect)).max() < 1e-12
+    for s in range(n):
+        draws = [(tf[s, li], d.pre_op, d.op, d.verts, d.tris) for li, r in enumerate(rd.renderables_) for d in r.draws]
+        om, ok = O.filter_frame(depth[s], P, draws, None, None, replace_value=5.0)
+        assert (ok != mask[s]).sum() == 0 and bits_equal(om, masked[s])
+        assert (mask[s] > 0).sum() > 50                 # the limbs are in view
+    ctx.close()
