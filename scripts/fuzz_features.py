@@ -3,7 +3,9 @@
 Every scene: 1-9 streams (work items with partial stream triples), 1-3 models with per-stream model selection,
 links made of primitives (boxes incl. the reference's second box, spheres, cylinders: fans, strips, quads with
 scale / translate ops) and of procedural meshes of up to several chunks, 32FC1 or 16UC1 frames, with or
-without the mask, fused or two-kernel, every result compared with the CPU oracle pixel by pixel."""
+without the mask, fused or two-kernel, one pipeline or several inside the context (small batches then replay captured
+hipGraphs; every pipeline is exercised), full planes or the bit-packed mask-only output expanded on the host -- every
+result compared with the CPU oracle pixel by pixel."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -47,6 +49,9 @@ for sc in range(n_scenes):
     if two: p.flags |= R.FLAG_TWO_KERNEL
     if rng.integers(0, 5) == 0: p.bin_capacity = 16
     if rng.integers(0, 4) == 0: p.max_inflight_streams = int(rng.integers(1, 4))      # several launch groups per batch
+    pipes = int(rng.choice([0, 0, 2, 3]))
+    p.pipelines = pipes
+    bits = (not two) and (W % 4 == 0) and bool(rng.integers(0, 3) == 0)
     ctx = R.Context(W, H, n_streams, 0, p)
     ids = []
     for links in models:
@@ -72,9 +77,19 @@ for sc in range(n_scenes):
         per.append((offinv, camtf, chosen, tfs_all))
     if u16:
         mm = np.clip(np.nan_to_num(depth, nan=0.0, posinf=0.0) * 1000.0 + rng.integers(-3, 4, depth.shape), 0, 65535).astype(np.uint16)
-        masked, mask = ctx.filter_batch_u16(mm, want_mask=want_mask)
-    else:
-        masked, mask = ctx.filter_batch(depth, want_mask=want_mask)
+    for rep_ in range((pipes + 1 + sc % pipes) if pipes else 1):   # with pipelines: every one gets a batch, some twice (graph replay); the checked batch lands on a varying one
+        if bits:
+            src = np.ascontiguousarray(mm if u16 else depth)
+            packed = np.zeros((n_streams, ctx.mask_bits_words()), np.uint32)
+            ctx.filter_batch_bits_async(src, packed)
+            ctx.sync()
+            pairs = [R.expand_mask_bits(src[s], packed[s], p.filter_replace_value) for s in range(n_streams)]
+            masked, mask = np.stack([a for a, _ in pairs]), np.stack([b for _, b in pairs])
+            want_mask = True
+        elif u16:
+            masked, mask = ctx.filter_batch_u16(mm, want_mask=want_mask)
+        else:
+            masked, mask = ctx.filter_batch(depth, want_mask=want_mask)
     for s, (offinv, camtf, chosen, tfs_all) in enumerate(per):
         draws = []
         for mi in chosen:
@@ -87,7 +102,7 @@ for sc in range(n_scenes):
         bd = int((depth_f32_to_u16(om) != masked[s]).sum()) if u16 else int((om.view(np.uint32) != masked[s].view(np.uint32)).sum())
         if bm or bd:
             bad_total += 1
-            print("MISMATCH scene %d (seed %d) stream %d/%d %dx%d two=%s u16=%s mask=%s models=%s: mask %d depth %d" % (sc, seed0 + sc, s, n_streams, W, H, two, u16, want_mask, chosen, bm, bd), flush=True)
+            print("MISMATCH scene %d (seed %d) stream %d/%d %dx%d two=%s u16=%s mask=%s pipelines=%d bits=%s models=%s: mask %d depth %d" % (sc, seed0 + sc, s, n_streams, W, H, two, u16, want_mask, pipes, bits, chosen, bm, bd), flush=True)
     ctx.close()
 print("scenes %d, streams with mismatches %d, %.1f s" % (n_scenes, bad_total, time.time() - t0))
 sys.exit(1 if bad_total else 0)

@@ -10,20 +10,23 @@ root=$PWD
 out=$root/gpurun_out/profiles
 rm -rf $out; mkdir -p $out
 B="python $root/bench.py"
-PROF_ARGS="--steps 20 --min-seconds 0 --cpu-seconds 0 --check-frames 0"
+PROF_ARGS="--steps 20 --min-seconds 0 --cpu-seconds 0 --check-frames 0 --overlap-pipelines 0"
 
 # ---- 1. bench lines ---------------------------------------------------------------------------------------------
-$B > /dev/null 2> $out/bench.err                                   # first run on a fresh box is the slowest: warm-up
-$B --cpu-seconds 12 > $out/${tag}_bench.json 2>> $out/bench.err
+$B --cpu-seconds 0 --overlap-pipelines 0 > /dev/null 2> $out/bench.err      # first run on a fresh box is the slowest: warm-up
+$B > $out/${tag}_bench.json 2>> $out/bench.err
 $B --cpu-seconds 0 --two-kernel > $out/${tag}_bench_two_kernel.json 2>> $out/bench.err
 $B --cpu-seconds 0 --two-kernel --streams 1024 --steps 30 > $out/${tag}_bench_two_kernel_1024.json 2>> $out/bench.err
 $B --cpu-seconds 0 --streams 1024 --steps 30 > $out/${tag}_bench_1024.json 2>> $out/bench.err
 $B --cpu-seconds 0 --u16 > $out/${tag}_bench_u16.json 2>> $out/bench.err
-$B --steps 200 --cpu-seconds 0 --streams 1 > $out/${tag}_bench_batch1.json 2>> $out/bench.err
+$B --steps 500 --cpu-seconds 0 --streams 1 --overlap-pipelines 0 > $out/${tag}_bench_batch1.json 2>> $out/bench.err
+$B --steps 500 --cpu-seconds 0 --streams 1 --overlap-pipelines 0 --pipelines 2 > $out/${tag}_bench_batch1_pipelines2.json 2>> $out/bench.err
+$B --steps 500 --cpu-seconds 0 --streams 1 --overlap-pipelines 0 --pipelines 3 > $out/${tag}_bench_batch1_pipelines3.json 2>> $out/bench.err
 $B --cpu-seconds 0 --host-poses > $out/${tag}_bench_host_poses.json 2>> $out/bench.err
 $B --cpu-seconds 0 --pipelines 2 > $out/${tag}_bench_pipelines2.json 2>> $out/bench.err
 $B --cpu-seconds 0 --workload c4 --shard-of 8 --steps 50 > $out/${tag}_bench_c4_share.json 2>> $out/bench.err
 $B --cpu-seconds 0 --workload c5 --shard-of 8 --steps 30 > $out/${tag}_bench_c5_share.json 2>> $out/bench.err
+python $root/scripts/host_planes_rate.py > $out/${tag}_host_planes.json 2>> $out/bench.err
 
 # ---- 2. kernel traces -------------------------------------------------------------------------------------------
 cd /tmp
@@ -74,7 +77,9 @@ for k, v in agg.items():
 PY
 cd $root
 python scripts/pmc_to_json.py $out $tag > $out/pmc_to_json.log 2>&1
+python scripts/valu_mix.py $out/valu_peak.json > $out/valu_mix.log 2>&1 || true
 (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5) > $out/${tag}_gpu_tests.txt
+{ python scripts/fuzz_parity.py 10000 $((20260928 + RANDOM)) 2>&1 | tail -2; python scripts/fuzz_features.py 6000 $((20270000 + RANDOM)) 2>&1 | tail -2; FUZZ_BIG=1 python scripts/fuzz_parity.py 150 $((333 + RANDOM)) 2>&1 | tail -2; } > $out/${tag}_fuzz.txt
 ls -la $out; cat $out/pmc_to_json.log; tail -c 400 $out/bench.err
 for f in $out/${tag}_bench*.json; do python - $f <<'PY'
 import json, sys

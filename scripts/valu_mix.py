@@ -25,7 +25,7 @@ TRANSCENDENTAL = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "
 
 
 def main():
-    vp_path = os.path.join(ROOT, "profiles", "valu_peak.json")
+    vp_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "valu_peak.json")
     vp = json.load(open(vp_path))
     ops = vp["ops"]
     slow, fast = vp["slow_class_G_per_s"], vp["fast_class_G_per_s"]
