@@ -269,8 +269,11 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
   c->tiles_y = (height + kTileH - 1) / kTileH;
   if (params) c->params = *params; else rtuf_default_params(&c->params);
   e = hipSetDevice(device_id);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+  // (a front context of several pipelines owns no streams of its own: HIP multiplexes streams onto a few hardware queues,
+  // and two pipelines whose main streams share a queue do not overlap at all)
+  const bool front = c->params.pipelines > 1;
+  if (e == hipSuccess && !front) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess && !front) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
   if (e != hipSuccess) {
     snprintf(g_create_error, sizeof g_create_error, "hip init failed: %s", hipGetErrorString(e));
     delete c;

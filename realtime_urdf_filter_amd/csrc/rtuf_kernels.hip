@@ -563,8 +563,14 @@ constexpr int kCoopTiles = 4;
 #define RTUF_FRONT_AREA 24
 #endif
 constexpr int kFrontArea = RTUF_FRONT_AREA;      // boxes up to this many pixel centres are binned from the front of a bin
+// `edges` (clip kernel only: it has the integer edge functions at hand) additionally drops the tiles of the bounding box
+// that the triangle does not touch at all -- an edge function is largest at one corner of the tile's part of the box; not
+// positive there means no pixel centre of that tile is covered (half of the tiles of a clipped wall's box): the tile
+// kernel would classify such a record away anyway, so the image is the same with fewer bin entries.  Every lane takes up
+// to four tiles per round and issues their (independent) slot reservations back to back before the first store needs its
+// answer: a 460-tile wall at 720p costs two atomic round trips instead of eight.
 __device__ __forceinline__ uint32_t emit_big_records_wave(const SetupArgs& a, int slot, bool big, uint32_t bbx, uint32_t bby,
-                                                          const PackedTri& pk)
+                                                          const PackedTri& pk, const TriRec* edges = nullptr)
 {
   const int lane = threadIdx.x & 63;
   const int tiles = a.tiles_x * a.tiles_y;
@@ -580,18 +586,59 @@ __device__ __forceinline__ uint32_t emit_big_records_wave(const SetupArgs& a, in
 #pragma unroll
       for (int k = 0; k < 8; k++) dp[k] = __builtin_amdgcn_readlane(sp[k], src);
     }
+    int eA[3] = {0, 0, 0}, eB[3] = {0, 0, 0}, eC[3] = {0, 0, 0};
+    if (edges) {
+#pragma unroll
+      for (int e = 0; e < 3; e++) {
+        eA[e] = __builtin_amdgcn_readlane(edges->A[e], src);
+        eB[e] = __builtin_amdgcn_readlane(edges->B[e], src);
+        eC[e] = __builtin_amdgcn_readlane(edges->C[e], src);
+      }
+    }
     const uint32_t qx = (uint32_t)__builtin_amdgcn_readlane((int)bbx, src), qy = (uint32_t)__builtin_amdgcn_readlane((int)bby, src);
     const int qslot = __builtin_amdgcn_readlane(slot, src);
-    const int tx0 = (int)(qx & 0xffff) / kTileW, tx1 = (int)(qx >> 16) / kTileW;
-    const int ty0 = (int)(qy & 0xffff) / kTileH, ty1 = (int)(qy >> 16) / kTileH;
+    const int bx0 = (int)(qx & 0xffff), bx1 = (int)(qx >> 16), by0 = (int)(qy & 0xffff), by1 = (int)(qy >> 16);
+    const int tx0 = bx0 / kTileW, tx1 = bx1 / kTileW;
+    const int ty0 = by0 / kTileH, ty1 = by1 / kTileH;
     const int tw = tx1 - tx0 + 1, ntile = tw * (ty1 - ty0 + 1);
-    for (int k = lane; k < ntile; k += 64) {
-      const int row = k / tw, tx = tx0 + k - row * tw;
-      const int bin = __mul24(qslot, tiles) + __mul24(ty0 + row, a.tiles_x) + tx;
-      const uint32_t pos = atomicAdd(&a.bin_count[2 * bin + 1], 1u);          // many-tile records are large: back of the bin
-      if (pos < a.capacity) store_record(a.bins + (size_t)bin * a.capacity + (a.capacity - 1u - pos), q);
+    uint32_t mine = 0;
+    constexpr int kPerRound = 4;
+    for (int k0 = lane; k0 < ntile; k0 += 64 * kPerRound) {
+      int bin[kPerRound];
+      uint32_t pos[kPerRound];
+#pragma unroll
+      for (int j = 0; j < kPerRound; j++) {
+        const int k = k0 + 64 * j;
+        bin[j] = -1;
+        pos[j] = 0;
+        if (k < ntile) {
+          const int row = k / tw, tx = tx0 + k - row * tw, ty = ty0 + row;
+          bool touches = true;
+          if (edges) {
+            // the tile's part of the box, in pixel-centre coordinates
+            const int x0 = max(bx0, tx * kTileW), x1 = min(bx1, tx * kTileW + kTileW - 1);
+            const int y0 = max(by0, ty * kTileH), y1 = min(by1, ty * kTileH + kTileH - 1);
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+              const int xa = eA[e] > 0 ? x1 : x0, ya = eB[e] > 0 ? y1 : y0;
+              touches = touches && (__mul24(eA[e], xa) + __mul24(eB[e], ya) + eC[e]) > 0;
+            }
+          }
+          if (touches) {
+            bin[j] = __mul24(qslot, tiles) + __mul24(ty, a.tiles_x) + tx;
+            pos[j] = atomicAdd(&a.bin_count[2 * bin[j] + 1], 1u);          // many-tile records are large: back of the bin
+            mine++;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kPerRound; j++)
+        if (bin[j] >= 0 && pos[j] < a.capacity) store_record(a.bins + (size_t)bin[j] * a.capacity + (a.capacity - 1u - pos[j]), q);
     }
-    if (lane == src) n += (uint32_t)ntile;
+    // the record's owner accounts for the entries of all lanes
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off);
+    if (lane == src) n += mine;
   }
   return n;
 }
@@ -601,7 +648,8 @@ __device__ __forceinline__ uint32_t emit_big_records_wave(const SetupArgs& a, in
 // atomicAdd in the SAME instruction, so a wave pays one atomic round trip per tile index
 // instead of one per distinct bin; group members get consecutive slots, which makes the
 // 32-byte record stores of neighbouring mesh triangles contiguous.
-__device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slot, bool have, uint32_t bbx, uint32_t bby, const PackedTri& pk)
+__device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slot, bool have, uint32_t bbx, uint32_t bby, const PackedTri& pk,
+                                                     const TriRec* edges = nullptr)
 {
   const int lane = threadIdx.x & 63;
   int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
@@ -616,7 +664,7 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slo
   // lane-per-triangle walk runs as long as the largest box in the wave).
   const int cls = ((int)(bbx >> 16) - (int)(bbx & 0xffff) + 1) * ((int)(bby >> 16) - (int)(bby & 0xffff) + 1) > kFrontArea ? 1 : 0;
   const bool big = have && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kCoopTiles;
-  if (__ballot(big)) n += emit_big_records_wave(a, slot, big, bbx, bby, pk);
+  if (__ballot(big)) n += emit_big_records_wave(a, slot, big, bbx, bby, pk, edges);
   have = have && !big;
   int tx = tx0, ty = ty0;                  // walks the touched tiles row by row
   for (;;) {
@@ -1167,6 +1215,9 @@ __device__ __forceinline__ float clipdist(const float* c, int plane)
   return s;
 }
 
+#ifndef RTUF_CLIP_RUN
+#define RTUF_CLIP_RUN 16
+#endif
 constexpr int kClipBlock = 128;          // threads per clip workgroup (48 KB of LDS polygon storage)
 constexpr int kClipMaxV = 16;            // clip-space vertices per triangle: 3 + at most 2 new ones per frustum plane (+1 spare)
 constexpr int kClipMaxP = 12;            // polygon vertices (5-bit pool indices packed in one 64-bit register)
@@ -1274,7 +1325,7 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
       wprev = wi;
     }
     binned += have ? 1u : 0u;
-    if (__ballot(have) && !RTUF_ABL(a.flags, 0x800000u)) entries += emit_record_wave(a, slot, have, r.bbx, r.bby, pk);      // (0x800000: timing experiment)
+    if (__ballot(have) && !RTUF_ABL(a.flags, 0x800000u)) entries += emit_record_wave(a, slot, have, r.bbx, r.bby, pk, &r);      // (0x800000: timing experiment)
   }
   // statistics: one atomic pair per wave (per-lane atomics on a shard's counters serialise at one L2
   // atomic unit -- that alone used to be three quarters of this kernel's time)
@@ -1293,8 +1344,19 @@ __global__ __launch_bounds__(kClipBlock) void clip_kernel(SetupArgs a)
   const uint32_t n = min(a.counters->shard[shard_id].clip_count, a.clip_capacity);
   const uint32_t per = gridDim.x / kCounterShards;
   const ClipItem* list = a.clip_list + (size_t)shard_id * a.clip_capacity;
-  for (uint32_t base = (blockIdx.x / kCounterShards) * blockDim.x; base < n; base += per * blockDim.x) {
-    const uint32_t i = base + threadIdx.x;          // whole waves stay in the loop (cooperative emission)
+  // Items are dealt out in runs of kClipRun over the shard's workgroups (run r -> workgroup r % per).  Neighbouring list
+  // entries come from the same chunk and stream: keeping a few together keeps the item, vertex and matrix loads of a
+  // wave on shared cache lines; but the expensive items (wall triangles whose fans each touch hundreds of tiles) come in
+  // long runs too, and whole blocks of 128 items would hand such a run to one workgroup, which then emits its
+  // many-tile records one after the other while the rest of the GPU has finished.
+  // Only as many workgroups as the list needs take part (the grid is fixed, the list length lives on the device), so
+  // that the waves stay densely filled: the cooperative emission costs per wave, not per lane.
+  constexpr uint32_t kClipRun = RTUF_CLIP_RUN;
+  const uint32_t wg = blockIdx.x / kCounterShards;
+  const uint32_t used = min(per, (n + blockDim.x - 1) / blockDim.x);
+  if (wg >= used) return;
+  for (uint32_t base = 0; base < n; base += used * blockDim.x) {
+    const uint32_t i = base + ((threadIdx.x / kClipRun) * used + wg) * kClipRun + threadIdx.x % kClipRun;          // whole waves stay in the loop (cooperative emission)
     ClipItem it; it.slot = 0; it.draw = 0; it.vert_begin = 0; it.packed = 0; it.order = 0;
     if (i < n) {
       const uint4* src = reinterpret_cast<const uint4*>(&list[i]);
