@@ -1351,10 +1351,11 @@ __global__ __launch_bounds__(kClipBlock) void clip_kernel(SetupArgs a)
   // many-tile records one after the other while the rest of the GPU has finished.
   // Only as many workgroups as the list needs take part (the grid is fixed, the list length lives on the device), so
   // that the waves stay densely filled: the cooperative emission costs per wave, not per lane.
-  constexpr uint32_t kClipRun = RTUF_CLIP_RUN;
+  // (A list that needs every workgroup for several passes is balanced by its volume: whole blocks then, for locality.)
   const uint32_t wg = blockIdx.x / kCounterShards;
   const uint32_t used = min(per, (n + blockDim.x - 1) / blockDim.x);
   if (wg >= used) return;
+  const uint32_t kClipRun = used < per ? (uint32_t)RTUF_CLIP_RUN : blockDim.x;
   for (uint32_t base = 0; base < n; base += used * blockDim.x) {
     const uint32_t i = base + ((threadIdx.x / kClipRun) * used + wg) * kClipRun + threadIdx.x % kClipRun;          // whole waves stay in the loop (cooperative emission)
     ClipItem it; it.slot = 0; it.draw = 0; it.vert_begin = 0; it.packed = 0; it.order = 0;
