@@ -141,6 +141,7 @@ struct rtuf_context {
   Batch batch[kMaxInflight];
   hipStream_t side = nullptr;                // pose stages (see Batch)
   hipEvent_t fork_ev = nullptr;              // graph capture: forks the side stream off the main stream
+  bool side_used_plain = false;              // the side stream carries work that was enqueued outside a graph
   // Small batches of a context that is one of several pipelines replay a captured hipGraph (one launch call instead of
   // ~12 API calls: there the host's launch cost is the limit, and the pipelines provide the overlap between batches).
   // A single-pipeline context keeps plain launches: its pose stage runs on the side stream underneath the previous
@@ -1098,6 +1099,8 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     for (auto& g : b.graphs) if (g.exec && g.hash == h) exec = g.exec;
     if (!exec) {
       hipGraph_t graph = nullptr;
+      // (the side stream joins the capture below: it must not still carry plain launches of an earlier batch)
+      if (c->side_used_plain) { hipStreamSynchronize(c->side); c->side_used_plain = false; }
       hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
       if (e == hipSuccess) {
         if (!c->fork_ev) hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
@@ -1129,6 +1132,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     }
   }
   if (!launched) {
+    if (!use_graph) c->side_used_plain = true;
     const int rc = issue_plan(c, b, plan, use_graph ? st : sp, st, c->items_hint, ev);
     if (rc != RTUF_OK) return rc;
   }

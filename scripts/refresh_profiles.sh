@@ -30,14 +30,14 @@ python $root/scripts/host_planes_rate.py > $out/${tag}_host_planes.json 2>> $out
 
 # ---- 2. kernel traces -------------------------------------------------------------------------------------------
 cd /tmp
-trace() {   # name, bench args
-  rm -rf /tmp/rp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp -o t -- $B $PROF_ARGS $2 > /dev/null 2>&1
+trace() {   # name, bench args: the bench's own default step counts (only the CPU legs and the second context are left out)
+  rm -rf /tmp/rp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp -o t -- $B --cpu-seconds 0 --check-frames 0 --overlap-pipelines 0 $2 > /dev/null 2>&1
   cp $(find /tmp/rp -name '*kernel_stats.csv' | head -1) $out/${tag}_kernel_stats$1.csv
 }
 trace "" ""
 trace "_two_kernel" "--two-kernel"
-trace "_two_kernel_1024" "--two-kernel --streams 1024"
-trace "_c4_share" "--workload c4 --shard-of 8"
+trace "_two_kernel_1024" "--two-kernel --streams 1024 --steps 30"
+trace "_c4_share" "--workload c4 --shard-of 8 --steps 50"
 
 # ---- 3. counters (one pass per group) ---------------------------------------------------------------------------
 pmc() {     # output file, bench args, counters...
