@@ -192,8 +192,11 @@ int rtuf_filter_batch(rtuf_context *ctx, int n_streams, const float *const *dept
  * while two are pending first retires the oldest (as rtuf_sync does for all of them), so a caller
  * that keeps enqueueing never leaves the GPU idle during the host round trip.  The buffers of a
  * batch must stay valid and unmodified until it is retired (a bin regrowth runs it again);
- * rtuf_set_joint_positions may be called at any time (its staging is per batch), every other
- * setter waits for the batches in flight.  rtuf_sync() retires everything in flight. */
+ * the per-frame pose setters -- rtuf_set_joint_positions, rtuf_set_camera(s), rtuf_set_camera_shift,
+ * rtuf_set_link_poses[_batch] -- may be called at any time: their staging is a ring of sets, one per batch in
+ * flight plus one being written, so the next frame's poses are staged while the GPU filters this one (only a call
+ * that switches a stream between forward kinematics and explicit matrices waits).  Every other setter (parameters,
+ * model selection, kinematic trees) waits for the batches in flight.  rtuf_sync() retires everything in flight. */
 int rtuf_filter_batch_device(rtuf_context *ctx, int n_streams, const float *d_depth,
                              float *d_masked, uint8_t *d_mask);
 /* 16UC1 variants: depth in / out as uint16 millimetres with the reference's conversions fused into the

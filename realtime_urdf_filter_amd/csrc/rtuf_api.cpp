@@ -84,8 +84,19 @@ struct rtuf_context {
   float4* d_cverts = nullptr; uint32_t* d_ctris = nullptr; uint32_t* d_corder = nullptr; Chunk* d_chunks = nullptr; Draw* d_draws = nullptr;
 
   // per-frame pose staging
-  Camera* h_cams = nullptr;            // pinned [max_streams]
-  double* h_link_tf = nullptr;         // pinned [max_streams][n_links][16]
+  // Cameras and link matrices are staged in a ring of kMaxInflight + 1 pinned sets, like the joint positions: every
+  // batch in flight owns the set it was enqueued with (a bin regrowth re-reads it), the setters write into a set no
+  // batch reads, so staging the next frame's TF-derived matrices never waits for the GPU.  h_cams / h_link_tf alias the
+  // set being written.
+  Camera* ring_cams[kMaxInflight + 1] = {};        // pinned [max_streams]
+  double* ring_link_tf[kMaxInflight + 1] = {};     // pinned [max_streams][n_links][16]
+  Camera* h_cams = nullptr;
+  double* h_link_tf = nullptr;
+  struct StageRing {                               // one per array: cameras and link matrices advance independently
+    int live = 0, write = 0;                       // set of the newest batch / set the setters write
+    bool written = false;                          // the write set has changes no batch has taken yet
+    bool carried = true;                           // the write set holds everything the live set does
+  } cam_ring, link_ring;
   uint64_t* h_model_mask = nullptr;    // pinned [max_streams]
   uint64_t* d_model_mask = nullptr;
 
@@ -115,6 +126,7 @@ struct rtuf_context {
     hipEvent_t done = nullptr;               // recorded after that copy
     std::vector<hipEvent_t> events;          // stage timing
     std::vector<int> q_idx;                  // per model: joint-position staging buffer
+    int cam_idx = 0, link_idx = 0;           // camera / link-matrix staging sets
     // The batch's pose stage (uploads, forward kinematics, matrix stacks, cull) runs on a side stream and
     // writes only buffers of its own slot, so it overlaps the raster kernels of the batch before it.
     Camera* d_cams = nullptr; double* d_link_tf = nullptr;
@@ -305,7 +317,10 @@ static void free_frame_buffers(rtuf_context* c)
   for (auto& b : c->batch) { dfree(b.d_cams); dfree(b.d_link_tf); dfree(b.d_mvp); dfree(b.d_bg); dfree(b.d_items); dfree(b.d_counters); }
   dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_zsurface);
   for (auto& b : c->batch) { dfree(b.st_depth); dfree(b.st_masked); dfree(b.st_mask); b.st_streams = 0; dfree(b.st_bits); b.st_bits_streams = 0; }
-  hfree(c->h_cams); hfree(c->h_link_tf); hfree(c->h_model_mask);
+  for (auto*& p : c->ring_cams) hfree(p);
+  for (auto*& p : c->ring_link_tf) hfree(p);
+  c->h_cams = nullptr; c->h_link_tf = nullptr;
+  hfree(c->h_model_mask);
   for (auto& b : c->batch) hfree(b.h_counters);
 }
 
@@ -436,8 +451,12 @@ static int alloc_frame_buffers(rtuf_context* c)
   const int N = c->max_streams;
   const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
   const size_t L = (size_t)std::max(c->n_links, 1);
-  HIP_TRY(c, hipHostMalloc(&c->h_cams, sizeof(Camera) * N));
-  HIP_TRY(c, hipHostMalloc(&c->h_link_tf, sizeof(double) * 16 * L * N));
+  for (int r = 0; r <= kMaxInflight; r++) {
+    HIP_TRY(c, hipHostMalloc(&c->ring_cams[r], sizeof(Camera) * N));
+    HIP_TRY(c, hipHostMalloc(&c->ring_link_tf[r], sizeof(double) * 16 * L * N));
+  }
+  c->cam_ring = rtuf_context::StageRing(); c->link_ring = rtuf_context::StageRing();
+  c->h_cams = c->ring_cams[0]; c->h_link_tf = c->ring_link_tf[0];
   HIP_TRY(c, hipHostMalloc(&c->h_model_mask, sizeof(uint64_t) * N));
   for (auto& b : c->batch) {
     HIP_TRY(c, hipHostMalloc(&b.h_counters, sizeof(Counters)));
@@ -458,11 +477,14 @@ static int alloc_frame_buffers(rtuf_context* c)
   // identity defaults
   static const double I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   for (int s = 0; s < N; s++) {
-    memcpy(c->h_cams[s].projection, I, sizeof I);
-    memcpy(c->h_cams[s].offset_inv, I, sizeof I);
-    memcpy(c->h_cams[s].cam_tf, I, sizeof I);
-    c->h_cams[s].shift[0] = c->h_cams[s].shift[1] = 0.0;
-    for (size_t l = 0; l < L; l++) memcpy(c->h_link_tf + ((size_t)s * L + l) * 16, I, sizeof I);
+    for (int r = 0; r <= kMaxInflight; r++) {
+      Camera& cam = c->ring_cams[r][s];
+      memcpy(cam.projection, I, sizeof I);
+      memcpy(cam.offset_inv, I, sizeof I);
+      memcpy(cam.cam_tf, I, sizeof I);
+      cam.shift[0] = cam.shift[1] = 0.0;
+      for (size_t l = 0; l < L; l++) memcpy(c->ring_link_tf[r] + ((size_t)s * L + l) * 16, I, sizeof I);
+    }
     c->h_model_mask[s] = ~0ull;
   }
   // rasteriser working set
@@ -642,6 +664,47 @@ int rtuf_finalize_models(rtuf_context* c)
   return RTUF_OK;
 }
 
+}  // extern "C"
+
+// The setters of cameras / link matrices write into the staging set no batch in flight reads.  The first write after a
+// batch took the previous set carries over what this call does not overwrite (`whole` = it overwrites everything).
+static void begin_camera_write(rtuf_context* c, bool whole)
+{
+  auto& r = c->cam_ring;
+  if (!r.carried) {
+    if (!whole) memcpy(c->ring_cams[r.write], c->ring_cams[r.live], sizeof(Camera) * (size_t)c->max_streams);
+    r.carried = true;
+  }
+  r.written = true;
+}
+static void begin_link_write(rtuf_context* c, bool whole)
+{
+  auto& r = c->link_ring;
+  if (!r.carried) {
+    if (!whole) memcpy(c->ring_link_tf[r.write], c->ring_link_tf[r.live], sizeof(double) * 16 * (size_t)std::max(c->n_links, 1) * (size_t)c->max_streams);
+    r.carried = true;
+  }
+  r.written = true;
+}
+// A new batch takes the staged set of one array (if anything was staged since the last batch) and moves the setters on
+// to a set no batch in flight reads (kMaxInflight + 1 sets: one is always free).  Returns the set the batch reads.
+template <typename IdxOf>
+static int take_staged(rtuf_context* c, rtuf_context::StageRing& r, const rtuf_context::Batch& b, IdxOf idx_of)
+{
+  if (r.written) {
+    r.live = r.write;
+    bool used[kMaxInflight + 1] = {};
+    used[r.live] = true;
+    for (const auto& o : c->batch) if (o.active && &o != &b) used[idx_of(o)] = true;
+    for (int i = 0; i <= kMaxInflight; i++) if (!used[i]) { r.write = i; break; }
+    r.written = false;
+    r.carried = false;
+  }
+  return r.live;
+}
+
+extern "C" {
+
 int rtuf_set_stream_models(rtuf_context* c, int stream, const int* model_ids, int n_models)
 {
   KIDS_ALL(c, rtuf_set_stream_models(k, stream, model_ids, n_models));
@@ -665,9 +728,9 @@ int rtuf_set_camera(rtuf_context* c, int stream, const double projection[16], co
 {
   KIDS_ALL(c, rtuf_set_camera(k, stream, projection, camera_offset_inv, camera_tf));
   if (!c) return RTUF_ERR_INVALID;
-  WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
   if (stream < 0 || stream >= c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream %d", stream);
+  begin_camera_write(c, false);
   Camera& cam = c->h_cams[stream];
   if (projection) memcpy(cam.projection, projection, sizeof cam.projection);
   if (camera_offset_inv) memcpy(cam.offset_inv, camera_offset_inv, sizeof cam.offset_inv);
@@ -697,12 +760,14 @@ int rtuf_set_link_poses(rtuf_context* c, int stream, int model, const double* li
 {
   KIDS_ALL(c, rtuf_set_link_poses(k, stream, model, link_tf, n_links));
   if (!c || !link_tf) return RTUF_ERR_INVALID;
-  WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
   if (stream < 0 || stream >= c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream %d", stream);
   if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
   const HostModel& m = c->models[model];
   if (n_links != (int)m.links.size()) return c->fail(RTUF_ERR_INVALID, "model %d has %d links, got %d", model, (int)m.links.size(), n_links);
+  // (switching a stream off forward kinematics changes single-buffered state: that alone waits for the batches in flight)
+  if (m.kin.h_enabled && m.kin.h_enabled[stream]) WAIT_IF_PENDING(c);
+  begin_link_write(c, false);
   memcpy(c->h_link_tf + ((size_t)stream * c->n_links + m.link_base) * 16, link_tf, sizeof(double) * 16 * (size_t)n_links);
   // (a stream that leaves forward kinematics also gets its host-set camera back: the FK kernel may have overwritten cam_tf)
   if (m.kin.h_enabled && m.kin.h_enabled[stream]) { c->models[model].kin.h_enabled[stream] = 0; c->models[model].kin.dirty_aux = true; for (auto& b : c->batch) b.dirty_cams = true; }
@@ -715,9 +780,9 @@ int rtuf_set_cameras(rtuf_context* c, int first, int n, const double* projection
 {
   KIDS_ALL(c, rtuf_set_cameras(k, first, n, projection, offset_inv, cam_tf));
   if (!c) return RTUF_ERR_INVALID;
-  WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
   if (first < 0 || n < 0 || first + n > c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream range %d+%d", first, n);
+  begin_camera_write(c, false);
   for (int s = 0; s < n; s++) {
     Camera& cam = c->h_cams[first + s];
     if (projection) memcpy(cam.projection, projection + 16 * (size_t)s, sizeof cam.projection);
@@ -732,9 +797,9 @@ int rtuf_set_camera_shift(rtuf_context* c, int first, int n, const double* camer
 {
   KIDS_ALL(c, rtuf_set_camera_shift(k, first, n, camera_tx, camera_ty));
   if (!c) return RTUF_ERR_INVALID;
-  WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
   if (first < 0 || n < 0 || first + n > c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream range %d+%d", first, n);
+  begin_camera_write(c, false);
   for (int s = 0; s < n; s++) {
     c->h_cams[first + s].shift[0] = camera_tx ? camera_tx[s] : 0.0;
     c->h_cams[first + s].shift[1] = camera_ty ? camera_ty[s] : 0.0;
@@ -747,12 +812,15 @@ int rtuf_set_link_poses_batch(rtuf_context* c, int first, int n, int model, cons
 {
   KIDS_ALL(c, rtuf_set_link_poses_batch(k, first, n, model, link_tf, n_links));
   if (!c || !link_tf) return RTUF_ERR_INVALID;
-  WAIT_IF_PENDING(c);
   if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
   if (first < 0 || n < 0 || first + n > c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad stream range %d+%d", first, n);
   if (model < 0 || model >= (int)c->models.size()) return c->fail(RTUF_ERR_INVALID, "bad model id %d", model);
   const HostModel& m = c->models[model];
   if (n_links != (int)m.links.size()) return c->fail(RTUF_ERR_INVALID, "model %d has %d links, got %d", model, (int)m.links.size(), n_links);
+  // (switching streams off forward kinematics changes single-buffered state: that alone waits for the batches in flight)
+  if (m.kin.h_enabled) for (int s = 0; s < n; s++) if (m.kin.h_enabled[first + s]) { WAIT_IF_PENDING(c); break; }
+  // one model that owns every link, all streams: this call overwrites the whole set, nothing to carry over
+  begin_link_write(c, first == 0 && n == c->max_streams && n_links == c->n_links);
   for (int s = 0; s < n; s++) {
     memcpy(c->h_link_tf + ((size_t)(first + s) * c->n_links + m.link_base) * 16, link_tf + (size_t)s * n_links * 16,
            sizeof(double) * 16 * (size_t)n_links);
@@ -1005,10 +1073,21 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
   // only what the host changed since the last batch crosses the bus (with on-device forward
   // kinematics that is just the joint positions below)
   const bool more = n > b.uploaded_streams;
-  if (b.dirty_cams || more) HIP_TRY(c, hipMemcpyAsync(b.d_cams, c->h_cams, sizeof(Camera) * n, hipMemcpyHostToDevice, sp));
-  if (b.dirty_link_tf || more) HIP_TRY(c, hipMemcpyAsync(b.d_link_tf, c->h_link_tf, sizeof(double) * 16 * L * n, hipMemcpyHostToDevice, sp));
+  if (!rerun) {
+    b.cam_idx = take_staged(c, c->cam_ring, b, [](const rtuf_context::Batch& o) { return o.cam_idx; });
+    b.link_idx = take_staged(c, c->link_ring, b, [](const rtuf_context::Batch& o) { return o.link_idx; });
+    c->h_cams = c->ring_cams[c->cam_ring.write];
+    c->h_link_tf = c->ring_link_tf[c->link_ring.write];
+  }
+  // (a re-run after a bin regrowth finds this slot's device copies as its first run left them; its dirty flags may
+  // already belong to setter calls made since, for the batch that comes next)
+  if (!rerun) {
+    if (b.dirty_cams || more) HIP_TRY(c, hipMemcpyAsync(b.d_cams, c->ring_cams[b.cam_idx], sizeof(Camera) * n, hipMemcpyHostToDevice, sp));
+    if (b.dirty_link_tf || more) HIP_TRY(c, hipMemcpyAsync(b.d_link_tf, c->ring_link_tf[b.link_idx], sizeof(double) * 16 * L * n, hipMemcpyHostToDevice, sp));
+    b.dirty_cams = b.dirty_link_tf = false;
+  }
   if (c->dirty_mask || n > c->mask_uploaded_streams) HIP_TRY(c, hipMemcpyAsync(c->d_model_mask, c->h_model_mask, sizeof(uint64_t) * n, hipMemcpyHostToDevice, sp));
-  b.dirty_cams = b.dirty_link_tf = c->dirty_mask = false;
+  c->dirty_mask = false;
   b.uploaded_streams = std::max(b.uploaded_streams, n);
   c->mask_uploaded_streams = std::max(c->mask_uploaded_streams, n);
   BatchPlan plan;

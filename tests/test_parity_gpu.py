@@ -428,9 +428,9 @@ def test_on_device_forward_kinematics():
 
 
 def test_staging_next_joint_positions_while_a_batch_is_in_flight():
-    """rtuf_set_joint_positions is double-buffered: the next frame's joint states may be staged between
+    """rtuf_set_joint_positions is staged per batch: the next frame's joint states may be staged between
     rtuf_filter_batch_device and rtuf_sync without disturbing the batch in flight, including partial
-    (per-stream) updates; every other setter waits for the batch instead."""
+    (per-stream) updates; setters of state that is not staged per batch wait for the batch instead."""
     import torch
     n, W, H = 4, 320, 240
     A = WL.pr2_workload(n, W, H, total_triangles=8000, first_state_seed=1000)
@@ -467,9 +467,9 @@ def test_staging_next_joint_positions_while_a_batch_is_in_flight():
     want_mask = np.concatenate([ref_a[1][:2], ref_b[1][2:]])
     want_masked = np.concatenate([ref_a[0][:2], ref_b[0][2:]])
     assert np.array_equal(got[1], want_mask) and bits_equal(got[0], want_masked)
-    # a setter that is not double-buffered waits for the batch in flight: the batch keeps its inputs
+    # a setter whose state is not staged per batch (here: the parameters) waits for the batch in flight: the batch keeps its inputs
     ctx.filter_batch_device(n, d_depth.data_ptr(), d_masked.data_ptr(), d_mask.data_ptr())
-    ctx.set_cameras(0, A.projection * 1.0, A.offset_inv, None)
+    ctx.set_params(params(A.replace_value, A.max_diff))
     assert np.array_equal(d_mask.cpu().numpy(), want_mask)
     ctx.sync()
     ctx.close()
@@ -1170,4 +1170,55 @@ def test_general_forward_kinematics_kernel_for_trees_of_more_than_256_frames():
         om, ok = O.filter_frame(depth[s], P, draws, None, None, replace_value=5.0)
         assert (ok != mask[s]).sum() == 0 and bits_equal(om, masked[s])
         assert (mask[s] > 0).sum() > 50                 # the limbs are in view
+    ctx.close()
+
+
+@pytest.mark.parametrize("cap", [0, 16])
+def test_staging_next_link_matrices_while_batches_are_in_flight(cap):
+    """The TF-driven shape of the reference at many streams: cameras and link matrices from the host every frame.  Their
+    staging is a ring of sets (one per batch in flight + one being written), so frame k+1's matrices are staged while
+    frames k and k-1 are still on the GPU, nothing waits in between -- and a bin regrowth (cap=16), which re-runs the
+    batches in flight, must re-read each batch's own set, not what was staged since."""
+    import torch
+    n, W, H = 5, 320, 240
+    wls = [WL.pr2_workload(n, W, H, total_triangles=8000, first_state_seed=seed) for seed in (100, 200, 300, 400)]
+    A = wls[0]
+    ctx = R.Context(W, H, n, 0, params(A.replace_value, A.max_diff, bin_capacity=cap))
+    ids = A.load_into(ctx)
+    steps = 7
+    depths = [A.depth_batch(first=3 * k) for k in range(steps)]
+    dev = torch.device("cuda:0")
+    d_in = [torch.from_numpy(d).to(dev) for d in depths]
+    outs = [(torch.empty((n, H, W), dtype=torch.float32, device=dev), torch.empty((n, H, W), dtype=torch.uint8, device=dev)) for _ in range(steps)]
+    torch.cuda.synchronize()
+
+    def stage(k):
+        wl = wls[k % 4]
+        if k % 3 == 0:
+            ctx.set_cameras(0, wl.projection, wl.offset_inv, wl.cam_tf)            # everything
+            ctx.set_link_poses_batch(0, ids[0], wl.link_tf[0])
+        elif k % 3 == 1:
+            ctx.set_cameras(0, None, None, wl.cam_tf)                              # camera transform only (the rest carries over)
+            for s in range(n):                                                     # stream by stream
+                ctx.set_link_poses(s, ids[0], wl.link_tf[0][s])
+        else:
+            for s in range(n):
+                ctx.set_camera(s, None, None, wl.cam_tf[s])
+            ctx.set_link_poses_batch(1, ids[0], wl.link_tf[0][1:])                 # partial ranges
+            ctx.set_link_poses_batch(0, ids[0], wl.link_tf[0][:1])
+
+    stage(0)
+    for k in range(steps):
+        ctx.filter_batch_device(n, d_in[k].data_ptr(), outs[k][0].data_ptr(), outs[k][1].data_ptr())
+        if k + 1 < steps:
+            stage(k + 1)                       # while up to two batches are in flight
+    ctx.sync()
+    for k in range(steps):
+        wl = wls[k % 4]
+        masked, mask = outs[k][0].cpu().numpy(), outs[k][1].cpu().numpy()
+        for s in range(n):
+            om, ok = O.filter_frame(depths[k][s], wl.projection[s], wl.oracle_draws(s), wl.offset_inv[s], wl.cam_tf[s],
+                                    max_diff=wl.max_diff, replace_value=wl.replace_value)
+            assert np.array_equal(ok, mask[s]) and bits_equal(om, masked[s]), (cap, k, s)
+    assert (ctx.stats()["regrowths"] > 0) == (cap == 16)
     ctx.close()
