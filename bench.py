@@ -482,7 +482,7 @@ def main():
                 if args.cpu_seconds >= 2 and HN.available("standin"):
                     import subprocess
                     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "llvmpipe_baseline.py"), "--bench-leg", "--shaders", "standin",
-                                        "--seconds", str(min(args.cpu_seconds, 6.0)), "--frames", "8"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+                                        "--seconds", str(min(args.cpu_seconds, 6.0)), "--frames", "8"], capture_output=True, text=True, cwd=ROOT, timeout=240)
                     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
                     if r.returncode == 0 and line:
                         cb["reference_llvmpipe_live"] = dict(json.loads(line[-1]), unit="frames/s",

@@ -1407,7 +1407,6 @@ constexpr int kSmallArea = RTUF_SMALL_AREA;     // bounding boxes up to this man
 constexpr int kWallArea = RTUF_WALL_AREA;         // ... larger bins only for boxes covering more of the tile than this
 constexpr int kParkBelow = RTUF_PARK_BELOW;       // bins of at most this many records use the cooperative whole-tile pass
 constexpr int kHugeMax = 255;
-constexpr uint32_t kParkClosed = 0x10000u;        // initial list count of a bin that does not park                    // whole-tile triangles a workgroup parks for its cooperative pass
 constexpr int kQuarterArea = RTUF_QUARTER_AREA;   // up to this many by a quarter wave (4 triangles at a time), larger by the whole wave
 
 // The tile's part of a record's box (local lx0..ly1) against the three edges: an edge function is largest /

@@ -110,7 +110,7 @@ def run_children(name, frames, seconds, shaders, threads, procs):
     ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT) for _ in range(procs)]
     out = []
     for pr in ps:
-        so, se = pr.communicate(timeout=1200)
+        so, se = pr.communicate(timeout=200)
         line = [l for l in so.splitlines() if l.startswith("{")]
         out.append(json.loads(line[-1]) if (pr.returncode == 0 and line) else {"error": (se or so)[-300:]})
     return out
