@@ -50,6 +50,21 @@ int main(int argc, char** argv)
     }
     return 0;
   }
+  if (argc >= 3 && std::string(argv[1]) == "--mesh") {
+    // CPU-only: load a mesh file (STL / Collada / OBJ) the way RenderableMesh does; prints the float bits of every vertex.
+    // Optional flags after the file: "no-up" (keep the file's up axis), "unit" (apply <unit meter>)
+    rtuf_host::MeshOptions opt;
+    for (int i = 3; i < argc; i++) {
+      if (std::string(argv[i]) == "no-up") opt.up_axis_to_y = false;
+      if (std::string(argv[i]) == "unit") opt.apply_unit = true;
+    }
+    std::vector<float> v;
+    std::vector<uint32_t> t;
+    if (!rtuf_host::load_mesh(argv[2], slurp(argv[2]), v, t, opt)) { std::printf("failed\n"); return 1; }
+    std::printf("%zu %zu\n", v.size() / 3, t.size() / 3);
+    for (float f : v) { uint32_t u; std::memcpy(&u, &f, 4); std::printf("%08x\n", u); }
+    return 0;
+  }
   if (argc != 12) { std::fprintf(stderr, "usage: %s urdf depth.f32 W H fx fy cx cy replace out_masked out_mask\n", argv[0]); return 2; }
   const std::string xml = slurp(argv[1]);
   const int W = std::atoi(argv[3]), H = std::atoi(argv[4]);

@@ -4,7 +4,7 @@
 //   tf / Bullet LinearMath   tf::Transform, tf::Quaternion, getOpenGLMatrix   -> rtuf_host::Transform
 //   urdfdom                  urdf::Model::initString, links, visuals, joints   -> rtuf_host::UrdfModel
 //   freeglut                 glutSolidCube / Sphere / Cylinder tessellation    -> rtuf_host::*_draws
-//   Assimp (STL only)        mesh import                                       -> rtuf_host::load_stl
+//   Assimp                   mesh import (STL, Collada, OBJ)                   -> rtuf_host::load_mesh (load_stl / load_collada / load_obj)
 //   TF tree                  lookupTransform                                   -> rtuf_host::TransformProvider,
 //                                                                                 forward_kinematics
 // Reference call sites: src/urdf_renderer.cpp:67-190, src/renderable.cpp:59-170, :306-452,
@@ -18,6 +18,11 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <initializer_list>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -159,6 +164,19 @@ struct XmlNode {
   std::string tag;
   std::map<std::string, std::string> attr;
   std::vector<XmlNode> children;
+  std::string text;             // character data directly inside the element (Collada arrays), concatenated
+  std::vector<const XmlNode*> all(const std::string& t) const
+  {
+    std::vector<const XmlNode*> out;
+    for (const auto& c : children) if (c.tag == t) out.push_back(&c);
+    return out;
+  }
+  const XmlNode* path(std::initializer_list<const char*> tags) const
+  {
+    const XmlNode* n = this;
+    for (const char* t : tags) { n = n->child(t); if (!n) return nullptr; }
+    return n;
+  }
   const XmlNode* child(const std::string& t) const
   {
     for (const auto& c : children) if (c.tag == t) return &c;
@@ -187,11 +205,13 @@ class XmlParser {
   size_t p_ = 0;
   void skip_ws() { while (p_ < s_.size() && std::isspace((unsigned char)s_[p_])) p_++; }
   bool starts(const char* lit) const { return s_.compare(p_, std::strlen(lit), lit) == 0; }
-  void skip_misc()
+  void skip_misc(std::string* text = nullptr)
   {
     for (;;) {
       // text (including stray '>' as in the reference's example URDF) up to the next '<'
+      const size_t t0 = p_;
       while (p_ < s_.size() && s_[p_] != '<') p_++;
+      if (text && p_ > t0) { text->append(s_, t0, p_ - t0); text->push_back(' '); }
       if (p_ >= s_.size()) return;
       if (starts("<!--")) { const size_t e = s_.find("-->", p_); p_ = e == std::string::npos ? s_.size() : e + 3; }
       else if (starts("<?")) { const size_t e = s_.find("?>", p_); p_ = e == std::string::npos ? s_.size() : e + 2; }
@@ -207,6 +227,7 @@ class XmlParser {
     size_t b = p_;
     while (p_ < s_.size() && name_char(s_[p_])) p_++;
     n.tag = s_.substr(b, p_ - b);
+    { const size_t colon = n.tag.find(':'); if (colon != std::string::npos) n.tag = n.tag.substr(colon + 1); }   // namespace prefix
     for (;;) {
       skip_ws();
       if (p_ >= s_.size()) throw std::runtime_error("XML: unterminated tag <" + n.tag);
@@ -226,7 +247,7 @@ class XmlParser {
       p_++;
     }
     for (;;) {
-      skip_misc();
+      skip_misc(&n.text);
       if (p_ >= s_.size()) throw std::runtime_error("XML: missing </" + n.tag + ">");
       if (starts("</")) {
         const size_t e = s_.find('>', p_);
@@ -557,6 +578,299 @@ inline bool load_stl(const std::string& data, std::vector<float>& verts, std::ve
   if ((verts.size() / 3) % 3) return false;
   for (uint32_t i = 0; i < verts.size() / 3; i++) tris.push_back(i);
   return true;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Collada (.dae) and Wavefront OBJ.  What of Assimp's behaviour (src/renderable.cpp:306-322 reads the file with
+// PreTransformVertices | SortByPType | GenNormals | Triangulate | GenUVCoords | FlipUVs; :352-415 take positions and three
+// indices per face) is restated here, and that none of it can be pinned against an Assimp in this image, is written
+// down in realtime_urdf_filter_amd/meshes.py -- the Python twin of this code; both are tested against each other.
+// ---------------------------------------------------------------------------------------------
+struct MeshOptions {
+  bool up_axis_to_y = true;     // Assimp's Collada importer rotates Z_UP / X_UP files to Y_UP (root node), PreTransformVertices bakes it in
+  bool apply_unit = false;      // Assimp >= 4.1 scales the root node by <unit meter>; 3.x (Ubuntu 14.04, README.md:29) does not
+};
+
+namespace detail {
+struct Mat4f {
+  float m[4][4];
+  static Mat4f identity() { Mat4f r{}; for (int i = 0; i < 4; i++) r.m[i][i] = 1.f; return r; }
+  Mat4f operator*(const Mat4f& b) const
+  {
+    Mat4f r{};
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        float acc = 0.f;
+        for (int k = 0; k < 4; k++) acc += m[i][k] * b.m[k][j];
+        r.m[i][j] = acc;
+      }
+    return r;
+  }
+};
+inline std::vector<double> parse_numbers(const std::string& s)
+{
+  std::vector<double> v;
+  const char* p = s.c_str();
+  for (;;) {
+    char* e = nullptr;
+    const double d = std::strtod(p, &e);
+    if (e == p) break;
+    v.push_back(d);
+    p = e;
+  }
+  return v;
+}
+inline std::string strip_hash(const std::string& s) { return !s.empty() && s[0] == '#' ? s.substr(1) : s; }
+inline void fan(const std::vector<long>& poly, std::vector<long>& corners)
+{
+  for (size_t k = 1; k + 1 < poly.size(); k++) { corners.push_back(poly[0]); corners.push_back(poly[k]); corners.push_back(poly[k + 1]); }
+}
+inline Mat4f collada_node_matrix(const XmlNode& node)
+{
+  Mat4f m = Mat4f::identity();
+  for (const auto& e : node.children) {
+    const std::vector<double> v = (e.tag == "matrix" || e.tag == "translate" || e.tag == "scale" || e.tag == "rotate") ? parse_numbers(e.text) : std::vector<double>();
+    Mat4f k = Mat4f::identity();
+    if (e.tag == "matrix" && v.size() == 16) {
+      for (int i = 0; i < 16; i++) k.m[i / 4][i % 4] = (float)v[i];
+    } else if (e.tag == "translate" && v.size() >= 3) {
+      for (int i = 0; i < 3; i++) k.m[i][3] = (float)v[i];
+    } else if (e.tag == "scale" && v.size() >= 3) {
+      for (int i = 0; i < 3; i++) k.m[i][i] = (float)v[i];
+    } else if (e.tag == "rotate" && v.size() >= 4) {
+      const double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      if (n <= 0) continue;
+      const double x = v[0] / n, y = v[1] / n, z = v[2] / n, a = v[3] * M_PI / 180.0;
+      const double c = std::cos(a), s = std::sin(a), o = 1.0 - std::cos(a);
+      const double r[3][3] = {{c + x * x * o, x * y * o - z * s, x * z * o + y * s},
+                              {y * x * o + z * s, c + y * y * o, y * z * o - x * s},
+                              {z * x * o - y * s, z * y * o + x * s, c + z * z * o}};
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) k.m[i][j] = (float)r[i][j];
+    } else {
+      continue;
+    }
+    m = m * k;
+  }
+  return m;
+}
+struct ColladaGeometry { bool ok = false; std::vector<float> pts; std::vector<long> corners; };
+inline ColladaGeometry collada_read_geometry(const XmlNode& geom)
+{
+  ColladaGeometry g;
+  const XmlNode* mesh = geom.child("mesh");
+  if (!mesh) return g;
+  std::map<std::string, std::pair<std::vector<float>, int>> sources;        // id -> (values, stride)
+  for (const XmlNode* src : mesh->all("source")) {
+    const XmlNode* fa = src->child("float_array");
+    if (!fa) continue;
+    const std::vector<double> vals = parse_numbers(fa->text);
+    const XmlNode* acc = src->path({"technique_common", "accessor"});
+    const long stride = acc ? std::atol(acc->get("stride", "3").c_str()) : 3;
+    const long offset = acc ? std::atol(acc->get("offset", "0").c_str()) : 0;
+    long count = ((long)vals.size() - offset) / std::max(stride, 1L);
+    if (acc && !acc->get("count").empty()) count = std::atol(acc->get("count").c_str());
+    if (stride < 1 || offset < 0 || count < 0 || offset + count * stride > (long)vals.size()) throw std::runtime_error("Collada: accessor outside its float_array");
+    std::vector<float> a((size_t)(count * stride));
+    for (long i = 0; i < count * stride; i++) a[(size_t)i] = (float)vals[(size_t)(offset + i)];
+    sources[src->get("id")] = {std::move(a), (int)stride};
+  }
+  const XmlNode* vtx = mesh->child("vertices");
+  if (!vtx) return g;
+  const std::string vertices_id = vtx->get("id");
+  const std::pair<std::vector<float>, int>* pos = nullptr;
+  for (const XmlNode* inp : vtx->all("input"))
+    if (inp->get("semantic") == "POSITION") {
+      auto it = sources.find(strip_hash(inp->get("source")));
+      if (it != sources.end()) pos = &it->second;
+    }
+  if (!pos) return g;
+  const int ps = pos->second;
+  const size_t npts = pos->first.size() / (size_t)ps;
+  g.pts.assign(npts * 3, 0.f);
+  for (size_t i = 0; i < npts; i++)
+    for (int k = 0; k < std::min(ps, 3); k++) g.pts[3 * i + k] = pos->first[i * ps + k];
+  for (const auto& prim : mesh->children) {
+    const std::string& t = prim.tag;
+    if (t != "triangles" && t != "polylist" && t != "polygons" && t != "trifans" && t != "tristrips") continue;
+    long stride = 1, voff = -1;
+    for (const XmlNode* inp : prim.all("input")) {
+      const long off = std::atol(inp->get("offset", "0").c_str());
+      stride = std::max(stride, off + 1);
+      if (inp->get("semantic") == "VERTEX" && strip_hash(inp->get("source")) == vertices_id) voff = off;
+    }
+    if (voff < 0) continue;
+    auto vertex_indices = [&](const std::string& text) {
+      const std::vector<double> p = parse_numbers(text);
+      std::vector<long> out;
+      for (size_t i = (size_t)voff; i < p.size(); i += (size_t)stride) out.push_back((long)p[i]);
+      return out;
+    };
+    if (t == "triangles") {
+      const XmlNode* p = prim.child("p");
+      std::vector<long> idx = vertex_indices(p ? p->text : "");
+      idx.resize(idx.size() / 3 * 3);
+      g.corners.insert(g.corners.end(), idx.begin(), idx.end());
+    } else if (t == "polylist") {
+      const XmlNode *p = prim.child("p"), *vc = prim.child("vcount");
+      const std::vector<long> idx = vertex_indices(p ? p->text : "");
+      size_t at = 0;
+      for (double nd : parse_numbers(vc ? vc->text : "")) {
+        const size_t n = (size_t)nd;
+        if (n >= 3 && at + n <= idx.size()) fan(std::vector<long>(idx.begin() + at, idx.begin() + at + n), g.corners);
+        at += n;
+      }
+    } else if (t == "polygons" || t == "trifans") {
+      for (const XmlNode* p : prim.all("p")) fan(vertex_indices(p->text), g.corners);
+    } else {
+      for (const XmlNode* p : prim.all("p")) {
+        const std::vector<long> idx = vertex_indices(p->text);
+        for (size_t k = 0; k + 2 < idx.size(); k++) {
+          if (k % 2 == 0) { g.corners.push_back(idx[k]); g.corners.push_back(idx[k + 1]); }
+          else { g.corners.push_back(idx[k + 1]); g.corners.push_back(idx[k]); }
+          g.corners.push_back(idx[k + 2]);
+        }
+      }
+    }
+  }
+  for (long c : g.corners) if (c < 0 || (size_t)c >= npts) throw std::runtime_error("Collada: vertex index out of range in geometry " + geom.get("id"));
+  g.ok = true;
+  return g;
+}
+inline void collect_library_nodes(const XmlNode& n, std::map<std::string, const XmlNode*>& out)
+{
+  for (const auto& c : n.children) {
+    if (c.tag == "node") { if (!c.get("id").empty()) out[c.get("id")] = &c; }
+    collect_library_nodes(c, out);
+  }
+}
+}  // namespace detail
+
+inline bool load_collada(const std::string& data, std::vector<float>& verts, std::vector<uint32_t>& tris, const MeshOptions& opt = MeshOptions())
+{
+  using namespace detail;
+  verts.clear();
+  tris.clear();
+  XmlNode root;
+  try {
+    root = XmlParser(data).parse_document();
+    if (root.tag != "COLLADA") return false;
+    std::string up = "Y_UP";
+    double meter = 1.0;
+    if (const XmlNode* asset = root.child("asset")) {
+      if (const XmlNode* u = asset->child("up_axis")) { up.clear(); for (char ch : u->text) if (!std::isspace((unsigned char)ch)) up.push_back((char)std::toupper((unsigned char)ch)); }
+      if (const XmlNode* u = asset->child("unit")) meter = std::atof(u->get("meter", "1").c_str());
+    }
+    std::map<std::string, const XmlNode*> geoms, lib_nodes, scenes;
+    const XmlNode* first_scene = nullptr;
+    for (const XmlNode* lib : root.all("library_geometries")) for (const XmlNode* g : lib->all("geometry")) geoms[g->get("id")] = g;
+    for (const XmlNode* lib : root.all("library_nodes")) collect_library_nodes(*lib, lib_nodes);
+    for (const XmlNode* lib : root.all("library_visual_scenes"))
+      for (const XmlNode* sc : lib->all("visual_scene")) { scenes[sc->get("id")] = sc; if (!first_scene) first_scene = sc; }
+    const XmlNode* scene = nullptr;
+    if (const XmlNode* inst = root.path({"scene", "instance_visual_scene"})) {
+      auto it = scenes.find(strip_hash(inst->get("url")));
+      if (it != scenes.end()) scene = it->second;
+    }
+    if (!scene) scene = first_scene;
+    Mat4f rootm = Mat4f::identity();
+    if (opt.up_axis_to_y && up == "Z_UP") { Mat4f k{}; k.m[0][0] = 1; k.m[1][2] = 1; k.m[2][1] = -1; k.m[3][3] = 1; rootm = rootm * k; }
+    else if (opt.up_axis_to_y && up == "X_UP") { Mat4f k{}; k.m[0][1] = -1; k.m[1][0] = 1; k.m[2][2] = 1; k.m[3][3] = 1; rootm = rootm * k; }
+    if (opt.apply_unit) { Mat4f k = Mat4f::identity(); for (int i = 0; i < 3; i++) k.m[i][i] = (float)meter; rootm = rootm * k; }
+    std::map<std::string, ColladaGeometry> cache;
+    auto emit = [&](const std::string& gid, const Mat4f& m) {
+      auto it = cache.find(gid);
+      if (it == cache.end()) {
+        auto g = geoms.find(gid);
+        it = cache.emplace(gid, g == geoms.end() ? ColladaGeometry() : collada_read_geometry(*g->second)).first;
+      }
+      const ColladaGeometry& g = it->second;
+      if (!g.ok) return;
+      for (long c : g.corners) {
+        const float x = g.pts[3 * c], y = g.pts[3 * c + 1], z = g.pts[3 * c + 2];
+        for (int r = 0; r < 3; r++) verts.push_back(m.m[r][0] * x + m.m[r][1] * y + m.m[r][2] * z + m.m[r][3]);
+      }
+    };
+    std::function<void(const XmlNode&, const Mat4f&, int)> walk = [&](const XmlNode& node, const Mat4f& parent, int depth) {
+      if (depth > 64) throw std::runtime_error("Collada: node hierarchy too deep");
+      const Mat4f m = parent * collada_node_matrix(node);
+      for (const auto& e : node.children) {
+        if (e.tag == "instance_geometry") emit(strip_hash(e.get("url")), m);
+        else if (e.tag == "instance_node") { auto it = lib_nodes.find(strip_hash(e.get("url"))); if (it != lib_nodes.end()) walk(*it->second, m, depth + 1); }
+        else if (e.tag == "node") walk(e, m, depth + 1);
+      }
+    };
+    if (scene) { for (const XmlNode* n : scene->all("node")) walk(*n, rootm, 0); }
+    else { for (const auto& g : geoms) emit(g.first, rootm); }
+  } catch (const std::exception&) {
+    verts.clear();
+    return false;
+  }
+  if (verts.empty()) return false;
+  for (uint32_t i = 0; i < verts.size() / 3; i++) tris.push_back(i);
+  return true;
+}
+
+inline bool load_obj(const std::string& data, std::vector<float>& verts, std::vector<uint32_t>& tris)
+{
+  verts.clear();
+  tris.clear();
+  std::vector<float> pts;
+  std::string text = data;
+  for (size_t p = 0; (p = text.find("\\\n", p)) != std::string::npos;) text.replace(p, 2, " ");
+  size_t at = 0;
+  while (at < text.size()) {
+    size_t e = text.find('\n', at);
+    if (e == std::string::npos) e = text.size();
+    std::string line = text.substr(at, e - at);
+    at = e + 1;
+    const size_t hash = line.find('#');
+    if (hash != std::string::npos) line.resize(hash);
+    std::vector<std::string> tok;
+    for (size_t p = 0; p < line.size();) {
+      while (p < line.size() && std::isspace((unsigned char)line[p])) p++;
+      size_t q = p;
+      while (q < line.size() && !std::isspace((unsigned char)line[q])) q++;
+      if (q > p) tok.push_back(line.substr(p, q - p));
+      p = q;
+    }
+    if (tok.empty()) continue;
+    if (tok[0] == "v" && tok.size() >= 4) {
+      for (int k = 1; k <= 3; k++) pts.push_back((float)std::atof(tok[k].c_str()));
+    } else if (tok[0] == "f" && tok.size() >= 4) {
+      std::vector<long> poly, corners;
+      const long n = (long)(pts.size() / 3);
+      for (size_t k = 1; k < tok.size(); k++) {
+        long i = std::atol(tok[k].c_str());            // stops at the first '/'
+        i = i > 0 ? i - 1 : n + i;
+        if (i < 0 || i >= n) { verts.clear(); return false; }
+        poly.push_back(i);
+      }
+      detail::fan(poly, corners);
+      for (long c : corners) for (int k = 0; k < 3; k++) verts.push_back(pts[3 * c + k]);
+    }
+  }
+  if (pts.empty()) return false;
+  for (uint32_t i = 0; i < verts.size() / 3; i++) tris.push_back(i);
+  return true;
+}
+
+// By extension of `name` (file name or URI), else by content.
+inline bool load_mesh(const std::string& name, const std::string& data, std::vector<float>& verts, std::vector<uint32_t>& tris,
+                      const MeshOptions& opt = MeshOptions())
+{
+  std::string ext;
+  const size_t dot = name.rfind('.');
+  if (dot != std::string::npos) for (size_t i = dot + 1; i < name.size(); i++) ext.push_back((char)std::tolower((unsigned char)name[i]));
+  if (ext == "dae") return load_collada(data, verts, tris, opt);
+  if (ext == "obj") return load_obj(data, verts, tris);
+  if (ext == "stl" || ext == "stlb" || ext == "stla") return load_stl(data, verts, tris);
+  size_t p = 0;
+  while (p < data.size() && std::isspace((unsigned char)data[p])) p++;
+  const std::string head = data.substr(p, 512);
+  if (head.compare(0, 5, "<?xml") == 0 || head.find("<COLLADA") != std::string::npos) return load_collada(data, verts, tris, opt);
+  if (load_stl(data, verts, tris)) return true;
+  return load_obj(data, verts, tris);
 }
 
 }  // namespace rtuf_host

@@ -244,11 +244,13 @@ class PackageResolver:
     """mesh_loader for URDFRenderer / RealtimeURDFFilter: resolves the mesh URIs a URDF carries --
     `package://<pkg>/<path>` against a list of package search roots (ROS_PACKAGE_PATH semantics: a root either IS the
     package directory `<pkg>` or contains it), `file://<path>` and plain paths -- and loads the file.  Replaces the
-    resource_retriever + Assimp pair of the reference (src/renderable.cpp:306-322).  STL only (binary, incl. the
-    "solid" header quirk, and ASCII): Collada / OBJ visual meshes are not supported and raise."""
+    resource_retriever + Assimp pair of the reference (src/renderable.cpp:306-322).  Formats: STL (binary, incl. the
+    "solid" header quirk, and ASCII), Collada (.dae) and Wavefront OBJ (`meshes.py`, which also says what of Assimp's
+    behaviour is restated and what is not pinned).  `up_axis_to_y` / `apply_unit`: see `meshes.load_collada`."""
 
-    def __init__(self, search_paths=None):
+    def __init__(self, search_paths=None, up_axis_to_y=True, apply_unit=False):
         import os
+        self.up_axis_to_y, self.apply_unit = up_axis_to_y, apply_unit
         paths = list(search_paths) if search_paths is not None else [p for p in os.environ.get("ROS_PACKAGE_PATH", "").split(":") if p]
         self.search_paths = paths
 
@@ -266,8 +268,7 @@ class PackageResolver:
         return uri
 
     def __call__(self, uri):
+        from . import meshes
         path = self.path_of(uri)
-        if not path.lower().endswith(".stl"):
-            raise IOError("mesh %r: only STL meshes are supported (the reference imports anything Assimp reads)" % uri)
         with open(path, "rb") as f:
-            return load_stl(f.read())
+            return meshes.load_mesh(path, f.read(), up_axis_to_y=self.up_axis_to_y, apply_unit=self.apply_unit)

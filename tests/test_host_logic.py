@@ -250,8 +250,8 @@ def test_package_resolver_finds_stl_meshes(tmp_path):
     assert tt.shape == (2, 3)
     with pytest.raises(IOError):
         G.PackageResolver([str(tmp_path / "ws")])("package://other_pkg/meshes/part.stl")
-    with pytest.raises(IOError):
-        G.PackageResolver([str(tmp_path / "ws")])("package://my_robot_description/meshes/part.dae")     # Collada: unsupported
+    with pytest.raises(ValueError):
+        G.PackageResolver([str(tmp_path / "ws")])("package://my_robot_description/meshes/part.dae")     # a Collada file without geometry
 
 
 def test_cpp_host_forward_kinematics_with_mimic_joints_matches_python(tmp_path):
@@ -278,3 +278,142 @@ def test_cpp_host_forward_kinematics_with_mimic_joints_matches_python(tmp_path):
         v = np.array([float(x) for x in parts[1:]])
         assert np.allclose(v[:9].reshape(3, 3), t.basis, atol=1e-15) and np.allclose(v[9:], t.origin, atol=1e-15), parts[0]
     assert not np.allclose(fk["tip"].origin, urdf.forward_kinematics(urdf.Model.from_string(xml), {})["tip"].origin)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Collada / OBJ import (meshes.py and its C++ twin in host.hpp): the files below are written for this test
+# ---------------------------------------------------------------------------------------------------------------------
+_DAE = """<?xml version="1.0" encoding="utf-8"?>
+<COLLADA xmlns="http://www.collada.org/2005/11/COLLADASchema" version="1.4.1">
+  <asset><unit name="inch" meter="0.0254"/><up_axis>%(up)s</up_axis></asset>
+  <library_geometries>
+    <geometry id="plate"><mesh>
+      <source id="plate-pos"><float_array id="plate-pos-array" count="12">0 0 0  2 0 0  2 1 0  0 1 0.5</float_array>
+        <technique_common><accessor source="#plate-pos-array" count="4" stride="3"><param name="X" type="float"/><param name="Y" type="float"/><param name="Z" type="float"/></accessor></technique_common></source>
+      <source id="plate-nrm"><float_array id="plate-nrm-array" count="3">0 0 1</float_array>
+        <technique_common><accessor source="#plate-nrm-array" count="1" stride="3"/></technique_common></source>
+      <vertices id="plate-vtx"><input semantic="POSITION" source="#plate-pos"/></vertices>
+      <polylist count="1" material="m"><input semantic="VERTEX" source="#plate-vtx" offset="0"/><input semantic="NORMAL" source="#plate-nrm" offset="1"/>
+        <vcount>4</vcount><p>0 0 1 0 2 0 3 0</p></polylist>
+    </mesh></geometry>
+    <geometry id="tri"><mesh>
+      <source id="tri-pos"><float_array id="tri-pos-array" count="9">0.25 0 0 0 0.5 0 0 0 0.75</float_array>
+        <technique_common><accessor source="#tri-pos-array" count="3" stride="3"/></technique_common></source>
+      <vertices id="tri-vtx"><input semantic="POSITION" source="#tri-pos"/></vertices>
+      <triangles count="1"><input semantic="VERTEX" source="#tri-vtx" offset="0"/><p>0 1 2</p></triangles>
+    </mesh></geometry>
+  </library_geometries>
+  <library_nodes><node id="shared"><translate>0 0 10</translate><instance_geometry url="#tri"/></node></library_nodes>
+  <library_visual_scenes><visual_scene id="Scene">
+    <node id="a"><matrix>1 0 0 1  0 1 0 2  0 0 1 3  0 0 0 1</matrix><instance_geometry url="#plate"/>
+      <node id="b"><rotate>0 0 1 90</rotate><scale>2 2 2</scale><instance_geometry url="#tri"/></node></node>
+    <node id="c"><instance_node url="#shared"/></node>
+  </visual_scene></library_visual_scenes>
+  <scene><instance_visual_scene url="#Scene"/></scene>
+</COLLADA>
+"""
+
+_OBJ = """# a quad and a triangle
+mtllib none.mtl
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+vn 0 0 1
+vt 0 0
+f 1/1/1 2/1/1 3/1/1 4/1/1
+v 0 0 2
+f -1 -4//1 -3
+l 1 2
+"""
+
+
+def _expected_dae(up_axis_to_y, apply_unit, up="Z_UP"):
+    plate = np.array([[0, 0, 0], [2, 0, 0], [2, 1, 0], [0, 1, 0.5]], np.float64)
+    tri = np.array([[0.25, 0, 0], [0, 0.5, 0], [0, 0, 0.75]], np.float64)
+    a = np.eye(4); a[:3, 3] = [1, 2, 3]
+    rot = np.array([[0, -1, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float64)
+    b = a @ rot @ np.diag([2.0, 2, 2, 1])
+    c = np.eye(4); c[2, 3] = 10
+    rootm = np.eye(4)
+    if up_axis_to_y and up == "Z_UP":
+        rootm = rootm @ np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]], np.float64)
+    if apply_unit:
+        rootm = rootm @ np.diag([0.0254, 0.0254, 0.0254, 1])
+    def tf(m, p):
+        return (rootm @ m @ np.c_[p, np.ones(len(p))].T).T[:, :3]
+    return np.concatenate([tf(a, plate[[0, 1, 2, 0, 2, 3]]), tf(b, tri), tf(c, tri)])
+
+
+def test_collada_import_node_transforms_up_axis_unit_and_polylist():
+    from realtime_urdf_filter_amd import meshes
+    for up_to_y, unit in ((True, False), (False, False), (True, True)):
+        v, t = meshes.load_collada((_DAE % {"up": "Z_UP"}).encode(), up_axis_to_y=up_to_y, apply_unit=unit)
+        assert v.dtype == np.float32 and v.shape == (12, 3) and np.array_equal(t, np.arange(12).reshape(4, 3))
+        np.testing.assert_allclose(v, _expected_dae(up_to_y, unit), rtol=0, atol=2e-6)
+    # the reference's behaviour for a Z_UP file (Assimp rotates the root to Y_UP): (x, y, z) -> (x, z, -y)
+    vz, _ = meshes.load_collada((_DAE % {"up": "Z_UP"}).encode(), up_axis_to_y=False)
+    vy, _ = meshes.load_collada((_DAE % {"up": "Z_UP"}).encode(), up_axis_to_y=True)
+    np.testing.assert_array_equal(vy, np.stack([vz[:, 0], vz[:, 2], -vz[:, 1]], axis=1))
+    vyy, _ = meshes.load_collada((_DAE % {"up": "Y_UP"}).encode(), up_axis_to_y=True)
+    np.testing.assert_array_equal(vyy, vz)
+    with pytest.raises(ValueError):
+        meshes.load_collada(b"<robot/>")
+    with pytest.raises(ValueError):
+        meshes.load_collada(b"<COLLADA><library_geometries/></COLLADA>")
+
+
+def test_obj_import_polygons_relative_indices_and_dispatch(tmp_path):
+    from realtime_urdf_filter_amd import meshes
+    v, t = meshes.load_obj(_OBJ.encode())
+    exp = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 2], [1, 0, 0], [1, 1, 0]], np.float32)
+    np.testing.assert_array_equal(v, exp)
+    assert np.array_equal(t, np.arange(9).reshape(3, 3))
+    with pytest.raises(ValueError):
+        meshes.load_obj(b"v 0 0 0\nf 1 2 3\n")
+    assert meshes.mesh_format("a/b/link.DAE", b"") == "collada" and meshes.mesh_format("x.obj", b"") == "obj" and meshes.mesh_format("x.STL", b"") == "stl"
+    assert meshes.mesh_format("noext", (_DAE % {"up": "Y_UP"}).encode()) == "collada" and meshes.mesh_format("noext", _OBJ.encode()) == "obj"
+    # through the resolver, all three formats
+    pkg = tmp_path / "ws" / "robot_description"
+    (pkg / "meshes").mkdir(parents=True)
+    (pkg / "meshes" / "l.dae").write_text(_DAE % {"up": "Z_UP"})
+    (pkg / "meshes" / "l.obj").write_text(_OBJ)
+    (pkg / "meshes" / "l.stl").write_bytes(G.write_binary_stl(exp, np.arange(9).reshape(3, 3)))
+    r = G.PackageResolver([str(tmp_path / "ws")])
+    assert r("package://robot_description/meshes/l.dae")[0].shape == (12, 3)
+    np.testing.assert_array_equal(r("package://robot_description/meshes/l.obj")[0], exp)
+    np.testing.assert_array_equal(r("package://robot_description/meshes/l.stl")[0], exp)
+    keep = G.PackageResolver([str(tmp_path / "ws")], up_axis_to_y=False)
+    assert not np.array_equal(keep("package://robot_description/meshes/l.dae")[0], r("package://robot_description/meshes/l.dae")[0])
+
+
+def test_cpp_mesh_import_matches_python_bit_for_bit(tmp_path):
+    """host.hpp load_mesh (what the C++ RenderableMesh calls) against meshes.py on the same files."""
+    import os
+    import subprocess
+    from realtime_urdf_filter_amd import meshes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "bin", "example_filter")
+    subprocess.check_call([os.path.join(root, "realtime_urdf_filter_amd", "csrc", "build_facade.sh")])
+    cases = []
+    for up in ("Z_UP", "Y_UP", "X_UP"):
+        f = tmp_path / ("m_%s.dae" % up)
+        f.write_text(_DAE % {"up": up})
+        cases += [(f, [], dict(up_axis_to_y=True, apply_unit=False)), (f, ["no-up"], dict(up_axis_to_y=False, apply_unit=False)),
+                  (f, ["unit"], dict(up_axis_to_y=True, apply_unit=True))]
+    fo = tmp_path / "m.obj"
+    fo.write_text(_OBJ)
+    cases.append((fo, [], {}))
+    fs = tmp_path / "m.stl"
+    fs.write_bytes(G.write_binary_stl(np.random.default_rng(3).standard_normal((9, 3)).astype(np.float32), np.arange(9).reshape(3, 3), header=b"solid quirk"))
+    cases.append((fs, [], {}))
+    for path, flags, kw in cases:
+        out = subprocess.check_output([exe, "--mesh", str(path)] + flags).decode().split()
+        nv, nt = int(out[0]), int(out[1])
+        got = np.array([int(h, 16) for h in out[2:]], np.uint32).view(np.float32).reshape(-1, 3)
+        v, t = meshes.load_mesh(str(path), path.read_bytes(), **kw)
+        assert (nv, nt) == (len(v), len(t))
+        np.testing.assert_array_equal(got.view(np.uint32), v.view(np.uint32), err_msg="%s %s" % (path, flags))
+    bad = tmp_path / "bad.dae"
+    bad.write_text("<COLLADA><library_geometries/></COLLADA>")
+    assert subprocess.run([exe, "--mesh", str(bad)], stdout=subprocess.PIPE).returncode == 1
