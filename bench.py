@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--u16", action="store_true", help="16UC1 depth in/out (uint16 millimetres) with the conversions fused into the kernels")
     ap.add_argument("--no-mask", action="store_true", help="need_mask_ == false: no mask output")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per leg (single thread, all cores); 0 disables")
+    ap.add_argument("--bin-capacity", type=int, default=0, help="rtuf_params.bin_capacity (records per tile bin; 0 = the library's default, grown on overflow)")
     ap.add_argument("--debug-flags", type=lambda x: int(x, 0), default=0, help="timing experiments only (needs the RTUF_ABLATE build; results are wrong)")
     ap.add_argument("--check-frames", type=int, default=4, help="frames of the last step verified against the oracle (per rank)")
     args = ap.parse_args()
@@ -125,6 +126,7 @@ def main():
     if args.two_kernel:
         p.flags |= R.FLAG_TWO_KERNEL
     p.flags |= args.debug_flags
+    p.bin_capacity = args.bin_capacity
     P = max(1, args.pipelines)
     p.pipelines = P if P > 1 else 0          # rtuf_params.pipelines: the library alternates the batches between P internal pipelines
     ctx = R.Context(W, H, n, local_rank, p)

@@ -198,8 +198,9 @@ struct rtuf_context {
       return (ctx)->fail(e_ == hipErrorOutOfMemory ? RTUF_ERR_OOM : RTUF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-// Setters whose staging buffers the batch in flight may still be reading (or would re-read on a bin
-// regrowth) wait for it; rtuf_set_joint_positions alone is double-buffered and never waits.
+// Setters of single-buffered state (model selection, parameters, forward-kinematics root poses / enable flags) wait for
+// the batches in flight, which may still read it (or would re-read it on a bin regrowth).  The per-frame pose setters --
+// joint positions, cameras, link matrices -- are staged in rings and never wait.
 #define WAIT_IF_PENDING(c) do { if ((c)->pending) { const int rc_ = rtuf_sync(c); if (rc_ != RTUF_OK) return rc_; } } while (0)
 
 // ---- pipelines: forwarding from the front context to its kids -------------------------------------------------

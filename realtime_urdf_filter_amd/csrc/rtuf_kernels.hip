@@ -1948,41 +1948,60 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(8)
 // compare_kernel (two-kernel mode): streaming, 13 B/pixel (4 sensor + 4 z + 4 masked + 1 mask)
 // ---------------------------------------------------------------------------------------
 
+#ifndef RTUF_CMP_UNROLL
+#define RTUF_CMP_UNROLL 1
+#endif
+constexpr int kCmpUnroll = RTUF_CMP_UNROLL;
 template <bool U16>
 __global__ __launch_bounds__(kBlock) void compare_kernel(CompareArgs a)
 {
   ShadeConsts sc;
   sc.num = a.sc_num; sc.off = a.sc_off; sc.max_diff = a.max_diff; sc.replace_value = a.replace_value;
   const size_t n4 = a.n_pixels >> 2;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
   const uint16_t* in16 = reinterpret_cast<const uint16_t*>(a.depth);
   uint16_t* out16 = reinterpret_cast<uint16_t*>(a.masked);
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float sv[4];
-    if (U16) {
-      const ushort4 q = reinterpret_cast<const ushort4*>(in16)[i];
-      sv[0] = u16_to_metres(q.x); sv[1] = u16_to_metres(q.y); sv[2] = u16_to_metres(q.z); sv[3] = u16_to_metres(q.w);
-    } else {
-      const float4 s = load_stream4(a.depth + 4 * i);
-      sv[0] = s.x; sv[1] = s.y; sv[2] = s.z; sv[3] = s.w;
-    }
-    const float4 z = load_stream4(a.zsurface + 4 * i);      // (the tile kernel's z stores stay temporal: this read may still find them in MALL)
-    const float zv[4] = {z.x, z.y, z.z, z.w};
-    float o[4];
-    uint32_t mbits = 0;
+  // No grid-stride loop: every workgroup takes kCmpUnroll * kBlock consecutive quads of pixels, so the workgroups in
+  // flight form ONE compact front through the four arrays (a strided loop over 32 k workgroups had every lane jump
+  // 134 MB per trip at 1,024 streams: 829 us instead of 640 for the same 4.09 GB).  All loads of a lane are issued
+  // before the first is used.
+  {
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x * kCmpUnroll + threadIdx.x;
+    const size_t stride = blockDim.x;
+    float sv[kCmpUnroll][4], zv[kCmpUnroll][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      bool f;
-      o[j] = shade(sv[j], zv[j], sc, f);
-      if (zv[j] != zv[j]) { o[j] = 0.0f; f = false; }
-      if (f) mbits |= 0xffu << (8 * j);
+    for (int u = 0; u < kCmpUnroll; u++) {
+      const size_t i = i0 + (size_t)u * stride;
+      if (i >= n4) break;
+      if (U16) {
+        const ushort4 q = reinterpret_cast<const ushort4*>(in16)[i];
+        sv[u][0] = u16_to_metres(q.x); sv[u][1] = u16_to_metres(q.y); sv[u][2] = u16_to_metres(q.z); sv[u][3] = u16_to_metres(q.w);
+      } else {
+        const float4 s = load_stream4(a.depth + 4 * i);
+        sv[u][0] = s.x; sv[u][1] = s.y; sv[u][2] = s.z; sv[u][3] = s.w;
+      }
+      const float4 z = load_stream4(a.zsurface + 4 * i);      // (the tile kernel's z stores stay temporal: this read may still find them in MALL)
+      zv[u][0] = z.x; zv[u][1] = z.y; zv[u][2] = z.z; zv[u][3] = z.w;
     }
-    if (U16) {
-      store_stream4(out16 + 4 * i, metres_to_u16(o[0]), metres_to_u16(o[1]), metres_to_u16(o[2]), metres_to_u16(o[3]));
-    } else {
-      store_stream4(a.masked + 4 * i, o[0], o[1], o[2], o[3]);
+#pragma unroll
+    for (int u = 0; u < kCmpUnroll; u++) {
+      const size_t i = i0 + (size_t)u * stride;
+      if (i >= n4) break;
+      float o[4];
+      uint32_t mbits = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        bool f;
+        o[j] = shade(sv[u][j], zv[u][j], sc, f);
+        if (zv[u][j] != zv[u][j]) { o[j] = 0.0f; f = false; }
+        if (f) mbits |= 0xffu << (8 * j);
+      }
+      if (U16) {
+        store_stream4(out16 + 4 * i, metres_to_u16(o[0]), metres_to_u16(o[1]), metres_to_u16(o[2]), metres_to_u16(o[3]));
+      } else {
+        store_stream4(a.masked + 4 * i, o[0], o[1], o[2], o[3]);
+      }
+      if (a.mask) __builtin_nontemporal_store(mbits, reinterpret_cast<uint32_t*>(a.mask) + i);
     }
-    if (a.mask) __builtin_nontemporal_store(mbits, reinterpret_cast<uint32_t*>(a.mask) + i);
   }
   // tail
   if (blockIdx.x == 0 && threadIdx.x < (a.n_pixels & 3)) {
@@ -2076,8 +2095,7 @@ void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st)
 void launch_compare(const CompareArgs& a, hipStream_t st)
 {
   size_t n4 = a.n_pixels >> 2;
-  size_t blocks = (n4 + kBlock - 1) / kBlock;
-  if (blocks > 32768) blocks = 32768;
+  size_t blocks = (n4 + (size_t)kBlock * kCmpUnroll - 1) / ((size_t)kBlock * kCmpUnroll);
   if (blocks == 0) blocks = 1;
   if (a.io_u16) hipLaunchKernelGGL(compare_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
   else hipLaunchKernelGGL(compare_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
