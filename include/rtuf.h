@@ -116,6 +116,10 @@ int rtuf_add_draw(rtuf_context *ctx, int model, int link, int pre_op, const floa
 int rtuf_finalize_models(rtuf_context *ctx);
 int rtuf_num_links(const rtuf_context *ctx, int model);
 int64_t rtuf_num_triangles(const rtuf_context *ctx);
+/* Vertices resident on the device after rtuf_finalize_models: per set-up chunk (<= 256 triangles) every distinct position
+ * once (bit-identical positions of one draw are merged: STL facets bring three vertices of their own each, which the
+ * reference uploads as they are, src/renderable.cpp:339-350; the image cannot tell), plus the background quad's four. */
+int64_t rtuf_num_vertices(const rtuf_context *ctx);
 
 /* Which models a stream renders (default: all).  Lets independent robots share a context
  * (BASELINE config 5); the reference renders every loaded model for its single stream. */

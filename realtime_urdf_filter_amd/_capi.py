@@ -22,7 +22,7 @@ ABI_VERSION = 3
 SYMBOLS = [
     "rtuf_default_params", "rtuf_abi_version", "rtuf_create", "rtuf_destroy", "rtuf_last_error",
     "rtuf_set_params", "rtuf_add_model", "rtuf_add_link", "rtuf_add_draw", "rtuf_finalize_models",
-    "rtuf_num_links", "rtuf_num_triangles", "rtuf_set_stream_models", "rtuf_set_camera",
+    "rtuf_num_links", "rtuf_num_triangles", "rtuf_num_vertices", "rtuf_set_stream_models", "rtuf_set_camera",
     "rtuf_projection_from_intrinsics", "rtuf_set_link_poses", "rtuf_set_cameras", "rtuf_set_camera_shift", "rtuf_set_link_poses_batch", "rtuf_set_kinematics", "rtuf_set_joint_positions", "rtuf_debug_read_poses", "rtuf_filter_batch",
     "rtuf_filter_batch_device", "rtuf_filter_batch_u16", "rtuf_filter_batch_device_u16", "rtuf_filter", "rtuf_get_masked_depth", "rtuf_get_mask", "rtuf_sync",
     "rtuf_stream", "rtuf_get_stats", "rtuf_enable_timing", "rtuf_debug_read_zsurface",
@@ -113,6 +113,8 @@ def load_library(path=None):
     lib.rtuf_num_links.argtypes = [vp, ci]
     lib.rtuf_num_triangles.argtypes = [vp]
     lib.rtuf_num_triangles.restype = ctypes.c_int64
+    lib.rtuf_num_vertices.argtypes = [vp]
+    lib.rtuf_num_vertices.restype = ctypes.c_int64
     lib.rtuf_set_stream_models.argtypes = [vp, ci, vp, ci]
     lib.rtuf_set_camera.argtypes = [vp, ci, vp, vp, vp]
     lib.rtuf_projection_from_intrinsics.argtypes = [cd, cd, cd, cd, cd, cd, ci, ci, cd, cd, vp, vp, vp]
@@ -224,6 +226,9 @@ class Context:
 
     def num_triangles(self):
         return int(self._lib.rtuf_num_triangles(self._h))
+
+    def num_vertices(self):
+        return int(self._lib.rtuf_num_vertices(self._h))
 
     def set_stream_models(self, stream, model_ids):
         m = np.ascontiguousarray(model_ids, np.int32)

@@ -13,6 +13,7 @@
 #include <deque>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "rtuf.h"
@@ -77,7 +78,7 @@ struct rtuf_context {
   bool finalized = false;
   bool broken = false;                 // a bin regrowth failed half-way: the bins are gone, every later filter call fails
   int n_links = 0, n_draws = 0, n_chunks = 0;
-  int64_t n_tris = 0;
+  int64_t n_tris = 0, n_cverts = 0;
   uint32_t bg_chunk = 0;
 
   // static geometry (device)
@@ -446,6 +447,7 @@ int rtuf_num_links(const rtuf_context* c, int model)
 }
 
 int64_t rtuf_num_triangles(const rtuf_context* c) { return c ? (c->kids.empty() ? c->n_tris : c->kids[0]->n_tris) : 0; }
+int64_t rtuf_num_vertices(const rtuf_context* c) { return c ? (c->kids.empty() ? c->n_cverts : c->kids[0]->n_cverts) : 0; }
 
 static int alloc_frame_buffers(rtuf_context* c)
 {
@@ -536,6 +538,21 @@ int rtuf_finalize_models(rtuf_context* c)
   // test's tie-break is the GL draw order, so every triangle keeps its original sequence number (corder).
   auto add_chunks = [&](const std::vector<float>& v, const std::vector<uint32_t>& t, uint32_t draw_id, uint32_t model, bool background) {
     const uint32_t nt = (uint32_t)(t.size() / 3);
+    // Vertices with bit-identical coordinates are one vertex here: STL (and Assimp's importers in general) bring three
+    // vertices of their own per facet, and the vertex shader gives identical inputs identical results, so the image
+    // cannot change -- but a chunk then transforms ~0.5 instead of 3 vertices per triangle and holds 256 triangles.
+    std::vector<uint32_t> canon(v.size() / 3);
+    {
+      struct Key { uint32_t x, y, z; bool operator==(const Key& o) const { return x == o.x && y == o.y && z == o.z; } };
+      struct KeyHash { size_t operator()(const Key& k) const { uint64_t h = k.x * 0x9E3779B97F4A7C15ull; h ^= (h >> 29) + k.y * 0xC2B2AE3D27D4EB4Full; h ^= (h >> 31) + k.z * 0x165667B19E3779F9ull; return (size_t)(h ^ (h >> 32)); } };
+      std::unordered_map<Key, uint32_t, KeyHash> first;
+      first.reserve(canon.size());
+      for (uint32_t i = 0; i < (uint32_t)canon.size(); i++) {
+        Key k;
+        memcpy(&k, &v[3 * (size_t)i], sizeof k);
+        canon[i] = first.emplace(k, i).first->second;
+      }
+    }
     std::vector<int32_t> local(v.size() / 3, -1);
     std::vector<uint32_t> touched;
     std::vector<uint32_t> perm(nt);
@@ -570,7 +587,7 @@ int rtuf_finalize_models(rtuf_context* c)
       touched.clear();
       uint32_t nv = 0, n = 0;
       while (done + n < nt && n < (uint32_t)kBlock) {
-        const uint32_t* ix = &t[3 * (size_t)perm[done + n]];
+        const uint32_t ix[3] = {canon[t[3 * (size_t)perm[done + n]]], canon[t[3 * (size_t)perm[done + n] + 1]], canon[t[3 * (size_t)perm[done + n] + 2]]};
         uint32_t fresh = 0;
         for (int k = 0; k < 3; k++) {
           bool seen = local[ix[k]] >= 0;
@@ -644,6 +661,7 @@ int rtuf_finalize_models(rtuf_context* c)
     add_chunks(bv, bt, (uint32_t)c->n_draws, 0, true);
   }
   c->n_chunks = (int)chunks.size();
+  c->n_cverts = (int64_t)cverts.size();
   if (draws.empty()) draws.push_back(Draw{});
   HIP_TRY(c, hipMalloc(&c->d_cverts, cverts.size() * sizeof(float4)));
   HIP_TRY(c, hipMalloc(&c->d_ctris, ctris.size() * sizeof(uint32_t)));

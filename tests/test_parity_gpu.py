@@ -1222,3 +1222,36 @@ def test_staging_next_link_matrices_while_batches_are_in_flight(cap):
             assert np.array_equal(ok, mask[s]) and bits_equal(om, masked[s]), (cap, k, s)
     assert (ctx.stats()["regrowths"] > 0) == (cap == 16)
     ctx.close()
+
+
+def test_stl_facets_are_welded_at_load_and_the_image_does_not_change():
+    """BASELINE config 2 names STL meshes: every facet brings three vertices of its own (so does everything else Assimp
+    imports for the reference, src/renderable.cpp:352-415).  rtuf_finalize_models merges bit-identical positions, so the
+    de-indexed model costs the set-up kernel no more vertex work than the indexed one -- and renders the same image."""
+    from realtime_urdf_filter_amd import geometry as G
+    wl = WL.pr2_workload(3, 640, 480, total_triangles=20000)
+    outs, verts = [], []
+    for stl in (False, True):
+        ctx = R.Context(640, 480, 3, 0, params(wl.replace_value, wl.max_diff))
+        ids = []
+        for links in wl.models:
+            m = ctx.add_model()
+            for draws in links:
+                l = ctx.add_link(m)
+                for d in draws:
+                    v, t = (G.load_stl(G.write_binary_stl(d.verts, d.tris)) if stl and len(d.tris) else (d.verts, d.tris))
+                    if stl and len(d.tris):
+                        assert len(v) == 3 * len(t)
+                    ctx.add_draw(m, l, v, t, d.pre_op, d.op)
+            ids.append(m)
+        ctx.finalize_models()
+        wl.stage(ctx, ids)
+        depth = wl.depth_batch()
+        outs.append(ctx.filter_batch(depth))
+        verts.append(ctx.num_vertices())
+        assert ctx.num_triangles() == wl.n_triangles()
+        ctx.close()
+    assert verts[0] == verts[1] and verts[0] < 0.8 * wl.n_triangles()            # ~0.5-0.6 vertices per triangle, not 3
+    assert bits_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    om, ok = O.filter_frame(depth[1], wl.projection[1], wl.oracle_draws(1), wl.offset_inv[1], wl.cam_tf[1], max_diff=wl.max_diff, replace_value=wl.replace_value)
+    assert (ok != outs[1][1][1]).sum() == 0 and bits_equal(om, outs[1][0][1])
