@@ -227,7 +227,6 @@ class XmlParser {
     size_t b = p_;
     while (p_ < s_.size() && name_char(s_[p_])) p_++;
     n.tag = s_.substr(b, p_ - b);
-    { const size_t colon = n.tag.find(':'); if (colon != std::string::npos) n.tag = n.tag.substr(colon + 1); }   // namespace prefix
     for (;;) {
       skip_ws();
       if (p_ >= s_.size()) throw std::runtime_error("XML: unterminated tag <" + n.tag);
@@ -737,6 +736,12 @@ inline ColladaGeometry collada_read_geometry(const XmlNode& geom)
   g.ok = true;
   return g;
 }
+inline void strip_namespace_prefixes(XmlNode& n)          // <dae:mesh> -> <mesh> (only here: URDFs carry prefixed extension tags that must stay apart)
+{
+  const size_t colon = n.tag.find(':');
+  if (colon != std::string::npos) n.tag = n.tag.substr(colon + 1);
+  for (auto& c : n.children) strip_namespace_prefixes(c);
+}
 inline void collect_library_nodes(const XmlNode& n, std::map<std::string, const XmlNode*>& out)
 {
   for (const auto& c : n.children) {
@@ -754,6 +759,7 @@ inline bool load_collada(const std::string& data, std::vector<float>& verts, std
   XmlNode root;
   try {
     root = XmlParser(data).parse_document();
+    strip_namespace_prefixes(root);
     if (root.tag != "COLLADA") return false;
     std::string up = "Y_UP";
     double meter = 1.0;
