@@ -105,6 +105,7 @@ struct rtuf_context {
   int group = 0;                       // in-flight streams per launch group
   uint32_t capacity = 0, fcapacity = 0, clip_capacity = 0;
   PackedTri* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr; uint32_t items_hint = 0;
+  BigRec* d_big_list = nullptr; uint32_t big_capacity = 0;      // many-tile records (per counter shard), see bigrec_kernel
   Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
   float* d_zsurface = nullptr;
 
@@ -317,7 +318,7 @@ static void free_frame_buffers(rtuf_context* c)
   auto hfree = [](auto*& p) { if (p) { hipHostFree(p); p = nullptr; } };
   dfree(c->d_model_mask);
   for (auto& b : c->batch) { dfree(b.d_cams); dfree(b.d_link_tf); dfree(b.d_mvp); dfree(b.d_bg); dfree(b.d_items); dfree(b.d_counters); }
-  dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_zsurface);
+  dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_big_list); dfree(c->d_zsurface);
   for (auto& b : c->batch) { dfree(b.st_depth); dfree(b.st_masked); dfree(b.st_mask); b.st_streams = 0; dfree(b.st_bits); b.st_bits_streams = 0; }
   for (auto*& p : c->ring_cams) hfree(p);
   for (auto*& p : c->ring_link_tf) hfree(p);
@@ -514,6 +515,8 @@ static int alloc_frame_buffers(rtuf_context* c)
   HIP_TRY(c, hipMalloc(&c->d_fbin_count, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(c->d_fbin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
+  c->big_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 64, 4096), (size_t)1 << 20);                 // per shard
+  HIP_TRY(c, hipMalloc(&c->d_big_list, (size_t)c->big_capacity * kCounterShards * sizeof(BigRec)));
   for (auto& b : c->batch) HIP_TRY(c, hipMalloc(&b.d_items, (size_t)c->n_chunks * (size_t)max_items_per_chunk(G) * sizeof(WorkItem)));
   if (c->params.flags & RTUF_FLAG_TWO_KERNEL)
     HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)G * c->width * c->height * sizeof(float)));
@@ -1058,6 +1061,7 @@ static int issue_plan(rtuf_context* c, rtuf_context::Batch& b, const BatchPlan& 
     b.setup_grid = single_group ? grid : 0xffffffffu;
     if (b.timing >= 2) hipEventRecord(get_event(b, ev++), st);
     launch_clip(gr.sa, st);
+    launch_bigrec(gr.sa, st);            // appends the many-tile records the two kernels above listed
     if (b.timing) hipEventRecord(get_event(b, ev++), st);
     launch_tile(gr.ta, two, st);
     if (b.timing) hipEventRecord(get_event(b, ev++), st);
@@ -1161,7 +1165,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     sa.cverts = c->d_cverts; sa.ctris = c->d_ctris; sa.corder = c->d_corder; sa.chunks = c->d_chunks; sa.mvp = b.d_mvp;
     sa.model_mask = c->d_model_mask; sa.bg = b.d_bg; sa.bins = c->d_bins; sa.bin_count = c->d_bin_count;
     sa.fbins = c->d_fbins; sa.fbin_count = c->d_fbin_count; sa.fcapacity = c->fcapacity;
-    sa.clip_list = c->d_clip_list; sa.counters = b.d_counters; sa.group_base = base; sa.group_size = gs;
+    sa.clip_list = c->d_clip_list; sa.big_list = c->d_big_list; sa.big_capacity = c->big_capacity; sa.counters = b.d_counters; sa.group_base = base; sa.group_size = gs;
     sa.n_draws = c->n_draws; sa.width = c->width; sa.height = c->height; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
     sa.capacity = c->capacity; sa.clip_capacity = c->clip_capacity; sa.bg_chunk = c->bg_chunk;
     sa.items = b.d_items; sa.n_chunks = c->n_chunks; sa.flags = c->params.flags;
@@ -1282,13 +1286,14 @@ static int retire_oldest(rtuf_context* c)
     rtuf_context::Batch& b = c->batch[c->oldest];
     if (!c->pending || !b.active) { c->pending = 0; return RTUF_OK; }
     HIP_TRY(c, hipEventSynchronize(b.done));
-    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0; unsigned max_bin_fill = 0, max_fbin_fill = 0, clip_overflow = 0, uncovered = 0; } k;
+    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0; unsigned max_bin_fill = 0, max_fbin_fill = 0, clip_overflow = 0, uncovered = 0, max_big_fill = 0; } k;
     c->items_hint = b.h_counters->work.n_items;      // sizes the next batches' set-up grid
     for (int i = 0; i < kCounterShards; i++) {
       const CounterShard& sh = b.h_counters->shard[i];
       k.tris_binned += sh.tris_binned; k.bin_entries += sh.bin_entries; k.clip_count += sh.clip_count;
       k.max_bin_fill = std::max(k.max_bin_fill, sh.max_bin_fill); k.clip_overflow |= sh.clip_overflow;
       k.max_fbin_fill = std::max(k.max_fbin_fill, sh.max_fbin_fill); k.frags += sh.frags; k.uncovered |= sh.uncovered;
+      k.max_big_fill = std::max(k.max_big_fill, sh.max_big_fill);
     }
     c->stats.triangles_submitted = (uint64_t)c->n_tris * (uint64_t)b.n;
     c->stats.triangles_binned = k.tris_binned;
@@ -1300,9 +1305,10 @@ static int retire_oldest(rtuf_context* c)
     c->stats.max_fbin_fill = k.max_fbin_fill;
     const bool bin_over = k.max_bin_fill > c->capacity || k.max_fbin_fill > c->fcapacity;
     const bool clip_over = k.clip_overflow != 0;
+    const bool big_over = k.max_big_fill > c->big_capacity;
     const bool list_over = b.h_counters->work.n_items > b.setup_grid;     // the set-up grid was sized too small
     if (list_over) c->stats.regrowths++;
-    if (!bin_over && !clip_over && !list_over) {
+    if (!bin_over && !clip_over && !list_over && !big_over) {
       if (b.host_io) HIP_TRY(c, hipEventSynchronize(b.downloaded));
       if (b.timing == 1 && b.events.size() >= 2) {
         // events: [start, pose_end, (setup_end, tile_end, compare_end) per group ...]
@@ -1355,6 +1361,12 @@ static int retire_oldest(rtuf_context* c)
       hipFree(c->d_clip_list); c->d_clip_list = nullptr;
       c->clip_capacity *= 4;
       HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
+      c->stats.regrowths++;
+    }
+    if (big_over) {
+      hipFree(c->d_big_list); c->d_big_list = nullptr;
+      while (c->big_capacity < k.max_big_fill) c->big_capacity *= 2;
+      HIP_TRY(c, hipMalloc(&c->d_big_list, (size_t)c->big_capacity * kCounterShards * sizeof(BigRec)));
       c->stats.regrowths++;
     }
     const size_t tiles = (size_t)c->tiles_x * c->tiles_y;

@@ -79,6 +79,16 @@ struct alignas(16) PackedTri {  // 32 B: what a triangle bin stores; the tile ke
 };
 static_assert(sizeof(PackedTri) == 32, "PackedTri must be 32 bytes");
 
+// A record whose bounding box touches more than kCoopTiles tiles is not appended to its bins by the lane that made it
+// (a wave with a run of wall triangles would append hundreds of (record, tile) pairs one record after the other while
+// the rest of the GPU idles): set-up and clip kernel put it on a list, bigrec_kernel gives every list entry a wave.
+struct alignas(16) BigRec {
+  PackedTri pk;
+  uint32_t slot;                // stream slot within the in-flight group
+  uint32_t pad[3];
+};
+static_assert(sizeof(BigRec) == 48, "BigRec is three 16-byte stores");
+
 // 8 B: one covered pixel of a small (<= 4x4 pixel centres, single tile) triangle, ready for the depth
 // test:  z24 << 40 | order << kFragPosBits | position in the tile (y * kTileW + x).
 // Fragments carry no z plane, so triangles that may win with window z <= 0.5 (where the float z the
@@ -145,7 +155,9 @@ struct alignas(128) CounterShard {
   unsigned int max_fbin_fill;
   unsigned long long frags;
   unsigned int uncovered;       // mask-bits output only: some pixel was reached by no fragment (see rtuf_filter_batch_bits*)
-  unsigned int pad[21];
+  unsigned int big_count;       // entries in this shard's segment of big_list (reset per in-flight group)
+  unsigned int max_big_fill;    // largest big_count of the batch's groups (overflow detection)
+  unsigned int pad[19];
 };
 static_assert(sizeof(CounterShard) == 128, "CounterShard must be one 128-byte line");
 struct alignas(128) WorkCount { unsigned int n_items; unsigned int pad[31]; };
@@ -214,6 +226,8 @@ struct SetupArgs {
   uint32_t* fbin_count;          // [G][tiles]
   uint32_t fcapacity;
   ClipItem* clip_list;
+  BigRec* big_list;              // [kCounterShards][big_capacity]  many-tile records, appended to their bins by bigrec_kernel
+  uint32_t big_capacity;         // per shard segment
   WorkItem* items;               // [n_chunks * ceil(group / kStreamsPerBlock)] visible (chunk, streams) jobs of this group
   Counters* counters;
   int n_chunks;
@@ -281,6 +295,7 @@ void launch_pose(const PoseArgs& a, hipStream_t st);
 void launch_cull(const SetupArgs& a, hipStream_t st);
 uint32_t launch_setup(const SetupArgs& a, uint32_t items_hint, bool sweep, hipStream_t st);    // returns the main grid size
 void launch_clip(const SetupArgs& a, hipStream_t st);
+void launch_bigrec(const SetupArgs& a, hipStream_t st);
 void launch_reset_clip(Counters* c, hipStream_t st);
 void launch_publish_counters(const Counters* src, Counters* host_dst, hipStream_t st);
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st);   // a.io_u16 selects the 16UC1 variant

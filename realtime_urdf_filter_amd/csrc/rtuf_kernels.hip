@@ -12,6 +12,8 @@
 //                   32-B records, binned per 64x32 tile
 //   clip_kernel     the few triangles that cross a frustum plane:         (GL driver clipper)
 //                   Sutherland-Hodgman in clip space, fan, same set-up
+//   bigrec_kernel   one wave per record that touches more than 4 tiles:   (binning: no counterpart in the reference)
+//                   appends it to the bins of the tiles it really touches
 //   tile_kernel     one workgroup per (stream, 64x32 tile): the tile's    replaces GL rasterisation + 24-bit
 //                   depth keys live in LDS, fragments resolve with        GL_LESS depth test + urdf_filter.frag
 //                   64-bit LDS atomicMin, then the per-pixel compare      + glGetTexImage conversions
@@ -554,93 +556,33 @@ __device__ __forceinline__ void store_record(PackedTri* dst, const PackedTri& r)
   d[0] = s[0]; d[1] = s[1];
 }
 
-// Records whose bounding box touches more than kCoopTiles tiles (the robot's own arm in front of
-// the camera, clipped near-plane triangles) are appended cooperatively: one triangle at a time is
-// broadcast to the wave and the 64 lanes take one tile each, so a 7x7-tile triangle costs one
-// atomic round trip instead of 49 serial ones in a single lane.
-constexpr int kCoopTiles = 4;
+// Records whose bounding box touches more than kCoopTiles tiles (the robot's own arm in front of the camera, clipped
+// near-plane triangles, walls) are not appended to their bins here: they go on the shard's big-record list (one
+// reservation per wave), and bigrec_kernel appends every list entry with a wave of its own.  Appending them where they
+// are made costs a wave one atomic round trip per record, and such records come in runs (a wall's fan: hundreds of
+// (record, tile) pairs in a handful of waves while the rest of the GPU has finished).
+constexpr int kCoopTiles = 4;            // (8: the same; 2: +20 us of bigrec_kernel; 1: every straddling record on the lists, 0.5 ms)
 #ifndef RTUF_FRONT_AREA
 #define RTUF_FRONT_AREA 24
 #endif
 constexpr int kFrontArea = RTUF_FRONT_AREA;      // boxes up to this many pixel centres are binned from the front of a bin
-// `edges` (clip kernel only: it has the integer edge functions at hand) additionally drops the tiles of the bounding box
-// that the triangle does not touch at all -- an edge function is largest at one corner of the tile's part of the box; not
-// positive there means no pixel centre of that tile is covered (half of the tiles of a clipped wall's box): the tile
-// kernel would classify such a record away anyway, so the image is the same with fewer bin entries.  Every lane takes up
-// to four tiles per round and issues their (independent) slot reservations back to back before the first store needs its
-// answer: a 460-tile wall at 720p costs two atomic round trips instead of eight.
-__device__ __forceinline__ uint32_t emit_big_records_wave(const SetupArgs& a, int slot, bool big, uint32_t bbx, uint32_t bby,
-                                                          const PackedTri& pk, const TriRec* edges = nullptr)
+__device__ __forceinline__ void list_big_records_wave(const SetupArgs& a, int slot, bool big, const PackedTri& pk)
 {
   const int lane = threadIdx.x & 63;
-  const int tiles = a.tiles_x * a.tiles_y;
-  uint32_t n = 0;
-  unsigned long long todo = __ballot(big);
-  while (todo) {
-    const int src = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
-    PackedTri q;
-    {
-      const int* sp = reinterpret_cast<const int*>(&pk);
-      int* dp = reinterpret_cast<int*>(&q);
-#pragma unroll
-      for (int k = 0; k < 8; k++) dp[k] = __builtin_amdgcn_readlane(sp[k], src);
+  const unsigned long long bm = __ballot(big);
+  const int shard_id = (int)(blockIdx.x % kCounterShards);
+  const int leader = __ffsll((long long)bm) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(&a.counters->shard[shard_id].big_count, (uint32_t)__popcll(bm));
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+  if (big) {
+    const uint32_t idx = base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+    if (idx < a.big_capacity) {          // (an over-full list is detected from the counter and the batch run again)
+      uint4* dst = reinterpret_cast<uint4*>(a.big_list + (size_t)shard_id * a.big_capacity + idx);
+      const uint4* src = reinterpret_cast<const uint4*>(&pk);
+      dst[0] = src[0]; dst[1] = src[1]; dst[2] = make_uint4((uint32_t)slot, 0u, 0u, 0u);
     }
-    int eA[3] = {0, 0, 0}, eB[3] = {0, 0, 0}, eC[3] = {0, 0, 0};
-    if (edges) {
-#pragma unroll
-      for (int e = 0; e < 3; e++) {
-        eA[e] = __builtin_amdgcn_readlane(edges->A[e], src);
-        eB[e] = __builtin_amdgcn_readlane(edges->B[e], src);
-        eC[e] = __builtin_amdgcn_readlane(edges->C[e], src);
-      }
-    }
-    const uint32_t qx = (uint32_t)__builtin_amdgcn_readlane((int)bbx, src), qy = (uint32_t)__builtin_amdgcn_readlane((int)bby, src);
-    const int qslot = __builtin_amdgcn_readlane(slot, src);
-    const int bx0 = (int)(qx & 0xffff), bx1 = (int)(qx >> 16), by0 = (int)(qy & 0xffff), by1 = (int)(qy >> 16);
-    const int tx0 = bx0 / kTileW, tx1 = bx1 / kTileW;
-    const int ty0 = by0 / kTileH, ty1 = by1 / kTileH;
-    const int tw = tx1 - tx0 + 1, ntile = tw * (ty1 - ty0 + 1);
-    uint32_t mine = 0;
-    constexpr int kPerRound = 4;
-    for (int k0 = lane; k0 < ntile; k0 += 64 * kPerRound) {
-      int bin[kPerRound];
-      uint32_t pos[kPerRound];
-#pragma unroll
-      for (int j = 0; j < kPerRound; j++) {
-        const int k = k0 + 64 * j;
-        bin[j] = -1;
-        pos[j] = 0;
-        if (k < ntile) {
-          const int row = k / tw, tx = tx0 + k - row * tw, ty = ty0 + row;
-          bool touches = true;
-          if (edges) {
-            // the tile's part of the box, in pixel-centre coordinates
-            const int x0 = max(bx0, tx * kTileW), x1 = min(bx1, tx * kTileW + kTileW - 1);
-            const int y0 = max(by0, ty * kTileH), y1 = min(by1, ty * kTileH + kTileH - 1);
-#pragma unroll
-            for (int e = 0; e < 3; e++) {
-              const int xa = eA[e] > 0 ? x1 : x0, ya = eB[e] > 0 ? y1 : y0;
-              touches = touches && (__mul24(eA[e], xa) + __mul24(eB[e], ya) + eC[e]) > 0;
-            }
-          }
-          if (touches) {
-            bin[j] = __mul24(qslot, tiles) + __mul24(ty, a.tiles_x) + tx;
-            pos[j] = atomicAdd(&a.bin_count[2 * bin[j] + 1], 1u);          // many-tile records are large: back of the bin
-            mine++;
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < kPerRound; j++)
-        if (bin[j] >= 0 && pos[j] < a.capacity) store_record(a.bins + (size_t)bin[j] * a.capacity + (a.capacity - 1u - pos[j]), q);
-    }
-    // the record's owner accounts for the entries of all lanes
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off);
-    if (lane == src) n += mine;
   }
-  return n;
 }
 
 // Wave-cooperative form: all 64 lanes call it; lanes with `have` own a record.  Lanes that
@@ -648,8 +590,7 @@ __device__ __forceinline__ uint32_t emit_big_records_wave(const SetupArgs& a, in
 // atomicAdd in the SAME instruction, so a wave pays one atomic round trip per tile index
 // instead of one per distinct bin; group members get consecutive slots, which makes the
 // 32-byte record stores of neighbouring mesh triangles contiguous.
-__device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slot, bool have, uint32_t bbx, uint32_t bby, const PackedTri& pk,
-                                                     const TriRec* edges = nullptr)
+__device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slot, bool have, uint32_t bbx, uint32_t bby, const PackedTri& pk)
 {
   const int lane = threadIdx.x & 63;
   int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
@@ -664,7 +605,7 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slo
   // lane-per-triangle walk runs as long as the largest box in the wave).
   const int cls = ((int)(bbx >> 16) - (int)(bbx & 0xffff) + 1) * ((int)(bby >> 16) - (int)(bby & 0xffff) + 1) > kFrontArea ? 1 : 0;
   const bool big = have && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kCoopTiles;
-  if (__ballot(big)) n += emit_big_records_wave(a, slot, big, bbx, bby, pk, edges);
+  if (__ballot(big)) list_big_records_wave(a, slot, big, pk);          // (their bin entries are counted by bigrec_kernel)
   have = have && !big;
   int tx = tx0, ty = ty0;                  // walks the touched tiles row by row
   for (;;) {
@@ -1215,9 +1156,6 @@ __device__ __forceinline__ float clipdist(const float* c, int plane)
   return s;
 }
 
-#ifndef RTUF_CLIP_RUN
-#define RTUF_CLIP_RUN 16
-#endif
 constexpr int kClipBlock = 128;          // threads per clip workgroup (48 KB of LDS polygon storage)
 constexpr int kClipMaxV = 16;            // clip-space vertices per triangle: 3 + at most 2 new ones per frustum plane (+1 spare)
 constexpr int kClipMaxP = 12;            // polygon vertices (5-bit pool indices packed in one 64-bit register)
@@ -1325,7 +1263,7 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
       wprev = wi;
     }
     binned += have ? 1u : 0u;
-    if (__ballot(have) && !RTUF_ABL(a.flags, 0x800000u)) entries += emit_record_wave(a, slot, have, r.bbx, r.bby, pk, &r);      // (0x800000: timing experiment)
+    if (__ballot(have) && !RTUF_ABL(a.flags, 0x800000u)) entries += emit_record_wave(a, slot, have, r.bbx, r.bby, pk);      // (0x800000: timing experiment)
   }
   // statistics: one atomic pair per wave (per-lane atomics on a shard's counters serialise at one L2
   // atomic unit -- that alone used to be three quarters of this kernel's time)
@@ -1344,20 +1282,16 @@ __global__ __launch_bounds__(kClipBlock) void clip_kernel(SetupArgs a)
   const uint32_t n = min(a.counters->shard[shard_id].clip_count, a.clip_capacity);
   const uint32_t per = gridDim.x / kCounterShards;
   const ClipItem* list = a.clip_list + (size_t)shard_id * a.clip_capacity;
-  // Items are dealt out in runs of kClipRun over the shard's workgroups (run r -> workgroup r % per).  Neighbouring list
-  // entries come from the same chunk and stream: keeping a few together keeps the item, vertex and matrix loads of a
-  // wave on shared cache lines; but the expensive items (wall triangles whose fans each touch hundreds of tiles) come in
-  // long runs too, and whole blocks of 128 items would hand such a run to one workgroup, which then emits its
-  // many-tile records one after the other while the rest of the GPU has finished.
-  // Only as many workgroups as the list needs take part (the grid is fixed, the list length lives on the device), so
-  // that the waves stay densely filled: the cooperative emission costs per wave, not per lane.
-  // (A list that needs every workgroup for several passes is balanced by its volume: whole blocks then, for locality.)
+  // Whole blocks of consecutive list entries per workgroup: neighbours come from the same chunk and stream, so the item,
+  // vertex and matrix loads of a wave share cache lines.  (While many-tile records were appended right here, runs of
+  // wall triangles had to be dealt out 16 at a time over the workgroups; with bigrec_kernel doing those appends whole
+  // blocks are the faster order again.)  Only as many workgroups as the list needs take part: the grid is fixed, the
+  // list length lives on the device.
   const uint32_t wg = blockIdx.x / kCounterShards;
   const uint32_t used = min(per, (n + blockDim.x - 1) / blockDim.x);
   if (wg >= used) return;
-  const uint32_t kClipRun = used < per ? (uint32_t)RTUF_CLIP_RUN : blockDim.x;
   for (uint32_t base = 0; base < n; base += used * blockDim.x) {
-    const uint32_t i = base + ((threadIdx.x / kClipRun) * used + wg) * kClipRun + threadIdx.x % kClipRun;          // whole waves stay in the loop (cooperative emission)
+    const uint32_t i = base + wg * blockDim.x + threadIdx.x;          // whole waves stay in the loop (cooperative emission)
     ClipItem it; it.slot = 0; it.draw = 0; it.vert_begin = 0; it.packed = 0; it.order = 0;
     if (i < n) {
       const uint4* src = reinterpret_cast<const uint4*>(&list[i]);
@@ -1366,6 +1300,77 @@ __global__ __launch_bounds__(kClipBlock) void clip_kernel(SetupArgs a)
     }
     clip_one(a, it, shard_id, s_pool, i < n);
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// bigrec_kernel: one wave per many-tile record of the shards' lists.  The wave rebuilds the record's edge functions
+// (uniform work, as in the tile kernel), spreads the tiles of its bounding box over the lanes, drops the tiles the
+// triangle does not touch at all -- an edge function is largest at one corner of the tile's part of the box; not positive
+// there means no pixel centre of that tile is covered (half of the tiles of a clipped wall's box): the tile kernel would
+// classify such a record away anyway, so the image is the same with fewer bin entries -- and appends the record to the
+// back of the others' bins.  Up to four slot reservations per lane are in flight before the first store needs its answer.
+// ---------------------------------------------------------------------------------------
+constexpr int kBigWavesPerShard = 64;     // (32 / 128 waves per shard, 2 / 8 reservations in flight per lane: no difference)
+__global__ __launch_bounds__(256) void bigrec_kernel(SetupArgs a)
+{
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const int shard_id = wave % kCounterShards, first = wave / kCounterShards;
+  CounterShard& shard = a.counters->shard[shard_id];
+  const uint32_t count = shard.big_count;
+  if (first == 0 && lane == 0 && count > shard.max_big_fill) shard.max_big_fill = count;      // (this wave alone writes the field)
+  const uint32_t n = min(count, a.big_capacity);
+  const int tiles = a.tiles_x * a.tiles_y;
+  uint32_t mine = 0;
+  for (uint32_t j = (uint32_t)first; j < n; j += kBigWavesPerShard) {
+    const BigRec* rec = a.big_list + (size_t)shard_id * a.big_capacity + j;
+    PackedTri q;
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(rec);
+      uint4* dst = reinterpret_cast<uint4*>(&q);
+      dst[0] = src[0]; dst[1] = src[1];
+    }
+    const int qslot = (int)rec->slot;
+    const TriRec r = unpack_record(q, a.width, a.height);
+    const int bx0 = (int)(r.bbx & 0xffff), bx1 = (int)(r.bbx >> 16), by0 = (int)(r.bby & 0xffff), by1 = (int)(r.bby >> 16);
+    const int tx0 = bx0 / kTileW, tx1 = bx1 / kTileW;
+    const int ty0 = by0 / kTileH, ty1 = by1 / kTileH;
+    const int tw = tx1 - tx0 + 1, ntile = tw * (ty1 - ty0 + 1);
+    constexpr int kPerRound = 4;
+    for (int k0 = lane; k0 < ntile; k0 += 64 * kPerRound) {
+      int bin[kPerRound];
+      uint32_t pos[kPerRound];
+#pragma unroll
+      for (int jj = 0; jj < kPerRound; jj++) {
+        const int k = k0 + 64 * jj;
+        bin[jj] = -1;
+        pos[jj] = 0;
+        if (k < ntile) {
+          const int row = k / tw, tx = tx0 + k - row * tw, ty = ty0 + row;
+          // the tile's part of the box, in pixel-centre coordinates
+          const int x0 = max(bx0, tx * kTileW), x1 = min(bx1, tx * kTileW + kTileW - 1);
+          const int y0 = max(by0, ty * kTileH), y1 = min(by1, ty * kTileH + kTileH - 1);
+          bool touches = true;
+#pragma unroll
+          for (int e = 0; e < 3; e++) {
+            const int xa = r.A[e] > 0 ? x1 : x0, ya = r.B[e] > 0 ? y1 : y0;
+            touches = touches && (__mul24(r.A[e], xa) + __mul24(r.B[e], ya) + r.C[e]) > 0;
+          }
+          if (touches) {
+            bin[jj] = __mul24(qslot, tiles) + __mul24(ty, a.tiles_x) + tx;
+            pos[jj] = atomicAdd(&a.bin_count[2 * bin[jj] + 1], 1u);          // many-tile records are large: back of the bin
+            mine++;
+          }
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < kPerRound; jj++)
+        if (bin[jj] >= 0 && pos[jj] < a.capacity) store_record(a.bins + (size_t)bin[jj] * a.capacity + (a.capacity - 1u - pos[jj]), q);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_down((int)mine, off);
+  if (lane == 0 && mine) atomicAdd(&shard.bin_entries, (unsigned long long)mine);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2030,7 +2035,7 @@ __global__ void publish_counters_kernel(const Counters* __restrict__ src, Counte
 __global__ void reset_clip_kernel(Counters* c)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < kCounterShards) c->shard[i].clip_count = 0;
+  if (i < kCounterShards) { c->shard[i].clip_count = 0; c->shard[i].big_count = 0; }
   if (i == kCounterShards) c->work.n_items = 0;
 }
 
@@ -2081,6 +2086,11 @@ void launch_clip(const SetupArgs& a, hipStream_t st)
 {
   // the item count lives on the device: fixed grid, grid-stride loop
   hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * (4096 / kCounterShards > 0 ? 4096 / kCounterShards : 1)), dim3(kClipBlock), 0, st, a);
+}
+void launch_bigrec(const SetupArgs& a, hipStream_t st)
+{
+  // the list lengths live on the device: fixed grid, kBigWavesPerShard waves per shard, each strides over its shard's list
+  hipLaunchKernelGGL(bigrec_kernel, dim3(kCounterShards * kBigWavesPerShard / 4), dim3(256), 0, st, a);
 }
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st)
 {
