@@ -515,7 +515,7 @@ static int alloc_frame_buffers(rtuf_context* c)
   HIP_TRY(c, hipMalloc(&c->d_fbin_count, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(c->d_fbin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
-  c->big_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 64, 4096), (size_t)1 << 20);                 // per shard
+  c->big_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 64, 1024), (size_t)1 << 20);                 // per shard
   HIP_TRY(c, hipMalloc(&c->d_big_list, (size_t)c->big_capacity * kCounterShards * sizeof(BigRec)));
   for (auto& b : c->batch) HIP_TRY(c, hipMalloc(&b.d_items, (size_t)c->n_chunks * (size_t)max_items_per_chunk(G) * sizeof(WorkItem)));
   if (c->params.flags & RTUF_FLAG_TWO_KERNEL)

@@ -745,7 +745,8 @@ def test_clipper_vertex_just_outside_the_frustum():
 def test_fragment_bin_and_clip_list_overflow_regrow():
     """Capacity stress: (a) 60,000 two-pixel triangles piled onto one 64x32 tile overflow that tile's fragment
     bin (and its record bin), (b) 120,000 triangles that all cross the near plane overflow the clip list; both
-    are detected from the batch's counters, the buffers grow, the batch runs again and matches the oracle."""
+    (c) 90,000 slivers that each touch more than four tiles overflow the many-tile lists; all are detected from the
+    batch's counters, the buffers grow, the batch runs again and matches the oracle."""
     W, H = 256, 128
     P = S.projection(210.0, 210.0, (W - 1) / 2, (H - 1) / 2, W, H)
     I = S.gl(np.eye(4))
@@ -761,7 +762,15 @@ def test_fragment_bin_and_clip_list_overflow_regrow():
     b = a + np.stack([rng.normal(scale=0.01, size=n2), rng.normal(scale=0.01, size=n2), -rng.uniform(2.5, 4.0, n2)], axis=1)
     c = a + rng.normal(scale=0.004, size=(n2, 3))
     vb = np.stack([a, b, c], axis=1).reshape(-1, 3).astype(np.float32)
-    for verts in (va, vb):
+    # (c) slivers across the image, all in front of the camera: every one touches more than four tiles, so all of
+    # them go through the many-tile lists (bigrec_kernel), which overflow
+    n3 = 90000
+    a3 = np.stack([rng.uniform(-0.5, 0.5, n3), rng.uniform(-0.25, 0.25, n3), rng.uniform(0.8, 2.0, n3)], axis=1)
+    ang = rng.uniform(0, 2 * np.pi, n3)
+    b3 = a3 + np.stack([0.9 * np.cos(ang), 0.9 * np.sin(ang), rng.normal(scale=0.05, size=n3)], axis=1)
+    c3 = a3 + rng.normal(scale=0.004, size=(n3, 3))
+    vc = np.stack([a3, b3, c3], axis=1).reshape(-1, 3).astype(np.float32)
+    for verts in (va, vb, vc):
         tris = np.arange(len(verts), dtype=np.uint32).reshape(-1, 3)
         om, ok = O.filter_frame(depth, P, [(I, 0, [0.0, 0.0, 0.0], verts, tris)], I, I, replace_value=5.0)
         ctx = R.Context(W, H, 1, 0, params(5.0, 0.05))
