@@ -314,7 +314,7 @@ def main():
             kernels["tile_kernel<fused>"] = (raster_ms, iso["ms_raster"], ((4 if args.u16 else 8) + mask_b) * px * n, "hbm")
         geo_bytes = sum(12 * g.variants[0].n_vertices() + 16 * g.variants[0].n_triangles() for g in share.groups)
         kernels["setup_kernel"] = (setup_ms, iso["ms_setup"], geo_bytes, "valu-issue (triangle set-up: neither HBM nor MFMA, SURVEY.md 8d); HBM figure for context")
-        kernels["clip_kernel"] = (clip_ms, iso["ms_clip"], 0, "latency / divergent scalar code at LDS-limited occupancy; no algorithmic HBM traffic of its own")
+        kernels["clip_kernel"] = (clip_ms, iso["ms_clip"], 0, "latency / divergent scalar code at LDS-limited occupancy; no algorithmic HBM traffic of its own (the time covers clip_kernel and bigrec_kernel, which appends the many-tile records both set-up and clip kernel listed)")
         peak = 8000.0
         # Off-line counter data of this same command (rocprofv3 --pmc passes cannot run inside the timed region):
         # used only when the committed measurement is of this exact workload, and labelled as such.
