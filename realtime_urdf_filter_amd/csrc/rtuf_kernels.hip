@@ -1465,7 +1465,7 @@ __device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriR
 template <int MODE>
 __device__ __forceinline__ void raster_bin(unsigned long long* keys, const PackedTri* recs, uint32_t n,
                                            int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, uint32_t n_front, uint32_t capacity,
-                                           uint32_t* s_huge, int dbg_skip = 0)
+                                           uint32_t* s_huge, TriRec* s_prec, uint4* s_pmeta, int dbg_skip = 0)
 {
   const int lane = tid & 63;
   for (uint32_t base = 0; base < n; base += kTileThreads) {
@@ -1606,50 +1606,72 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     }
   }
   // workgroup-cooperative: the parked triangles (those that cover a large part of the tile: walls, close
-  // links), one at a time, the box's run of candidate pairs spread over all four waves.  Every wave loads
-  // and unpacks the same (few) records itself and takes the record it works on from its own lanes.
+  // links), one at a time, the box's run of candidate pairs spread over all four waves.  ONE wave loads, unpacks
+  // and classifies a batch of them (a lane each) and leaves the records and what the others need to know in LDS; the
+  // other three waves wait at the barrier instead of repeating the same two hundred instructions (with ten wall
+  // records in every tile of a 720p frame that repetition was 30 % of the walls' cost).
   __syncthreads();
   const uint32_t nh = min(s_huge[0], (uint32_t)kHugeMax);
   uint32_t zfull = 0xffffffffu;                  // largest depth any pixel of the tile can still have (24-bit)
   for (uint32_t hb = 0; hb < nh; hb += 64) {
     const bool have = hb + (uint32_t)lane < nh;
-    TriRec r;
-    if (have) {
-      PackedTri pk;
-      const uint4* src = reinterpret_cast<const uint4*>(recs + s_huge[1 + hb + lane]);
-      uint4* dst = reinterpret_cast<uint4*>(&pk);
-      dst[0] = src[0]; dst[1] = src[1];
-      r = unpack_record(pk, width, height);
-    } else {
+    if (tid < 64) {
+      TriRec r;
+      if (have) {
+        PackedTri pk;
+        const uint4* src = reinterpret_cast<const uint4*>(recs + s_huge[1 + hb + lane]);
+        uint4* dst = reinterpret_cast<uint4*>(&pk);
+        dst[0] = src[0]; dst[1] = src[1];
+        r = unpack_record(pk, width, height);
+      } else {
 #pragma unroll
-      for (int k = 0; k < 16; k++) reinterpret_cast<int*>(&r)[k] = 0;
+        for (int k = 0; k < 16; k++) reinterpret_cast<int*>(&r)[k] = 0;
+      }
+      // per lane: the record's part of the tile, whether it is covered entirely, and the range of its depth
+      // there.  The plane is evaluated exactly like fragment() does, which is monotonic in px and in py, so
+      // the extremes over the box are at its corners.
+      const int lx0 = max((int)(r.bbx & 0xffff) - x_base, 0), lx1 = min((int)(r.bbx >> 16) - x_base, kTileW - 1);
+      const int ly0 = max((int)(r.bby & 0xffff) - y_base, 0), ly1 = min((int)(r.bby >> 16) - y_base, kTileH - 1);
+      const int cls = have ? classify_box(r, x_base, y_base, lx0, lx1, ly0, ly1) : 0;
+      const float cx0 = __fmaf_rn(r.dzdx, (float)(x_base + lx0), r.a0), cx1 = __fmaf_rn(r.dzdx, (float)(x_base + lx1), r.a0);
+      const float fy0 = (float)(y_base + ly0), fy1 = (float)(y_base + ly1);
+      const float z00 = __fmaf_rn(r.dzdy, fy0, cx0), z10 = __fmaf_rn(r.dzdy, fy0, cx1);
+      const float z01 = __fmaf_rn(r.dzdy, fy1, cx0), z11 = __fmaf_rn(r.dzdy, fy1, cx1);
+      const uint32_t zmin24 = z24_of(fminf(fminf(z00, z10), fminf(z01, z11))), zmax24 = z24_of(fmaxf(fmaxf(z00, z10), fmaxf(z01, z11)));
+      const bool whole = cls == 2 && lx0 == 0 && ly0 == 0 && lx1 == min(kTileW, width - x_base) - 1 && ly1 == min(kTileH, height - y_base) - 1;
+      if (have) {
+        const uint4* sp = reinterpret_cast<const uint4*>(&r);
+        uint4* dp = reinterpret_cast<uint4*>(&s_prec[lane]);
+        dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2]; dp[3] = sp[3];
+        s_pmeta[lane] = make_uint4((uint32_t)cls, zmin24, whole ? zmax24 : 0xffffffffu, 0u);
+      }
     }
-    // per lane: the record's part of the tile, whether it is covered entirely, and the range of its depth
-    // there.  The plane is evaluated exactly like fragment() does, which is monotonic in px and in py, so
-    // the extremes over the box are at its corners.
-    const int lx0 = max((int)(r.bbx & 0xffff) - x_base, 0), lx1 = min((int)(r.bbx >> 16) - x_base, kTileW - 1);
-    const int ly0 = max((int)(r.bby & 0xffff) - y_base, 0), ly1 = min((int)(r.bby >> 16) - y_base, kTileH - 1);
-    const int cls = have ? classify_box(r, x_base, y_base, lx0, lx1, ly0, ly1) : 0;
-    const float cx0 = __fmaf_rn(r.dzdx, (float)(x_base + lx0), r.a0), cx1 = __fmaf_rn(r.dzdx, (float)(x_base + lx1), r.a0);
-    const float fy0 = (float)(y_base + ly0), fy1 = (float)(y_base + ly1);
-    const float z00 = __fmaf_rn(r.dzdy, fy0, cx0), z10 = __fmaf_rn(r.dzdy, fy0, cx1);
-    const float z01 = __fmaf_rn(r.dzdy, fy1, cx0), z11 = __fmaf_rn(r.dzdy, fy1, cx1);
-    const uint32_t zmin24 = z24_of(fminf(fminf(z00, z10), fminf(z01, z11))), zmax24 = z24_of(fmaxf(fmaxf(z00, z10), fmaxf(z01, z11)));
+    __syncthreads();
+    uint4 meta = make_uint4(0u, 0xffffffffu, 0xffffffffu, 0u);
+    if (have) meta = s_pmeta[lane];
+    const uint32_t zmin24 = meta.y;
     // Occlusion among them: once a triangle covers every pixel of the tile, no pixel's key can have a
     // larger depth than that triangle's largest; a triangle whose smallest depth here is larger still
     // (the back of a wall, the wall behind it) cannot win anywhere in this tile and is skipped.
-    const bool whole = cls == 2 && lx0 == 0 && ly0 == 0 && lx1 == min(kTileW, width - x_base) - 1 && ly1 == min(kTileH, height - y_base) - 1;
-    uint32_t zf = whole ? zmax24 : 0xffffffffu;
+    uint32_t zf = meta.z;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) zf = min(zf, (uint32_t)__shfl_xor((int)zf, o));
     zfull = min(zfull, zf);
     unsigned long long m = __ballot(have && zmin24 <= zfull);
-    const unsigned long long full = __ballot(cls == 2);
+    const unsigned long long full = __ballot(have && meta.x == 2u);
     while (m) {
       const int src = __ffsll((long long)m) - 1;
       m &= m - 1;
       const bool inside = ((full >> src) & 1ull) != 0;
-      const TriRec q = broadcast_record(r, src);
+      TriRec q;                                        // the record from LDS into scalar registers (same address in every lane)
+      {
+        const uint4* sp = reinterpret_cast<const uint4*>(&s_prec[src]);
+        uint4 w[4] = {sp[0], sp[1], sp[2], sp[3]};
+        const int* wi = reinterpret_cast<const int*>(w);
+        int* d = reinterpret_cast<int*>(&q);
+#pragma unroll
+        for (int k = 0; k < 16; k++) d[k] = __builtin_amdgcn_readfirstlane(wi[k]);
+      }
       const int qx0 = max((int)(q.bbx & 0xffff) - x_base, 0), qx1 = min((int)(q.bbx >> 16) - x_base, kTileW - 1);
       const int qy0 = max((int)(q.bby & 0xffff) - y_base, 0), qy1 = min((int)(q.bby >> 16) - y_base, kTileH - 1);
       const int qw = qx1 - qx0 + 1, npair = qw * ((qy1 - qy0 + 2) >> 1);
@@ -1685,6 +1707,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
         }
       }
     }
+    if (hb + 64 < nh) __syncthreads();               // (more than 64 parked: the next batch overwrites the LDS records)
   }
 }
 
@@ -1756,6 +1779,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
 {
   __shared__ unsigned long long keys[kTileW * kTileH];
   __shared__ uint32_t s_huge[2 + kHugeMax];        // raster_bin's list of whole-tile triangles (+ count in front, area threshold behind)
+  __shared__ TriRec s_prec[64];                    // ... a batch of them unpacked by the first wave for all four,
+  __shared__ uint4 s_pmeta[64];                    //     with {class, smallest depth, largest depth if it covers the whole tile}
 
   const int tid = threadIdx.x;
   const int tiles = a.tiles_x * a.tiles_y;
@@ -1818,10 +1843,10 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       if (fcount) atomicMax(&sh.max_fbin_fill, fcount);
     }
 #ifdef RTUF_ABLATE
-    if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, (int)((a.flags >> 12) & 3u));
+    if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, (int)((a.flags >> 12) & 3u));
     if (!(a.flags & 0x400u)) raster_frags(keys, frags, nf, tid);
 #else
-    raster_bin<0>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge);
+    raster_bin<0>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta);
     raster_frags(keys, frags, nf, tid);
 #endif
     __syncthreads();
@@ -1835,7 +1860,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       if (k != bgkey && (uint32_t)(k >> 32) <= 8388608u) need = true;
     }
     if (__syncthreads_or(need)) {
-      raster_bin<1>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge);
+      raster_bin<1>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta);
       __syncthreads();
     }
   }
@@ -1947,7 +1972,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6)
 // two-kernel mode writes the z-surface instead of resolving the compare: one register over 64 VGPRs without
 // the hint, i.e. 7 instead of 8 waves/SIMD (+10 % kernel time)
 template <>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(8))) void tile_kernel<true, false>(TileArgs a) { tile_body<true, false, false>(a); }
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(7))) void tile_kernel<true, false>(TileArgs a) { tile_body<true, false, false>(a); }      // (22.3 KB of LDS per workgroup: 7 fit a CU)
 
 // ---------------------------------------------------------------------------------------
 // compare_kernel (two-kernel mode): streaming, 13 B/pixel (4 sensor + 4 z + 4 masked + 1 mask)
