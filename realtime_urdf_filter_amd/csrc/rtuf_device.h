@@ -16,7 +16,9 @@
 //   rasteriser working set, per in-flight stream g and screen tile
 //     bin_count u32[G][tiles][2], bins PackedTri[G][tiles][capacity]  (32 B records: small boxes from the front, larger from the back)
 //     fbin_count u32[G][tiles], fbins Frag[G][tiles][fcapacity]    (pixels of small triangles, 8 B)
-//     clip_list ClipItem[], zsurface f32[G][H][W] (two-kernel mode only)
+//     clip_list ClipItem[shards][clip_capacity]   triangles that cross a frustum plane (set-up kernel -> clip kernel)
+//     big_list  BigRec[shards][big_capacity]      records over more than 4 tiles (set-up / clip kernel -> bigrec_kernel)
+//     zsurface  f32[G][H][W]                       two-kernel mode only
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
