@@ -302,6 +302,14 @@ _DAE = """<?xml version="1.0" encoding="utf-8"?>
       <vertices id="tri-vtx"><input semantic="POSITION" source="#tri-pos"/></vertices>
       <triangles count="1"><input semantic="VERTEX" source="#tri-vtx" offset="0"/><p>0 1 2</p></triangles>
     </mesh></geometry>
+    <geometry id="misc"><mesh>
+      <source id="misc-pos"><float_array id="misc-pos-array" count="18">0 0 0  1 0 0  1 1 0  0 1 0  2 0 1  2 1 1</float_array>
+        <technique_common><accessor source="#misc-pos-array" count="6" stride="3"/></technique_common></source>
+      <vertices id="misc-vtx"><input semantic="POSITION" source="#misc-pos"/></vertices>
+      <tristrips count="1"><input semantic="VERTEX" source="#misc-vtx" offset="0"/><p>0 1 3 2 5</p></tristrips>
+      <trifans count="1"><input semantic="VERTEX" source="#misc-vtx" offset="0"/><p>1 4 5 2</p></trifans>
+      <polygons count="2"><input semantic="VERTEX" source="#misc-vtx" offset="0"/><p>0 1 2 3</p><p>1 4 5</p></polygons>
+    </mesh></geometry>
   </library_geometries>
   <library_nodes><node id="shared"><translate>0 0 10</translate><instance_geometry url="#tri"/></node></library_nodes>
   <library_visual_scenes><visual_scene id="Scene">
@@ -417,3 +425,24 @@ def test_cpp_mesh_import_matches_python_bit_for_bit(tmp_path):
     bad = tmp_path / "bad.dae"
     bad.write_text("<COLLADA><library_geometries/></COLLADA>")
     assert subprocess.run([exe, "--mesh", str(bad)], stdout=subprocess.PIPE).returncode == 1
+
+
+def test_collada_strips_fans_polygons_python_and_cpp(tmp_path):
+    import os
+    import subprocess
+    from realtime_urdf_filter_amd import meshes
+    doc = (_DAE % {"up": "Y_UP"}).replace('<node id="c">', '<node id="d"><translate>0 0 -5</translate><instance_geometry url="#misc"/></node><node id="c">')
+    v, t = meshes.load_collada(doc.encode())
+    assert len(t) == 4 + 8
+    P = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [2, 0, 1], [2, 1, 1]], np.float32) + np.float32([0, 0, -5])
+    want = [(0, 1, 3), (3, 1, 2), (3, 2, 5), (1, 4, 5), (1, 5, 2), (0, 1, 2), (0, 2, 3), (1, 4, 5)]
+    # node "d" comes after "a" (6 + 3 corners) and before "c" (3 corners) in document order
+    np.testing.assert_array_equal(v[9:9 + 24], P[np.array(want).reshape(-1)])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "bin", "example_filter")
+    subprocess.check_call([os.path.join(root, "realtime_urdf_filter_amd", "csrc", "build_facade.sh")])
+    f = tmp_path / "misc.dae"
+    f.write_text(doc)
+    out = subprocess.check_output([exe, "--mesh", str(f)]).decode().split()
+    got = np.array([int(h, 16) for h in out[2:]], np.uint32).view(np.float32).reshape(-1, 3)
+    np.testing.assert_array_equal(got.view(np.uint32), v.view(np.uint32))
