@@ -105,6 +105,7 @@ struct rtuf_context {
   int group = 0;                       // in-flight streams per launch group
   uint32_t capacity = 0, fcapacity = 0, clip_capacity = 0;
   PackedTri* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr; uint32_t items_hint = 0;
+  float4* d_clip_spill = nullptr;
   BigRec* d_big_list = nullptr; uint32_t big_capacity = 0;      // many-tile records (per counter shard), see bigrec_kernel
   Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
   float* d_zsurface = nullptr;
@@ -318,7 +319,7 @@ static void free_frame_buffers(rtuf_context* c)
   auto hfree = [](auto*& p) { if (p) { hipHostFree(p); p = nullptr; } };
   dfree(c->d_model_mask);
   for (auto& b : c->batch) { dfree(b.d_cams); dfree(b.d_link_tf); dfree(b.d_mvp); dfree(b.d_bg); dfree(b.d_items); dfree(b.d_counters); }
-  dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_big_list); dfree(c->d_zsurface);
+  dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_clip_spill); dfree(c->d_big_list); dfree(c->d_zsurface);
   for (auto& b : c->batch) { dfree(b.st_depth); dfree(b.st_masked); dfree(b.st_mask); b.st_streams = 0; dfree(b.st_bits); b.st_bits_streams = 0; }
   for (auto*& p : c->ring_cams) hfree(p);
   for (auto*& p : c->ring_link_tf) hfree(p);
@@ -515,6 +516,7 @@ static int alloc_frame_buffers(rtuf_context* c)
   HIP_TRY(c, hipMalloc(&c->d_fbin_count, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(c->d_fbin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
+  HIP_TRY(c, hipMalloc(&c->d_clip_spill, clip_spill_bytes()));
   c->big_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 64, 1024), (size_t)1 << 20);                 // per shard
   HIP_TRY(c, hipMalloc(&c->d_big_list, (size_t)c->big_capacity * kCounterShards * sizeof(BigRec)));
   for (auto& b : c->batch) HIP_TRY(c, hipMalloc(&b.d_items, (size_t)c->n_chunks * (size_t)max_items_per_chunk(G) * sizeof(WorkItem)));
@@ -1165,7 +1167,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     sa.cverts = c->d_cverts; sa.ctris = c->d_ctris; sa.corder = c->d_corder; sa.chunks = c->d_chunks; sa.mvp = b.d_mvp;
     sa.model_mask = c->d_model_mask; sa.bg = b.d_bg; sa.bins = c->d_bins; sa.bin_count = c->d_bin_count;
     sa.fbins = c->d_fbins; sa.fbin_count = c->d_fbin_count; sa.fcapacity = c->fcapacity;
-    sa.clip_list = c->d_clip_list; sa.big_list = c->d_big_list; sa.big_capacity = c->big_capacity; sa.counters = b.d_counters; sa.group_base = base; sa.group_size = gs;
+    sa.clip_list = c->d_clip_list; sa.clip_spill = c->d_clip_spill; sa.big_list = c->d_big_list; sa.big_capacity = c->big_capacity; sa.counters = b.d_counters; sa.group_base = base; sa.group_size = gs;
     sa.n_draws = c->n_draws; sa.width = c->width; sa.height = c->height; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
     sa.capacity = c->capacity; sa.clip_capacity = c->clip_capacity; sa.bg_chunk = c->bg_chunk;
     sa.items = b.d_items; sa.n_chunks = c->n_chunks; sa.flags = c->params.flags;

@@ -228,6 +228,7 @@ struct SetupArgs {
   uint32_t* fbin_count;          // [G][tiles]
   uint32_t fcapacity;
   ClipItem* clip_list;
+  float4* clip_spill;            // clip kernel: polygon vertices beyond the eight per thread that live in LDS
   BigRec* big_list;              // [kCounterShards][big_capacity]  many-tile records, appended to their bins by bigrec_kernel
   uint32_t big_capacity;         // per shard segment
   WorkItem* items;               // [n_chunks * ceil(group / kStreamsPerBlock)] visible (chunk, streams) jobs of this group
@@ -297,6 +298,7 @@ void launch_pose(const PoseArgs& a, hipStream_t st);
 void launch_cull(const SetupArgs& a, hipStream_t st);
 uint32_t launch_setup(const SetupArgs& a, uint32_t items_hint, bool sweep, hipStream_t st);    // returns the main grid size
 void launch_clip(const SetupArgs& a, hipStream_t st);
+size_t clip_spill_bytes();
 void launch_bigrec(const SetupArgs& a, hipStream_t st);
 void launch_reset_clip(Counters* c, hipStream_t st);
 void launch_publish_counters(const Counters* src, Counters* host_dst, hipStream_t st);

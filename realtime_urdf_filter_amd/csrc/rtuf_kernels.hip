@@ -1156,17 +1156,24 @@ __device__ __forceinline__ float clipdist(const float* c, int plane)
   return s;
 }
 
-constexpr int kClipBlock = 128;          // threads per clip workgroup (48 KB of LDS polygon storage)
+constexpr int kClipBlock = 128;          // threads per clip workgroup (16 KB of LDS polygon storage)
 constexpr int kClipMaxV = 16;            // clip-space vertices per triangle: 3 + at most 2 new ones per frustum plane (+1 spare)
+constexpr int kClipLdsV = 8;             // ... of which this many live in LDS (a triangle that crosses one or two planes needs 5..7);
+                                         // the rest, for the rare triangle that crosses three and more, in a per-thread global spill area
+constexpr int kClipGridWgs = 64;         // workgroups per counter shard (the spill area is sized for the grid)
 constexpr int kClipMaxP = 12;            // polygon vertices (5-bit pool indices packed in one 64-bit register)
 
 // Per-thread polygon clipper.  The vertex pool lives in LDS (thread-interleaved float4s: conflict
 // free, no scratch memory) and the two polygon index lists are 5-bit fields of 64-bit registers.
 __device__ __forceinline__ int list_get(unsigned long long l, int i) { return (int)((l >> (5 * i)) & 31ull); }
 
-__device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, int shard_id, float4 (*pool)[kClipBlock], bool valid)
+__device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, int shard_id, float4 (*lds_pool)[kClipBlock], bool valid)
 {
   const int t = threadIdx.x;
+  float4* const spill = a.clip_spill + (size_t)blockIdx.x * kClipBlock + t;        // [kClipMaxV - kClipLdsV][grid threads]
+  const size_t spill_stride = (size_t)gridDim.x * kClipBlock;
+  auto pget = [&](int i) -> float4 { return i < kClipLdsV ? lds_pool[i][t] : spill[(size_t)(i - kClipLdsV) * spill_stride]; };
+  auto pset = [&](int i, const float4& v) { if (i < kClipLdsV) lds_pool[i][t] = v; else spill[(size_t)(i - kClipLdsV) * spill_stride] = v; };
   const int slot = (int)it.slot, stream = a.group_base + slot;
   const float* __restrict__ M = a.mvp + ((size_t)stream * (a.n_draws + 1) + it.draw) * 16;
   const uint32_t packed = it.packed;
@@ -1182,7 +1189,7 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
       const float4 p = a.cverts[it.vert_begin + vi[i]];
       float c[4];
       vs_position(M, p.x, p.y, p.z, c);
-      pool[i][t] = make_float4(c[0], c[1], c[2], c[3]);
+      lds_pool[i][t] = make_float4(c[0], c[1], c[2], c[3]);
       ormask |= clipmask_of(c);
     }
   }
@@ -1196,13 +1203,13 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
     clipmask &= ~(1u << plane);
     if (nv >= kClipMaxP) { bad = true; break; }
     int prev = list_get(inl, 0);
-    float4 cprev = pool[prev][t];
+    float4 cprev = pget(prev);
     float dp_prev = clipdist(&cprev.x, plane);
     int outc = 0;
     outl = 0;
     for (int i = 1; i <= nv; i++) {
       const int cur = list_get(inl, i == nv ? 0 : i);
-      const float4 ccur = pool[cur][t];
+      const float4 ccur = pget(cur);
       const float dp = clipdist(&ccur.x, plane);
       bool diff;
       if (dp_prev >= 0.0f) {
@@ -1226,7 +1233,7 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
         nc.y = __fadd_rn(__fmul_rn(__fsub_rn(in.y, o.y), tt), o.y);
         nc.z = __fadd_rn(__fmul_rn(__fsub_rn(in.z, o.z), tt), o.z);
         nc.w = __fadd_rn(__fmul_rn(__fsub_rn(in.w, o.w), tt), o.w);
-        pool[npool][t] = nc;
+        pset(npool, nc);
         outl |= (unsigned long long)npool << (5 * outc++);
         npool++;
       }
@@ -1242,7 +1249,7 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
   // window coordinates: shaded (original) vertices and clipper-made ones go through different
   // viewport arithmetic (viewport_vs / viewport_clip)
   auto window_of = [&](int idx) {
-    const float4 c4 = pool[idx][t];
+    const float4 c4 = pget(idx);
     const float c[4] = {c4.x, c4.y, c4.z, c4.w};
     return idx < 3 ? viewport_vs(c, sx, sy) : viewport_clip(c, sx, sy);
   };
@@ -1276,7 +1283,7 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
 
 __global__ __launch_bounds__(kClipBlock) void clip_kernel(SetupArgs a)
 {
-  __shared__ float4 s_pool[kClipMaxV][kClipBlock];
+  __shared__ float4 s_pool[kClipLdsV][kClipBlock];
   // workgroups b, b + kCounterShards, ... serve shard b % kCounterShards
   const int shard_id = blockIdx.x % kCounterShards;
   const uint32_t n = min(a.counters->shard[shard_id].clip_count, a.clip_capacity);
@@ -2110,8 +2117,9 @@ uint32_t launch_setup(const SetupArgs& a, uint32_t items_hint, bool sweep, hipSt
 void launch_clip(const SetupArgs& a, hipStream_t st)
 {
   // the item count lives on the device: fixed grid, grid-stride loop
-  hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * (4096 / kCounterShards > 0 ? 4096 / kCounterShards : 1)), dim3(kClipBlock), 0, st, a);
+  hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * kClipGridWgs), dim3(kClipBlock), 0, st, a);
 }
+size_t clip_spill_bytes() { return (size_t)(kClipMaxV - kClipLdsV) * kCounterShards * kClipGridWgs * kClipBlock * sizeof(float4); }
 void launch_bigrec(const SetupArgs& a, hipStream_t st)
 {
   // the list lengths live on the device: fixed grid, kBigWavesPerShard waves per shard, each strides over its shard's list
