@@ -74,7 +74,8 @@ class RenderableMesh(Renderable):
         self.meshname = meshname
         try:
             if mesh_loader is None:
-                raise IOError("no mesh loader configured")
+                # the reference resolves every URI through resource_retriever: package:// against ROS_PACKAGE_PATH
+                mesh_loader = geometry.PackageResolver()
             v, t = mesh_loader(meshname)
             self.draws = geometry.mesh_draws(v, t, sx, sy, sz)
         except Exception as e:                      # noqa: BLE001 - mirror ROS_ERROR + continue

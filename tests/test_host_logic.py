@@ -446,3 +446,16 @@ def test_collada_strips_fans_polygons_python_and_cpp(tmp_path):
     out = subprocess.check_output([exe, "--mesh", str(f)]).decode().split()
     got = np.array([int(h, 16) for h in out[2:]], np.uint32).view(np.float32).reshape(-1, 3)
     np.testing.assert_array_equal(got.view(np.uint32), v.view(np.uint32))
+
+
+def test_renderable_mesh_defaults_to_the_package_path_resolver(tmp_path, monkeypatch):
+    """Without an explicit mesh_loader the Python mirror resolves package:// against ROS_PACKAGE_PATH, as
+    resource_retriever does for the reference (src/renderable.cpp:270-300); an unresolvable mesh draws nothing (Q15)."""
+    from realtime_urdf_filter_amd.filter import RenderableMesh
+    pkg = tmp_path / "ws" / "arm_description"
+    (pkg / "meshes").mkdir(parents=True)
+    (pkg / "meshes" / "link.obj").write_text(_OBJ)
+    monkeypatch.setenv("ROS_PACKAGE_PATH", str(tmp_path / "ws"))
+    r = RenderableMesh("package://arm_description/meshes/link.obj", 1.0, 2.0, 3.0)
+    assert len(r.draws) == 1 and len(r.draws[0].tris) == 3 and tuple(r.draws[0].op) == (1.0, 2.0, 3.0)
+    assert RenderableMesh("package://missing_pkg/meshes/link.obj", 1.0, 1.0, 1.0).draws == []
