@@ -879,4 +879,41 @@ inline bool load_mesh(const std::string& name, const std::string& data, std::vec
   return load_obj(data, verts, tris);
 }
 
+// resource_retriever's job for the façade when the host supplies no MeshResolver: package://<pkg>/<path> against the
+// roots in ROS_PACKAGE_PATH (a root either is the package directory or contains it), file://<path>, plain paths.
+inline bool default_mesh_resolver(const std::string& uri, std::string& data, void* /*user*/)
+{
+  auto slurp = [&](const std::string& path) {
+    std::FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    data.clear();
+    char buf[65536];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, n);
+    std::fclose(f);
+    return true;
+  };
+  if (uri.compare(0, 10, "package://") == 0) {
+    const size_t slash = uri.find('/', 10);
+    if (slash == std::string::npos) return false;
+    const std::string pkg = uri.substr(10, slash - 10), rel = uri.substr(slash + 1);
+    const char* env = std::getenv("ROS_PACKAGE_PATH");
+    std::string roots = env ? env : "";
+    for (size_t at = 0; at <= roots.size();) {
+      size_t e = roots.find(':', at);
+      if (e == std::string::npos) e = roots.size();
+      std::string root = roots.substr(at, e - at);
+      at = e + 1;
+      if (root.empty()) continue;
+      while (root.size() > 1 && root.back() == '/') root.pop_back();
+      if (slurp(root + "/" + pkg + "/" + rel)) return true;
+      const size_t base = root.rfind('/');
+      if ((base == std::string::npos ? root : root.substr(base + 1)) == pkg && slurp(root + "/" + rel)) return true;
+    }
+    return false;
+  }
+  if (uri.compare(0, 7, "file://") == 0) return slurp(uri.substr(7));
+  return slurp(uri);
+}
+
 }  // namespace rtuf_host

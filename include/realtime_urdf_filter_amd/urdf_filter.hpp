@@ -65,7 +65,8 @@ struct RenderableMesh : Renderable {
     std::string data;
     std::vector<float> v;
     std::vector<uint32_t> t;
-    if (resolve && resolve(meshname, data, user) && rtuf_host::load_mesh(meshname, data, v, t)) draws = rtuf_host::mesh_draws(v, t, sx, sy, sz);
+    if (!resolve) resolve = &rtuf_host::default_mesh_resolver;        // package:// against ROS_PACKAGE_PATH, file://, plain paths
+    if (resolve(meshname, data, user) && rtuf_host::load_mesh(meshname, data, v, t)) draws = rtuf_host::mesh_draws(v, t, sx, sy, sz);
     else std::fprintf(stderr, "[realtime_urdf_filter] Could not load resource [%s]\n", meshname.c_str());
   }
 };

@@ -459,3 +459,25 @@ def test_renderable_mesh_defaults_to_the_package_path_resolver(tmp_path, monkeyp
     r = RenderableMesh("package://arm_description/meshes/link.obj", 1.0, 2.0, 3.0)
     assert len(r.draws) == 1 and len(r.draws[0].tris) == 3 and tuple(r.draws[0].op) == (1.0, 2.0, 3.0)
     assert RenderableMesh("package://missing_pkg/meshes/link.obj", 1.0, 1.0, 1.0).draws == []
+
+
+def test_cpp_facade_resolves_package_uris_by_default(tmp_path):
+    """RenderableMesh of the C++ façade without a MeshResolver: package:// against ROS_PACKAGE_PATH (--parse prints what
+    would be uploaded)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "bin", "example_filter")
+    subprocess.check_call([os.path.join(root, "realtime_urdf_filter_amd", "csrc", "build_facade.sh")])
+    pkg = tmp_path / "ws" / "arm_description"
+    (pkg / "meshes").mkdir(parents=True)
+    (pkg / "meshes" / "link.obj").write_text(_OBJ)
+    (pkg / "meshes" / "link.dae").write_text(_DAE % {"up": "Z_UP"})
+    f = tmp_path / "r.urdf"
+    f.write_text("""<robot name="r"><link name="a"><visual><geometry><mesh filename="package://arm_description/meshes/link.obj"/></geometry></visual></link>
+      <link name="b"><visual><geometry><mesh filename="package://arm_description/meshes/link.dae" scale="2 2 2"/></geometry></visual></link>
+      <link name="c"><visual><geometry><mesh filename="package://nowhere/meshes/link.stl"/></geometry></visual></link>
+      <joint name="j" type="fixed"><parent link="a"/><child link="b"/></joint><joint name="k" type="fixed"><parent link="a"/><child link="c"/></joint></robot>""")
+    env = dict(os.environ, ROS_PACKAGE_PATH="/nonexistent:" + str(tmp_path / "ws"))
+    out = subprocess.check_output([exe, "--parse", str(f)], env=env, stderr=subprocess.DEVNULL).decode().strip()
+    assert out.startswith("renderables=3 draws=2 triangles=%d " % (3 + 4)), out
