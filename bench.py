@@ -9,7 +9,7 @@ pose for every stream, then runs forward kinematics -> pose -> cull -> set-up/bi
 per-pixel compare on depth frames that are already resident in HBM.  Inputs rotate through `--variants`
 distinct pre-generated batches so no step can reuse the previous result.
 
-`--workload c4` / `c5` are the two 8-GPU configs of BASELINE.json (realtime_urdf_filter_amd/configs.py): c4 = 512
+`--workload c4` / `c5` are the two 8-GPU configs of BASELINE.json (bench_support/configs.py): c4 = 512
 720p streams of the robot + two wall URDFs block-partitioned over the ranks, c5 = 64 distinct URDFs x 128 cameras
 with URDF m on rank m % N.  Their totals are fixed, so they scale strongly; `--shard-of W` runs rank 0's share of
 a W-GPU job on however many GPUs are present (to measure the per-GPU share on one GPU).
@@ -83,12 +83,14 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per leg (single thread, all cores); 0 disables")
     ap.add_argument("--bin-capacity", type=int, default=0, help="rtuf_params.bin_capacity (records per tile bin; 0 = the library's default, grown on overflow)")
     ap.add_argument("--debug-flags", type=lambda x: int(x, 0), default=0, help="timing experiments only (needs the RTUF_ABLATE build; results are wrong)")
-    ap.add_argument("--check-frames", type=int, default=4, help="frames of the last step verified against the oracle (per rank)")
+    ap.add_argument("--near-arm", action="store_true", help="c3 / c4: every stream poses the robot's right forearm 0.1-0.35 m in front of the lens (exact-z pass, near-plane clipping, whole-tile occluders)")
+    ap.add_argument("--check-frames", type=int, default=16, help="frames of the last step verified against the oracle (per rank)")
     args = ap.parse_args()
 
     import torch
     import realtime_urdf_filter_amd as R
-    from realtime_urdf_filter_amd import configs as CF, sharding
+    from realtime_urdf_filter_amd import sharding
+    from bench_support import configs as CF
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -102,7 +104,9 @@ def main():
     torch.cuda.set_device(local_rank)
     pinned_cpus = pin_to_numa_node_of_gpu(local_rank) if world > 1 and "RTUF_BENCH_DEVICE" not in os.environ else None
     dist = None
-    if world > 1:
+    # launched by torch.distributed.run (also with one rank: the driver's N = 1 run goes straight to python, a torchrun with
+    # --nproc-per-node 1 exercises the RCCL init, barrier, all-reduce and all-gather lines on one GPU)
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -117,7 +121,7 @@ def main():
     if rank >= job_world:
         raise SystemExit("--shard-of %d: rank %d has no share" % (job_world, rank))
     share = CF.build(args.workload, job_world, rank, streams=args.streams, triangles=args.triangles, variants=args.variants,
-                     width=args.width, height=args.height, urdfs=args.urdfs)
+                     width=args.width, height=args.height, urdfs=args.urdfs, near_arm=args.near_arm)
     n, W, H = share.n, share.width, share.height
     wl0 = share.wl0
     p = R.default_params()
@@ -362,6 +366,18 @@ def main():
             return e
 
         entries = [kernel_entry(k) for k in kernels]
+        # depth tests issued per drawn pixel: needs the instrumented build (-DRTUF_COUNT: a counter in the walks), so it is an
+        # OFFLINE figure of this same command (scripts/overdraw.sh -> profiles/overdraw.json), never measured in the timed run
+        overdraw = None
+        try:
+            od = json.load(open(os.path.join(ROOT, "profiles", "overdraw.json")))
+            key = "near_arm" if args.near_arm else args.workload
+            if default_cmd or key in od:
+                rec = od.get(key)
+                if rec:
+                    overdraw = dict(rec, source="OFFLINE: profiles/overdraw.json (librtuf built with -DRTUF_COUNT, same workload)")
+        except Exception:
+            overdraw = None
         dom = max(entries, key=lambda e: e["avg_launch_ms"])       # the dominant kernel: longest average launch, no exclusions
         if dom["bound"] != "hbm":
             dom = dict(dom, bound_note=dom["bound"], bound="hbm")   # (the contract's vocabulary; the note says what really limits it)
@@ -380,12 +396,20 @@ def main():
                        "parallelism": ("stream-sharded x%d" % world) + (" (shares of a %d-GPU job)" % job_world if args.shard_of else ""), "pipelines_per_gpu": P,
                        "host_threads_pinned_to_gpu_numa_node": pinned_cpus},
             "per_stream_fps": value / max(sum(x["streams"] for x in per_rank), 1),
+            "collectives": ({"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "world": world,
+                             "used_for": "barriers around the timed region, MAX all-reduce of the repetition count and the elapsed time, all-gather of per-rank frame and parity counts; no data-path collective"}
+                            if dist is not None else None),
             "kernel_ms_per_step": dict(per, note="stage breakdown from %d extra steps after the timed region: one batch in flight, every stage bracketed by HIP events (ms_setup there = cull + set-up + clip + waiting for the pose stage); roofline.avg_launch_ms is measured inside the timed region" % extra),
             "rasteriser": {"triangles_per_s": float(share.triangles_per_stream().sum()) / (setup_ms * 1e-3) if setup_ms > 0 else None,
                            "binned_triangles_per_s": st["triangles_binned"] / (raster_ms * 1e-3) if raster_ms > 0 else None,
                            "triangles_submitted": int(share.triangles_per_stream().sum()), "triangles_binned": st["triangles_binned"],
                            "triangles_clipped": st["triangles_clipped"], "bin_entries": st["bin_entries"],
-                           "fragments_binned": st["fragments_binned"], "max_bin_fill": st["max_bin_fill"], "max_fragment_bin_fill": st["max_fbin_fill"], "bin_capacity": st["bin_capacity"], "regrowths": st["regrowths"]},
+                           "fragments_binned": st["fragments_binned"], "max_bin_fill": st["max_bin_fill"], "max_fragment_bin_fill": st["max_fbin_fill"], "bin_capacity": st["bin_capacity"], "regrowths": st["regrowths"],
+                           "setup": {"work_items": st["work_items"], "zero_survivor_items": st["zero_survivor_items"],
+                                     "note": "work item = one set-up workgroup: a chunk of <= 256 triangles x up to 3 streams whose frustum its box touches; zero-survivor = none of its triangles reached a bin or the clip list's survivors (sub-pixel or outside)"},
+                           "tile": {"cover_tiles": st["cover_tiles"], "occluded_entries": st["occluded_entries"], "exact_z_tiles": st["exact_tiles"],
+                                    "tiles_per_launch": n * ((W + 63) // 64) * ((H + 31) // 32), "overdraw": overdraw}},
+            "device_memory_bytes": st["device_bytes"],
             "roofline": roof,
             "parity": {"frames_checked": checked_total, "mismatching_values": bad_total, "mask_mismatch_pixels": bad_mask, "depth_mismatch_pixels": bad_depth,
                        "per_rank": per_rank, "note": "every rank checks --check-frames frames of its last step against the oracle; mask/depth split is rank 0's"},
@@ -400,7 +424,7 @@ def main():
             ctx.sync()
             ctx2 = R.Context(W, H, n, local_rank, p2)
             share2 = CF.build(args.workload, job_world, rank, streams=args.streams, triangles=args.triangles, variants=args.variants,
-                              width=args.width, height=args.height, urdfs=args.urdfs)
+                              width=args.width, height=args.height, urdfs=args.urdfs, near_arm=args.near_arm)
             share2.load(ctx2, on_device_fk=not args.host_poses)
             sets2 = [(torch.empty_like(d_masked_set[0]), None if args.no_mask else torch.empty_like(d_mask_set[0])) for _ in range(2 * PO)]
 
@@ -466,11 +490,14 @@ def main():
             t1 = time.perf_counter() - c0
             # all cores: POSIX threads inside the oracle library for --cpu-seconds (a shared counter hands out frames; no
             # Python in the loop; per-thread scratch memory)
-            nN, tN = O.filter_throughput(prepared, args.cpu_seconds, cores)
+            # as many threads as cores this process may really use at once: min(visible hardware threads, cgroup CPU quota) --
+            # 256 threads under a 16-core quota only measure the scheduler
+            threads = max(1, min(cores, int(quota))) if quota else cores
+            nN, tN = O.filter_throughput(prepared, args.cpu_seconds, threads)
             cb = {"value": n1 / t1, "unit": "frames/s", "cores": 1, "kind": "port",
                   "sample": "%d frames of the last batch (first %d streams, cycled) through oracle/rtuf_oracle.c, single thread, %.1f s" % (n1, n_in, t1),
-                  "all_cores": {"value": nN / tN, "unit": "frames/s", "cores": cores, "cgroup_cpu_quota_cores": quota,
-                                "sample": "%d frames of the same set on %d POSIX threads inside the oracle library, %.1f s" % (nN, cores, tN)}}
+                  "all_cores": {"value": nN / tN, "unit": "frames/s", "cores": threads, "hardware_threads_visible": cores, "cgroup_cpu_quota_cores": quota,
+                                "sample": "%d frames of the same set on %d POSIX threads (= min(hardware threads, cgroup quota)) inside the oracle library, %.1f s" % (nN, threads, tN)}}
             try:
                 lp = json.load(open(os.path.join(ROOT, "profiles", "llvmpipe_baseline.json")))
                 cb["reference_llvmpipe"] = dict(lp.get("bench_workload", {}), source="OFFLINE: profiles/llvmpipe_baseline.json -- the reference's own GLSL on Mesa llvmpipe, timed in the development container (scripts/llvmpipe_baseline.py): the harness reads the reference's shaders from /root/reference at run time, which does not exist on the GPU box")

@@ -238,6 +238,24 @@ class SyntheticRobot:
         out.append('</robot>')
         return "\n".join(out)
 
+    #: the right forearm pointing at the head camera, its middle 0.25 m in front of the lens (found by hill climbing on the
+    #: forward kinematics of this description): the self-filter's own normal case of an arm right in front of the sensor
+    NEAR_ARM_BASE = {"r_shoulder_pan_joint": 0.7099, "r_shoulder_lift_joint": -0.5236, "r_upper_arm_roll_joint": -0.1123,
+                     "r_elbow_flex_joint": -1.0739, "r_forearm_roll_joint": -2.5904, "r_wrist_flex_joint": -0.778,
+                     "head_tilt_joint": 1.2172, "head_pan_joint": 0.3705}
+
+    def near_arm_joint_state(self, seed, jitter=0.08):
+        """random_joint_state(seed) with the right arm and the head moved to NEAR_ARM_BASE +- jitter rad: the forearm
+        surface lies about 0.1 - 0.35 m in front of the lens (window z below and above 0.5: exact-z territory), fills
+        the middle of the image and the gripper passes the near plane."""
+        q = self.random_joint_state(seed)
+        rng = SplitMix64(seed * 7919 + 17)
+        lims = {j["name"]: (j["lower"], j["upper"]) for j in self.joints}
+        for n, v in self.NEAR_ARM_BASE.items():
+            lo, hi = lims[n]
+            q[n] = min(hi, max(lo, v + (rng.uniform() - 0.5) * 2.0 * jitter))
+        return q
+
     def random_joint_state(self, seed, arms_in_view=True):
         """Uniform in limits; with arms_in_view the shoulder/elbow ranges are narrowed
         so that the arms reach into the head camera's field of view, as during manipulation."""

@@ -9,9 +9,10 @@ import os
 
 import numpy as np
 
-from . import synthetic, urdf
-from .filter import URDFRenderer, CameraInfo
-from ._capi import projection_from_intrinsics
+from realtime_urdf_filter_amd import urdf
+from . import synthetic
+from realtime_urdf_filter_amd.filter import URDFRenderer, CameraInfo
+from realtime_urdf_filter_amd._capi import projection_from_intrinsics
 
 EXAMPLE_URDF = """<robot name="example">
     <link name="world"/>
@@ -142,13 +143,14 @@ _robot_cache = {}
 
 
 def pr2_workload(n_streams, width=640, height=480, total_triangles=250000, seed=7, first_state_seed=1000,
-                 walls=False):
+                 walls=False, near_arm=False):
     """C2/C3 (and C4 with walls=True): synthetic PR2-like robot, one random joint state per stream,
     camera = the head-mounted RGB optical frame, fixed frame = base_footprint."""
     key = (total_triangles, seed)
     if key not in _robot_cache:
         _robot_cache[key] = synthetic.SyntheticRobot(total_triangles, seed)
     robot = _robot_cache[key]
+    joint_state = robot.near_arm_joint_state if near_arm else robot.random_joint_state
     xml = robot.to_urdf_xml()
     model = urdf.Model.from_string(xml)
 
@@ -158,7 +160,7 @@ def pr2_workload(n_streams, width=640, height=480, total_triangles=250000, seed=
 
     tf0 = urdf.StaticTransformProvider()
     rd = URDFRenderer(xml, "", robot.camera_frame, robot.fixed_frame, tf0, "visual", 1.0, [], loader)
-    w = Workload("PR2-like %dk triangles x %d streams" % (robot.n_triangles() // 1000, n_streams), width, height, n_streams)
+    w = Workload("PR2-like %dk triangles x %d streams%s" % (robot.n_triangles() // 1000, n_streams, ", forearm in front of the lens" if near_arm else ""), width, height, n_streams)
     w.models = [[r.draws for r in rd.renderables_]]
     L = len(rd.renderables_)
     link_tf = np.zeros((n_streams, L, 16))
@@ -170,7 +172,7 @@ def pr2_workload(n_streams, width=640, height=480, total_triangles=250000, seed=
         w.models.append([r.draws for r in wall_rd.renderables_])
         wall_tf = np.zeros((n_streams, len(wall_rd.renderables_), 16))
     for s in range(n_streams):
-        q = robot.random_joint_state(first_state_seed + s)
+        q = joint_state(first_state_seed + s)
         fk = urdf.forward_kinematics(model, q)
         tf = urdf.StaticTransformProvider()
         tf.set_frames(fk, "/")
@@ -194,5 +196,5 @@ def pr2_workload(n_streams, width=640, height=480, total_triangles=250000, seed=
     strip = lambda n: n[1:] if n.startswith("/") else n
     w.kinematics = urdf.kinematic_arrays(model, [strip(r.name) for r in rd.renderables_], [r.link_offset for r in rd.renderables_])
     w.camera_frame_index = w.kinematics["frame_index"][robot.camera_frame]
-    w.joint_q = np.stack([urdf.joint_vector(w.kinematics, robot.random_joint_state(first_state_seed + s)) for s in range(n_streams)])
+    w.joint_q = np.stack([urdf.joint_vector(w.kinematics, joint_state(first_state_seed + s)) for s in range(n_streams)])
     return w

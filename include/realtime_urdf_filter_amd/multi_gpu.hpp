@@ -1,0 +1,197 @@
+// multi_gpu.hpp -- one host process, one thread and one rtuf_context per GPU.
+//
+// Camera streams are independent, so a job is partitioned with NO data-path collective:
+//   * block shares   (BASELINE config 3 / 4): streams [first, first + count) of the job on device d, geometry replicated
+//   * model shares   (BASELINE config 5):     URDF m lives on device m % N, a device holds only its own robots' streams
+// RCCL carries only the trivial end-of-run gather ({frames, seconds, mismatches} per device: one ncclAllGather of three
+// doubles) and, optionally, the all-gather of the bit-packed masks (38 KB per VGA frame) for a consumer that wants every
+// stream's mask on every GPU.  The masks can also go peer to peer: xGMI is a point-to-point fabric (7 links per GPU), so
+// every device writes its slice straight into each peer's buffer with hipMemcpyPeerAsync -- one hop, all links busy --
+// instead of passing through a ring.
+//
+// The reference has no multi-GPU notion at all (one GL context, one camera: src/urdf_filter.cpp:207-267); this header is
+// the C++ twin of realtime_urdf_filter_amd/sharding.py + the collective lines of bench.py for hosts that stay C++ / ROS.
+// Header-only; needs the HIP runtime and RCCL headers (hipcc, -lrtuf -lrccl).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "rtuf.h"
+
+namespace realtime_urdf_filter {
+namespace multi_gpu {
+
+// Contiguous block partition of range(n_items): (first, count) of `rank`'s share; the first n_items % world ranks get one
+// extra item.  Same rule as sharding.shard_range.
+inline std::pair<int, int> shard_range(int n_items, int world, int rank)
+{
+  if (world <= 0 || rank < 0 || rank >= world) throw std::invalid_argument("bad world / rank");
+  const int base = n_items / world, extra = n_items % world;
+  return {rank * base + (rank < extra ? rank : extra), base + (rank < extra ? 1 : 0)};
+}
+
+// BASELINE config 5: URDF m lives on device m % world.  Same rule as sharding.models_for_rank.
+inline std::vector<int> models_for_rank(int n_models, int world, int rank)
+{
+  std::vector<int> out;
+  for (int m = rank; m < n_models; m += world) out.push_back(m);
+  return out;
+}
+
+struct DeviceReport {
+  double frames = 0, seconds = 0, mismatches = 0;      // doubles: they travel as one ncclDouble triple
+};
+
+inline void check_hip(hipError_t e, const char* what)
+{
+  if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+inline void check_nccl(ncclResult_t r, const char* what)
+{
+  if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r));
+}
+
+// The devices of one node: a context, a HIP stream for the collectives and an RCCL communicator each.
+class DeviceGroup {
+ public:
+  // devices: HIP device ids (e.g. {0, 1, ..., 7}); streams_per_device[i]: max_streams of device i's context
+  DeviceGroup(const std::vector<int>& devices, int width, int height, const std::vector<int>& streams_per_device, const rtuf_params& params)
+      : devices_(devices), ctx_(devices.size(), nullptr), comm_(devices.size(), nullptr), stream_(devices.size(), nullptr),
+        d_report_(devices.size(), nullptr)
+  {
+    if (devices.empty() || streams_per_device.size() != devices.size()) throw std::invalid_argument("device / stream lists differ in length");
+    for (size_t i = 0; i < devices_.size(); i++) {
+      if (streams_per_device[i] <= 0) continue;          // (a device without a share keeps no context but still takes part in the collectives)
+      const int rc = rtuf_create(&ctx_[i], devices_[i], width, height, streams_per_device[i], &params);
+      if (rc != RTUF_OK) {
+        const std::string msg = rtuf_last_error(nullptr);
+        destroy();
+        throw std::runtime_error("rtuf_create on device " + std::to_string(devices_[i]) + ": " + msg);
+      }
+    }
+    // single-process communicator set: one rank per device, in the order of `devices`
+    check_nccl(ncclCommInitAll(comm_.data(), (int)devices_.size(), devices_.data()), "ncclCommInitAll");
+    for (size_t i = 0; i < devices_.size(); i++) {
+      check_hip(hipSetDevice(devices_[i]), "hipSetDevice");
+      check_hip(hipStreamCreateWithFlags(&stream_[i], hipStreamNonBlocking), "hipStreamCreate");
+      check_hip(hipMalloc(&d_report_[i], sizeof(double) * 3 * (1 + devices_.size())), "hipMalloc(report)");
+    }
+  }
+  DeviceGroup(const DeviceGroup&) = delete;
+  DeviceGroup& operator=(const DeviceGroup&) = delete;
+  ~DeviceGroup() { destroy(); }
+
+  int size() const { return (int)devices_.size(); }
+  int device(int i) const { return devices_[i]; }
+  rtuf_context* context(int i) const { return ctx_[i]; }
+
+  // Runs f(i) for every device on a host thread of its own (the device is current on that thread) and joins them:
+  // the per-frame loop of every device -- stage poses, enqueue, retire -- runs concurrently with the others'.
+  void for_each_device(const std::function<void(int)>& f)
+  {
+    std::vector<std::thread> th;
+    std::vector<std::string> err(devices_.size());
+    for (size_t i = 0; i < devices_.size(); i++)
+      th.emplace_back([&, i] {
+        try {
+          check_hip(hipSetDevice(devices_[i]), "hipSetDevice");
+          f((int)i);
+        } catch (const std::exception& e) { err[i] = e.what(); }
+      });
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < err.size(); i++)
+      if (!err[i].empty()) throw std::runtime_error("device " + std::to_string(devices_[i]) + ": " + err[i]);
+  }
+
+  // The trivial gather: every device contributes one report, all devices (and the host) get all of them.
+  // One ncclAllGather of three doubles per device inside a group call (single-process multi-device use of RCCL).
+  std::vector<DeviceReport> gather_reports(const std::vector<DeviceReport>& mine)
+  {
+    const size_t n = devices_.size();
+    if (mine.size() != n) throw std::invalid_argument("one report per device");
+    for (size_t i = 0; i < n; i++) {
+      check_hip(hipSetDevice(devices_[i]), "hipSetDevice");
+      const double v[3] = {mine[i].frames, mine[i].seconds, mine[i].mismatches};
+      check_hip(hipMemcpyAsync(d_report_[i], v, sizeof v, hipMemcpyHostToDevice, stream_[i]), "report upload");
+    }
+    check_nccl(ncclGroupStart(), "ncclGroupStart");
+    for (size_t i = 0; i < n; i++)
+      check_nccl(ncclAllGather(d_report_[i], d_report_[i] + 3, 3, ncclDouble, comm_[i], stream_[i]), "ncclAllGather(reports)");
+    check_nccl(ncclGroupEnd(), "ncclGroupEnd");
+    std::vector<DeviceReport> all(n);
+    std::vector<double> host(3 * n);
+    for (size_t i = 0; i < n; i++) {
+      check_hip(hipSetDevice(devices_[i]), "hipSetDevice");
+      check_hip(hipMemcpyAsync(host.data(), d_report_[i] + 3, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_[i]), "report download");
+      check_hip(hipStreamSynchronize(stream_[i]), "hipStreamSynchronize");
+      // every device must hold the same gathered table
+      for (size_t k = 0; k < n; k++) {
+        const DeviceReport r{host[3 * k], host[3 * k + 1], host[3 * k + 2]};
+        if (i == 0) all[k] = r;
+        else if (r.frames != all[k].frames || r.seconds != all[k].seconds || r.mismatches != all[k].mismatches)
+          throw std::runtime_error("all-gather: devices disagree on the gathered reports");
+      }
+    }
+    return all;
+  }
+
+  // All-gather of the bit-packed masks (rtuf_filter_batch_device_bits output): device i holds `streams[i]` frames of
+  // `words` 32-bit words at d_bits[i]; afterwards d_all[i] on EVERY device holds all frames, device 0's first.
+  // direct = true : every device writes its slice into each peer's buffer (hipMemcpyPeerAsync: point to point over xGMI)
+  // direct = false: ncclAllGather; RCCL needs equal contributions, so slices are padded to the largest share and d_all
+  //                 must hold size() * max(streams) frames (slice i starts at i * max(streams) frames)
+  void all_gather_mask_bits(const std::vector<const uint32_t*>& d_bits, const std::vector<int>& streams, size_t words,
+                            const std::vector<uint32_t*>& d_all, bool direct)
+  {
+    const size_t n = devices_.size();
+    if (d_bits.size() != n || streams.size() != n || d_all.size() != n) throw std::invalid_argument("one buffer per device");
+    int most = 0;
+    for (int s : streams) most = s > most ? s : most;
+    if (direct) {
+      size_t first = 0;
+      for (size_t i = 0; i < n; i++) {
+        check_hip(hipSetDevice(devices_[i]), "hipSetDevice");
+        const size_t bytes = (size_t)streams[i] * words * sizeof(uint32_t);
+        for (size_t e = 0; e < n && bytes; e++)
+          check_hip(hipMemcpyPeerAsync(d_all[e] + first * words, devices_[e], d_bits[i], devices_[i], bytes, stream_[i]), "hipMemcpyPeerAsync");
+        first += (size_t)streams[i];
+      }
+    } else {
+      check_nccl(ncclGroupStart(), "ncclGroupStart");
+      for (size_t i = 0; i < n; i++)
+        check_nccl(ncclAllGather(d_bits[i], d_all[i], (size_t)most * words, ncclUint32, comm_[i], stream_[i]), "ncclAllGather(masks)");
+      check_nccl(ncclGroupEnd(), "ncclGroupEnd");
+    }
+    for (size_t i = 0; i < n; i++) {
+      check_hip(hipSetDevice(devices_[i]), "hipSetDevice");
+      check_hip(hipStreamSynchronize(stream_[i]), "hipStreamSynchronize");
+    }
+  }
+
+ private:
+  void destroy()
+  {
+    for (size_t i = 0; i < devices_.size(); i++) {
+      if (ctx_[i]) { rtuf_destroy(ctx_[i]); ctx_[i] = nullptr; }
+      (void)hipSetDevice(devices_[i]);
+      if (d_report_[i]) { (void)hipFree(d_report_[i]); d_report_[i] = nullptr; }
+      if (stream_[i]) { (void)hipStreamDestroy(stream_[i]); stream_[i] = nullptr; }
+      if (comm_[i]) { (void)ncclCommDestroy(comm_[i]); comm_[i] = nullptr; }
+    }
+  }
+  std::vector<int> devices_;
+  std::vector<rtuf_context*> ctx_;
+  std::vector<ncclComm_t> comm_;
+  std::vector<hipStream_t> stream_;
+  std::vector<double*> d_report_;
+};
+
+}  // namespace multi_gpu
+}  // namespace realtime_urdf_filter

@@ -241,11 +241,53 @@ class RealtimeURDFFilter {
   // src/urdf_filter.cpp:503-744 without GL
   void render(const double* camera_projection_matrix, double timestamp = 0.0)
   {
-    if (!ctx_) return;
+    if (!ctx_ || !stage_frame(camera_projection_matrix, timestamp)) return;
+    check(rtuf_filter(ctx_, pending_buffer_, nullptr, width_, height_));
+    masked_depth_ = rtuf_get_masked_depth(ctx_);
+    if (need_mask_) mask_ = rtuf_get_mask(ctx_);
+  }
+
+  // ---- beyond the reference's surface: what a ROS adapter needs to leave the CPU out of the pixel path ----------------
+  // The reference converts 16UC1 <-> 32FC1 with cv::Mat::convertTo around filter() (src/urdf_filter.cpp:280-289, :308-312);
+  // here the frame goes to the GPU in the encoding it arrived in and the outputs land in the caller's buffers (e.g. the
+  // data vectors of the messages to publish).  Either output may be null.  Returns false when the camera transform is not
+  // available yet (nothing was written; the reference's quirk Q6 keeps the previous frame instead).
+  bool filter_into(const void* depth, bool is_16uc1, double* glTf, int width, int height, double timestamp, void* masked_out, uint8_t* mask_out)
+  {
+    prepare(width, height);
+    if (renderers_.empty() || !stage_frame(glTf, timestamp)) return false;
+    if (!masked_out) {
+      // mask only: one bit per pixel comes back over the bus (rtuf_filter_batch_bits*), expanded here
+      bits_.resize(rtuf_mask_bits_words(width_, height_));
+      uint32_t* bits = bits_.data();
+      const void* in = depth;
+      check(is_16uc1 ? rtuf_filter_batch_bits_u16_async(ctx_, 1, reinterpret_cast<const uint16_t* const*>(&in), &bits)
+                     : rtuf_filter_batch_bits_async(ctx_, 1, reinterpret_cast<const float* const*>(&in), &bits));
+      check(rtuf_sync(ctx_));
+      if (mask_out) check(rtuf_expand_mask_bits(depth, is_16uc1 ? 1 : 0, bits, width_, height_, (float)filter_replace_value_, nullptr, mask_out));
+      return true;
+    }
+    const void* in = depth;
+    check(is_16uc1 ? rtuf_filter_batch_u16(ctx_, 1, reinterpret_cast<const uint16_t* const*>(&in), reinterpret_cast<uint16_t* const*>(&masked_out), mask_out ? &mask_out : nullptr)
+                   : rtuf_filter_batch(ctx_, 1, reinterpret_cast<const float* const*>(&in), reinterpret_cast<float* const*>(&masked_out), mask_out ? &mask_out : nullptr));
+    return true;
+  }
+
+ private:
+  void prepare(int width, int height)
+  {
+    if (width_ == width && height_ == height) return;
+    width_ = width;
+    height_ = height;
+    this->initGL();
+  }
+  // camera + link poses + uniforms of one frame (the part of render() before the draw calls, src/urdf_filter.cpp:576-632)
+  bool stage_frame(const double* camera_projection_matrix, double timestamp)
+  {
     Transform camera_transform;
     if (!tf_.lookup(cam_frame_, fixed_frame_, camera_transform)) {
       std::fprintf(stderr, "[realtime_urdf_filter] no transform %s <- %s\n", cam_frame_.c_str(), fixed_frame_.c_str());
-      return;                                     // outputs keep the previous frame (quirk Q6)
+      return false;                               // outputs keep the previous frame (quirk Q6)
     }
     double off[16], cam[16];
     const Transform offset = Transform::from_quaternion({params_.camera_offset_rotation[0], params_.camera_offset_rotation[1], params_.camera_offset_rotation[2], params_.camera_offset_rotation[3]},
@@ -274,11 +316,10 @@ class RealtimeURDFFilter {
       p.filter_replace_value = (float)filter_replace_value_;
       check(rtuf_set_params(ctx_, &p));
     }
-    check(rtuf_filter(ctx_, pending_buffer_, nullptr, width_, height_));
-    masked_depth_ = rtuf_get_masked_depth(ctx_);
-    if (need_mask_) mask_ = rtuf_get_mask(ctx_);
+    return true;
   }
 
+ public:
   // copy char buffer to the device (src/urdf_filter.cpp:332-353): deferred to render(), which uploads
   void textureBufferFromDepthBuffer(unsigned char* buffer, int /*size_in_bytes*/) { pending_buffer_ = buffer; }
 
@@ -312,6 +353,7 @@ class RealtimeURDFFilter {
   rtuf_context* ctx_ = nullptr;
   std::vector<int> model_ids_;
   unsigned char* pending_buffer_ = nullptr;
+  std::vector<uint32_t> bits_;
 };
 
 }  // namespace realtime_urdf_filter

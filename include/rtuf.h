@@ -19,8 +19,8 @@
  * bound to one GPU and used from one host thread at a time; several contexts (one per
  * GPU) may run concurrently.  All matrices are OpenGL style: 16 values, column-major.
  *
- * There is NO CPU fallback: without a visible gfx950 device rtuf_create() fails
- * with RTUF_ERR_NO_DEVICE.
+ * There is NO CPU fallback: without a visible gfx950 device (hipDeviceProp_t::gcnArchName) rtuf_create()
+ * fails with RTUF_ERR_NO_DEVICE.
  */
 #ifndef RTUF_H_
 #define RTUF_H_
@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTUF_ABI_VERSION 3
+#define RTUF_ABI_VERSION 4
 
 typedef struct rtuf_context rtuf_context;
 
@@ -261,7 +261,9 @@ const float *rtuf_get_masked_depth(const rtuf_context *ctx);      /* getMaskedDe
 const uint8_t *rtuf_get_mask(const rtuf_context *ctx);            /* mask_ */
 
 int rtuf_sync(rtuf_context *ctx);
-/* The HIP stream all work of this context is enqueued on (for callers that time with HIP events). */
+/* The HIP stream the raster stage of this context is enqueued on (for callers that time with HIP events or order their
+ * own work behind a batch).  A single-pipeline concept: a context created with rtuf_params.pipelines > 1 spreads its
+ * batches over several internal streams and returns NULL here. */
 void *rtuf_stream(rtuf_context *ctx);
 
 /* Counters of the last batch and kernel timings measured with HIP events on the context's
@@ -281,6 +283,15 @@ typedef struct {
   uint64_t timed_batches;           /* batches retired since rtuf_enable_timing, and the sums  */
   double sum_ms_pose, sum_ms_setup, sum_ms_raster, sum_ms_compare, sum_ms_total;   /* of their times */
   double sum_ms_clip;
+  /* ABI 4 */
+  uint64_t device_bytes;            /* device memory the context holds right now (all pipelines)                      */
+  uint64_t occluded_entries;        /* (record, tile) pairs never appended: they lie behind a triangle that covers the tile */
+  uint32_t cover_tiles;             /* tiles whose initial depth keys came from a triangle covering the whole tile     */
+  uint32_t exact_tiles;             /* tiles that ran the exact-z pass (a winner with window z <= 0.5)                 */
+  uint32_t work_items;              /* set-up work items (chunk x up to 3 streams that see it) of the last batch       */
+  uint32_t zero_survivor_items;     /* ... of which no triangle survived the clip / sub-pixel culls                    */
+  uint64_t raster_atomics;          /* instrumented builds (-DRTUF_COUNT) only: depth tests the tile kernel issued      */
+  uint64_t drawn_pixels;            /* instrumented builds only: pixels whose final depth key is not the background's   */
 } rtuf_stats;
 int rtuf_get_stats(rtuf_context *ctx, rtuf_stats *out);
 /* Per-kernel HIP-event timing (off by default: every event costs a few microseconds of stream

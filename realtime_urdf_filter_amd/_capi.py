@@ -16,7 +16,7 @@ RTUF_OK = 0
 RTUF_ERR_NO_DEVICE = -2
 OP_NONE, OP_SCALE, OP_TRANSLATE = 0, 1, 2
 FLAG_TWO_KERNEL = 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 #: every symbol include/rtuf.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -48,7 +48,11 @@ class Stats(ctypes.Structure):
                 ("ms_compare", ctypes.c_float), ("ms_total", ctypes.c_float), ("ms_clip", ctypes.c_float),
                 ("timed_batches", ctypes.c_uint64), ("sum_ms_pose", ctypes.c_double), ("sum_ms_setup", ctypes.c_double),
                 ("sum_ms_raster", ctypes.c_double), ("sum_ms_compare", ctypes.c_double), ("sum_ms_total", ctypes.c_double),
-                ("sum_ms_clip", ctypes.c_double)]
+                ("sum_ms_clip", ctypes.c_double),
+                ("device_bytes", ctypes.c_uint64), ("occluded_entries", ctypes.c_uint64),
+                ("cover_tiles", ctypes.c_uint32), ("exact_tiles", ctypes.c_uint32),
+                ("work_items", ctypes.c_uint32), ("zero_survivor_items", ctypes.c_uint32),
+                ("raster_atomics", ctypes.c_uint64), ("drawn_pixels", ctypes.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

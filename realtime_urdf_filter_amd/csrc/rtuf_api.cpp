@@ -104,11 +104,15 @@ struct rtuf_context {
   // rasteriser working set
   int group = 0;                       // in-flight streams per launch group
   uint32_t capacity = 0, fcapacity = 0, clip_capacity = 0;
-  PackedTri* d_bins = nullptr; uint32_t* d_bin_count = nullptr; ClipItem* d_clip_list = nullptr; uint32_t items_hint = 0;
+  PackedTri* d_bins = nullptr; BinHeader* d_bin_hdr = nullptr;
+  Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
+  ClipItem* d_clip_list = nullptr; uint32_t items_hint = 0;
   float4* d_clip_spill = nullptr;
   BigRec* d_big_list = nullptr; uint32_t big_capacity = 0;      // many-tile records (per counter shard), see bigrec_kernel
-  Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
   float* d_zsurface = nullptr;
+  // every device allocation of the context goes through dev_alloc / dev_free: rtuf_stats.device_bytes is their sum
+  std::unordered_map<void*, size_t> dev_blocks;
+  size_t device_bytes = 0;
 
   // staging for the host-pointer API
   hipStream_t h2d = nullptr, d2h = nullptr;  // copy streams of the host-plane calls (rtuf_filter_batch*)
@@ -163,6 +167,8 @@ struct rtuf_context {
   // batch's raster kernels, which a graph on the main stream would serialise (batch = 1: 75 us plain, 94 us as a graph).
   // Cleared when the runtime refuses stream capture / instantiation.
   bool graphs_ok = false;
+  uint32_t graph_hits = 0, graph_misses = 0; // replays / captures: a caller that never repeats an argument set (fresh output buffers
+                                             // every frame) would pay a capture + instantiate per batch -- then graphs are switched off
   int oldest = 0;                            // ring index of the oldest batch in flight
   int pending = 0;                           // batches in flight
 
@@ -201,6 +207,72 @@ struct rtuf_context {
       return (ctx)->fail(e_ == hipErrorOutOfMemory ? RTUF_ERR_OOM : RTUF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
+template <typename T>
+static hipError_t dev_alloc(rtuf_context* c, T** p, size_t bytes)
+{
+  void* q = nullptr;
+  const hipError_t e = hipMalloc(&q, bytes ? bytes : 1);
+  *p = e == hipSuccess ? static_cast<T*>(q) : nullptr;
+  if (e == hipSuccess) { c->dev_blocks[q] = bytes; c->device_bytes += bytes; }
+  return e;
+}
+template <typename T>
+static void dev_free(rtuf_context* c, T*& p)
+{
+  if (!p) return;
+  auto it = c->dev_blocks.find((void*)p);
+  if (it != c->dev_blocks.end()) { c->device_bytes -= it->second; c->dev_blocks.erase(it); }
+  (void)hipFree((void*)p);
+  p = nullptr;
+}
+
+// A working buffer of the rasteriser is too small for the batch in flight: the new one is allocated BEFORE the old one is
+// freed whenever both fit (a failed allocation then leaves the context as it was, and the call fails with RTUF_ERR_OOM);
+// only when they do not fit together the old one goes first, and a failure after that marks the context unusable.
+template <typename T>
+static int regrow(rtuf_context* c, T*& buf, size_t new_bytes, const char* what)
+{
+  T* fresh = nullptr;
+  hipError_t e = dev_alloc(c, &fresh, new_bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    dev_free(c, buf);
+    e = dev_alloc(c, &fresh, new_bytes);
+    if (e != hipSuccess) {
+      c->broken = true;
+      return c->fail(RTUF_ERR_OOM, "growing the %s to %zu bytes failed: %s", what, new_bytes, hipGetErrorString(e));
+    }
+  } else {
+    dev_free(c, buf);
+  }
+  buf = fresh;
+  c->stats.regrowths++;
+  return RTUF_OK;
+}
+
+// Bins sized from what the batch asked for: a quarter above the fullest record / fragment bin, in steps of 256 / 1024 entries
+// (never smaller than they are).  One allocation holds what used to be sized for the worst tile any scene could have.
+static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
+{
+  const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
+  auto round_up = [](uint64_t v, uint64_t q) { return (uint32_t)std::min<uint64_t>(((v + q - 1) / q) * q, 0x7fffffffu); };
+  const uint32_t cap = std::max(c->capacity, needed > c->capacity ? round_up((uint64_t)needed + needed / 4, 256) : c->capacity);
+  const uint32_t fcap = std::max(c->fcapacity, fneeded > c->fcapacity ? round_up((uint64_t)fneeded + fneeded / 4, 1024) : c->fcapacity);
+  if ((size_t)c->group * tiles * ((size_t)cap * sizeof(PackedTri) + (size_t)fcap * sizeof(Frag)) > ((size_t)200 << 30))
+    return c->fail(RTUF_ERR_CAPACITY, "bin capacity %u/%u too large", cap, fcap);
+  if (cap != c->capacity) {
+    const int rc = regrow(c, c->d_bins, (size_t)c->group * tiles * cap * sizeof(PackedTri), "record bins");
+    if (rc != RTUF_OK) return rc;
+    c->capacity = cap;
+  }
+  if (fcap != c->fcapacity) {
+    const int rc = regrow(c, c->d_fbins, (size_t)c->group * tiles * fcap * sizeof(Frag), "fragment bins");
+    if (rc != RTUF_OK) return rc;
+    c->fcapacity = fcap;
+  }
+  return RTUF_OK;
+}
+
 // Setters of single-buffered state (model selection, parameters, forward-kinematics root poses / enable flags) wait for
 // the batches in flight, which may still read it (or would re-read it on a bin regrowth).  The per-frame pose setters --
 // joint positions, cameras, link matrices -- are staged in rings and never wait.
@@ -220,23 +292,28 @@ struct rtuf_context {
     if (rc_ < 0) (c)->error = k->error;                                                    \
     return rc_;                                                                            \
   }
-// the kid that takes the next batch; keeps `order` in step with what that kid will retire on its own
-static rtuf_context* take_next_kid(rtuf_context* c)
+// The kid that takes the next batch is chosen without side effects; the rotation and `order` (the kids of the batches in
+// flight, oldest first) change only after the call, from what the kid really did: a successful call adds one entry, and
+// whatever the kid retired on the way (its oldest when it was full, everything after a failed regrowth) is trimmed from
+// the front -- so a call that fails before or after retiring leaves `order` describing exactly the batches in flight.
+static void settle_order(rtuf_context* c, int j, bool accepted)
 {
-  const int j = c->next_kid;
-  const int limit = (c->params.flags & RTUF_FLAG_TWO_KERNEL) ? 1 : kMaxInflight;
-  if ((int)std::count(c->order.begin(), c->order.end(), j) >= limit)
-    c->order.erase(std::find(c->order.begin(), c->order.end(), j));      // the kid retires its oldest itself when it is full
-  c->order.push_back(j);
-  c->last_kid = j;
-  c->next_kid = (j + 1) % (int)c->kids.size();
-  return c->kids[j];
+  if (accepted) {
+    c->order.push_back(j);
+    c->last_kid = j;
+    c->next_kid = (j + 1) % (int)c->kids.size();
+  }
+  int have = (int)std::count(c->order.begin(), c->order.end(), j);
+  for (const int want = c->kids[j]->pending; have > want; have--)
+    c->order.erase(std::find(c->order.begin(), c->order.end(), j));
 }
 #define KIDS_NEXT(c, expr)                                                                 \
   if ((c) && !(c)->kids.empty()) {                                                         \
-    rtuf_context* k = take_next_kid(c);                                                    \
+    const int j_ = (c)->next_kid;                                                          \
+    rtuf_context* k = (c)->kids[j_];                                                       \
     const int rc_ = (expr);                                                                \
-    if (rc_ < 0) { (c)->error = k->error; (c)->order.pop_back(); }                         \
+    settle_order((c), j_, rc_ >= 0);                                                       \
+    if (rc_ < 0) (c)->error = k->error;                                                    \
     return rc_;                                                                            \
   }
 
@@ -278,6 +355,18 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
     snprintf(g_create_error, sizeof g_create_error, "unknown rtuf_params.flags bits 0x%x", params->flags & ~kKnownFlags);
     return RTUF_ERR_INVALID;
   }
+  {
+    // the kernels exist for gfx950 (MI350X / MI355X) only: on any other device the first launch would fail with an opaque
+    // "invalid device function"
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      snprintf(g_create_error, sizeof g_create_error,
+               "device %d is %s, not gfx950 (MI350X / MI355X): this library carries gfx950 code only and has no CPU fallback",
+               device_id, e == hipSuccess ? prop.gcnArchName : hipGetErrorString(e));
+      return RTUF_ERR_NO_DEVICE;
+    }
+  }
   rtuf_context* c = new (std::nothrow) rtuf_context();
   if (!c) return RTUF_ERR_OOM;
   c->device = device_id;
@@ -315,12 +404,11 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
 static void free_frame_buffers(rtuf_context* c)
 {
   hipSetDevice(c->device);
-  auto dfree = [](auto*& p) { if (p) { hipFree(p); p = nullptr; } };
   auto hfree = [](auto*& p) { if (p) { hipHostFree(p); p = nullptr; } };
-  dfree(c->d_model_mask);
-  for (auto& b : c->batch) { dfree(b.d_cams); dfree(b.d_link_tf); dfree(b.d_mvp); dfree(b.d_bg); dfree(b.d_items); dfree(b.d_counters); }
-  dfree(c->d_bins); dfree(c->d_bin_count); dfree(c->d_fbins); dfree(c->d_fbin_count); dfree(c->d_clip_list); dfree(c->d_clip_spill); dfree(c->d_big_list); dfree(c->d_zsurface);
-  for (auto& b : c->batch) { dfree(b.st_depth); dfree(b.st_masked); dfree(b.st_mask); b.st_streams = 0; dfree(b.st_bits); b.st_bits_streams = 0; }
+  dev_free(c, c->d_model_mask);
+  for (auto& b : c->batch) { dev_free(c, b.d_cams); dev_free(c, b.d_link_tf); dev_free(c, b.d_mvp); dev_free(c, b.d_bg); dev_free(c, b.d_items); dev_free(c, b.d_counters); }
+  dev_free(c, c->d_bins); dev_free(c, c->d_bin_hdr); dev_free(c, c->d_fbins); dev_free(c, c->d_fbin_count); dev_free(c, c->d_clip_list); dev_free(c, c->d_clip_spill); dev_free(c, c->d_big_list); dev_free(c, c->d_zsurface);
+  for (auto& b : c->batch) { dev_free(c, b.st_depth); dev_free(c, b.st_masked); dev_free(c, b.st_mask); b.st_streams = 0; dev_free(c, b.st_bits); b.st_bits_streams = 0; }
   for (auto*& p : c->ring_cams) hfree(p);
   for (auto*& p : c->ring_link_tf) hfree(p);
   c->h_cams = nullptr; c->h_link_tf = nullptr;
@@ -340,15 +428,14 @@ void rtuf_destroy(rtuf_context* c)
   if (c->d2h) hipStreamSynchronize(c->d2h);
   for (HostModel& m : c->models) {
     Kinematics& k = m.kin;
-    hipFree(k.d_depth); hipFree(k.d_parent); hipFree(k.d_type); hipFree(k.d_origin); hipFree(k.d_axis); hipFree(k.d_link_frame); hipFree(k.d_link_offset);
-    hipFree(k.d_root); hipFree(k.d_enabled);
+    dev_free(c, k.d_depth); dev_free(c, k.d_parent); dev_free(c, k.d_type); dev_free(c, k.d_origin); dev_free(c, k.d_axis); dev_free(c, k.d_link_frame); dev_free(c, k.d_link_offset);
+    dev_free(c, k.d_root); dev_free(c, k.d_enabled);
     for (double* q : k.h_q) if (q) hipHostFree(q);
     if (k.h_root) hipHostFree(k.h_root);
     if (k.h_enabled) hipHostFree(k.h_enabled);
   }
   free_frame_buffers(c);
-  auto dfree = [](auto*& p) { if (p) { hipFree(p); p = nullptr; } };
-  dfree(c->d_cverts); dfree(c->d_ctris); dfree(c->d_corder); dfree(c->d_chunks); dfree(c->d_draws);
+  dev_free(c, c->d_cverts); dev_free(c, c->d_ctris); dev_free(c, c->d_corder); dev_free(c, c->d_chunks); dev_free(c, c->d_draws);
   for (auto& b : c->batch) {
     for (hipEvent_t ev : b.events) hipEventDestroy(ev);
     if (b.done) hipEventDestroy(b.done);
@@ -392,7 +479,7 @@ int rtuf_set_params(rtuf_context* c, const rtuf_params* p)
   const bool two_now = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
   if (c->finalized && two_now && !two_before && !c->d_zsurface) {
     hipSetDevice(c->device);
-    HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));
+    HIP_TRY(c, dev_alloc(c, &c->d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));
   }
   return RTUF_OK;
 }
@@ -467,13 +554,13 @@ static int alloc_frame_buffers(rtuf_context* c)
     HIP_TRY(c, hipHostMalloc(&b.h_counters, sizeof(Counters)));
     if (!b.done) HIP_TRY(c, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
   }
-  HIP_TRY(c, hipMalloc(&c->d_model_mask, sizeof(uint64_t) * N));
+  HIP_TRY(c, dev_alloc(c, &c->d_model_mask, sizeof(uint64_t) * N));
   for (auto& b : c->batch) {
-    HIP_TRY(c, hipMalloc(&b.d_cams, sizeof(Camera) * N));
-    HIP_TRY(c, hipMalloc(&b.d_link_tf, sizeof(double) * 16 * L * N));
-    HIP_TRY(c, hipMalloc(&b.d_mvp, sizeof(float) * 16 * (size_t)(c->n_draws + 1) * N));
-    HIP_TRY(c, hipMalloc(&b.d_bg, sizeof(BgInfo) * N));
-    HIP_TRY(c, hipMalloc(&b.d_counters, sizeof(Counters)));
+    HIP_TRY(c, dev_alloc(c, &b.d_cams, sizeof(Camera) * N));
+    HIP_TRY(c, dev_alloc(c, &b.d_link_tf, sizeof(double) * 16 * L * N));
+    HIP_TRY(c, dev_alloc(c, &b.d_mvp, sizeof(float) * 16 * (size_t)(c->n_draws + 1) * N));
+    HIP_TRY(c, dev_alloc(c, &b.d_bg, sizeof(BgInfo) * N));
+    HIP_TRY(c, dev_alloc(c, &b.d_counters, sizeof(Counters)));
     HIP_TRY(c, hipMemset(b.d_counters, 0, sizeof(Counters)));
     b.dirty_cams = b.dirty_link_tf = true; b.uploaded_streams = 0;
     if (!b.posed) HIP_TRY(c, hipEventCreateWithFlags(&b.posed, hipEventDisableTiming));
@@ -497,31 +584,34 @@ static int alloc_frame_buffers(rtuf_context* c)
   // (1024 streams in one group: 522 k frames/s, in four groups of 256: 460 k)
   int G = c->params.max_inflight_streams ? (int)c->params.max_inflight_streams : 1024;
   G = std::min(G, N);
-  uint32_t cap = c->params.bin_capacity;
-  if (!cap) cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->n_tris + 16, 256), 4 * kTileW * kTileH);   // 4 records per tile pixel
-  // the bins (records + fragments) may take a third of the free device memory (96 GiB of an idle MI355X's
-  // 288): beyond that the in-flight group shrinks
+  // Bins: fixed capacity per (stream, tile), direct addressing (one atomicAdd gives the slot: anything cleverer -- paged
+  // bins were built and measured, DESIGN.md section 4b -- costs the two big kernels 8 to 24 %).  What is NOT fixed any more is
+  // the size: 1024 records + 4096 fragments per bin to start with (64 KiB: 2.5 GB for 256 VGA streams), grown on the first
+  // batch to a quarter above the fullest bin that batch produced (the 250 k-triangle robot: 3840 + 13568, 8.7 GB; round 2
+  // reserved 8192 + 32768 = 19.6 GB whatever the scene).  rtuf_params.bin_capacity fixes the starting point.
+  uint32_t cap = c->params.bin_capacity ? c->params.bin_capacity : 1024u;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
   const size_t budget = std::max(free_b / 3, (size_t)1 << 30);
   while (G > 1 && (size_t)G * tiles * cap * (sizeof(PackedTri) + 4 * sizeof(Frag)) > budget) G = (G + 1) / 2;
   c->group = G;
   c->capacity = cap;
-  c->clip_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 8192 / kCounterShards, 1024), (size_t)1 << 22);   // per shard
   c->fcapacity = std::max<uint32_t>(4 * cap, 1024);   // 8-byte fragments of all boxes up to 4x4 pixel centres
-  HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(PackedTri)));
-  HIP_TRY(c, hipMalloc(&c->d_bin_count, (size_t)G * tiles * 2 * sizeof(uint32_t)));      // (front, back) fill per bin
-  HIP_TRY(c, hipMemset(c->d_bin_count, 0, (size_t)G * tiles * 2 * sizeof(uint32_t)));
-  HIP_TRY(c, hipMalloc(&c->d_fbins, (size_t)G * tiles * c->fcapacity * sizeof(Frag)));
-  HIP_TRY(c, hipMalloc(&c->d_fbin_count, (size_t)G * tiles * sizeof(uint32_t)));
-  HIP_TRY(c, hipMemset(c->d_fbin_count, 0, (size_t)G * tiles * sizeof(uint32_t)));
-  HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
-  HIP_TRY(c, hipMalloc(&c->d_clip_spill, clip_spill_bytes()));
+  c->clip_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 8192 / kCounterShards, 1024), (size_t)1 << 22);   // per shard
+  HIP_TRY(c, dev_alloc(c, &c->d_bins, (size_t)G * tiles * cap * sizeof(PackedTri)));
+  HIP_TRY(c, dev_alloc(c, &c->d_bin_hdr, (size_t)G * tiles * sizeof(BinHeader)));
+  HIP_TRY(c, dev_alloc(c, &c->d_fbins, (size_t)G * tiles * c->fcapacity * sizeof(Frag)));
+  HIP_TRY(c, dev_alloc(c, &c->d_fbin_count, (size_t)G * tiles * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemsetAsync(c->d_fbin_count, 0, (size_t)G * tiles * sizeof(uint32_t), c->stream));
+  launch_init_headers(c->d_bin_hdr, (size_t)G * tiles, c->stream);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, dev_alloc(c, &c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
+  HIP_TRY(c, dev_alloc(c, &c->d_clip_spill, clip_spill_bytes(c->clip_capacity)));
   c->big_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 64, 1024), (size_t)1 << 20);                 // per shard
-  HIP_TRY(c, hipMalloc(&c->d_big_list, (size_t)c->big_capacity * kCounterShards * sizeof(BigRec)));
-  for (auto& b : c->batch) HIP_TRY(c, hipMalloc(&b.d_items, (size_t)c->n_chunks * (size_t)max_items_per_chunk(G) * sizeof(WorkItem)));
+  HIP_TRY(c, dev_alloc(c, &c->d_big_list, (size_t)c->big_capacity * kCounterShards * sizeof(BigRec)));
+  for (auto& b : c->batch) HIP_TRY(c, dev_alloc(c, &b.d_items, (size_t)c->n_chunks * (size_t)max_items_per_chunk(G) * sizeof(WorkItem)));
   if (c->params.flags & RTUF_FLAG_TWO_KERNEL)
-    HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)G * c->width * c->height * sizeof(float)));
+    HIP_TRY(c, dev_alloc(c, &c->d_zsurface, (size_t)G * c->width * c->height * sizeof(float)));
   return RTUF_OK;
 }
 
@@ -668,11 +758,11 @@ int rtuf_finalize_models(rtuf_context* c)
   c->n_chunks = (int)chunks.size();
   c->n_cverts = (int64_t)cverts.size();
   if (draws.empty()) draws.push_back(Draw{});
-  HIP_TRY(c, hipMalloc(&c->d_cverts, cverts.size() * sizeof(float4)));
-  HIP_TRY(c, hipMalloc(&c->d_ctris, ctris.size() * sizeof(uint32_t)));
-  HIP_TRY(c, hipMalloc(&c->d_corder, corder.size() * sizeof(uint32_t)));
-  HIP_TRY(c, hipMalloc(&c->d_chunks, chunks.size() * sizeof(Chunk)));
-  HIP_TRY(c, hipMalloc(&c->d_draws, draws.size() * sizeof(Draw)));
+  HIP_TRY(c, dev_alloc(c, &c->d_cverts, cverts.size() * sizeof(float4)));
+  HIP_TRY(c, dev_alloc(c, &c->d_ctris, ctris.size() * sizeof(uint32_t)));
+  HIP_TRY(c, dev_alloc(c, &c->d_corder, corder.size() * sizeof(uint32_t)));
+  HIP_TRY(c, dev_alloc(c, &c->d_chunks, chunks.size() * sizeof(Chunk)));
+  HIP_TRY(c, dev_alloc(c, &c->d_draws, draws.size() * sizeof(Draw)));
   HIP_TRY(c, hipMemcpy(c->d_cverts, cverts.data(), cverts.size() * sizeof(float4), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_ctris, ctris.data(), ctris.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_corder, corder.data(), corder.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -722,6 +812,15 @@ static int take_staged(rtuf_context* c, rtuf_context::StageRing& r, const rtuf_c
     for (const auto& o : c->batch) if (o.active && &o != &b) used[idx_of(o)] = true;
     for (int i = 0; i <= kMaxInflight; i++) if (!used[i]) { r.write = i; break; }
     r.written = false;
+    r.carried = false;
+  } else if (r.write == r.live) {
+    // nothing was staged since the last batch (or ever): the batch reads the live set, so the setters must move on to a
+    // set no batch reads -- a setter called while this batch is in flight would otherwise write into the pinned set its
+    // upload is still reading
+    bool used[kMaxInflight + 1] = {};
+    used[r.live] = true;
+    for (const auto& o : c->batch) if (o.active && &o != &b) used[idx_of(o)] = true;
+    for (int i = 0; i <= kMaxInflight; i++) if (!used[i]) { r.write = i; break; }
     r.carried = false;
   }
   return r.live;
@@ -893,28 +992,47 @@ int rtuf_set_kinematics(rtuf_context* c, int model, int n_frames, const int32_t*
   std::vector<int32_t> depth(n_frames, 0);
   int max_depth = 0;
   for (int i = 0; i < n_frames; i++) { depth[i] = parent[i] < 0 ? 0 : depth[parent[i]] + 1; max_depth = std::max(max_depth, depth[i]); }
-  HIP_TRY(c, hipMalloc(&k.d_depth, sizeof(int32_t) * n_frames));
-  HIP_TRY(c, hipMemcpy(k.d_depth, depth.data(), sizeof(int32_t) * n_frames, hipMemcpyHostToDevice));
+  // all or nothing: a failure part-way releases what this call allocated, so the call can simply be made again
+  auto release = [&]() {
+    dev_free(c, k.d_depth); dev_free(c, k.d_parent); dev_free(c, k.d_type); dev_free(c, k.d_origin); dev_free(c, k.d_axis);
+    dev_free(c, k.d_link_frame); dev_free(c, k.d_link_offset); dev_free(c, k.d_root); dev_free(c, k.d_enabled);
+    for (double*& q : k.h_q) if (q) { hipHostFree(q); q = nullptr; }
+    if (k.h_root) { hipHostFree(k.h_root); k.h_root = nullptr; }
+    if (k.h_enabled) { hipHostFree(k.h_enabled); k.h_enabled = nullptr; }
+  };
+  auto build = [&]() -> hipError_t {
+    hipError_t e;
+#define KIN_TRY(expr) do { e = (expr); if (e != hipSuccess) return e; } while (0)
+    KIN_TRY(dev_alloc(c, &k.d_depth, sizeof(int32_t) * n_frames));
+    KIN_TRY(dev_alloc(c, &k.d_parent, sizeof(int32_t) * n_frames));
+    KIN_TRY(dev_alloc(c, &k.d_type, sizeof(int32_t) * n_frames));
+    KIN_TRY(dev_alloc(c, &k.d_origin, sizeof(double) * 12 * n_frames));
+    KIN_TRY(dev_alloc(c, &k.d_axis, sizeof(double) * 3 * n_frames));
+    KIN_TRY(dev_alloc(c, &k.d_link_frame, sizeof(int32_t) * std::max(n_links, 1)));
+    KIN_TRY(dev_alloc(c, &k.d_link_offset, sizeof(double) * off.size()));
+    KIN_TRY(dev_alloc(c, &k.d_root, sizeof(double) * N * 12));
+    KIN_TRY(dev_alloc(c, &k.d_enabled, N));
+    for (double*& q : k.h_q) KIN_TRY(hipHostMalloc(&q, sizeof(double) * N * n_frames));
+    KIN_TRY(hipHostMalloc(&k.h_root, sizeof(double) * N * 12));
+    KIN_TRY(hipHostMalloc(&k.h_enabled, N));
+    memset(k.h_enabled, 0, N);
+    for (double* q : k.h_q) memset(q, 0, sizeof(double) * N * n_frames);
+    KIN_TRY(hipMemcpy(k.d_depth, depth.data(), sizeof(int32_t) * n_frames, hipMemcpyHostToDevice));
+    KIN_TRY(hipMemcpy(k.d_parent, parent, sizeof(int32_t) * n_frames, hipMemcpyHostToDevice));
+    KIN_TRY(hipMemcpy(k.d_type, joint_type, sizeof(int32_t) * n_frames, hipMemcpyHostToDevice));
+    KIN_TRY(hipMemcpy(k.d_origin, org.data(), sizeof(double) * org.size(), hipMemcpyHostToDevice));
+    KIN_TRY(hipMemcpy(k.d_axis, joint_axis, sizeof(double) * 3 * n_frames, hipMemcpyHostToDevice));
+    if (n_links) KIN_TRY(hipMemcpy(k.d_link_frame, link_frame, sizeof(int32_t) * n_links, hipMemcpyHostToDevice));
+    KIN_TRY(hipMemcpy(k.d_link_offset, off.data(), sizeof(double) * off.size(), hipMemcpyHostToDevice));
+#undef KIN_TRY
+    return hipSuccess;
+  };
+  const hipError_t e = build();
+  if (e != hipSuccess) {
+    release();
+    return c->fail(e == hipErrorOutOfMemory ? RTUF_ERR_OOM : RTUF_ERR_HIP, "rtuf_set_kinematics: %s", hipGetErrorString(e));
+  }
   k.max_depth = max_depth;
-  HIP_TRY(c, hipMalloc(&k.d_parent, sizeof(int32_t) * n_frames));
-  HIP_TRY(c, hipMalloc(&k.d_type, sizeof(int32_t) * n_frames));
-  HIP_TRY(c, hipMalloc(&k.d_origin, sizeof(double) * 12 * n_frames));
-  HIP_TRY(c, hipMalloc(&k.d_axis, sizeof(double) * 3 * n_frames));
-  HIP_TRY(c, hipMalloc(&k.d_link_frame, sizeof(int32_t) * std::max(n_links, 1)));
-  HIP_TRY(c, hipMalloc(&k.d_link_offset, sizeof(double) * off.size()));
-  HIP_TRY(c, hipMalloc(&k.d_root, sizeof(double) * N * 12));
-  HIP_TRY(c, hipMalloc(&k.d_enabled, N));
-  for (double*& q : k.h_q) HIP_TRY(c, hipHostMalloc(&q, sizeof(double) * N * n_frames));
-  HIP_TRY(c, hipHostMalloc(&k.h_root, sizeof(double) * N * 12));
-  HIP_TRY(c, hipHostMalloc(&k.h_enabled, N));
-  memset(k.h_enabled, 0, N);
-  for (double* q : k.h_q) memset(q, 0, sizeof(double) * N * n_frames);
-  HIP_TRY(c, hipMemcpy(k.d_parent, parent, sizeof(int32_t) * n_frames, hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(k.d_type, joint_type, sizeof(int32_t) * n_frames, hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(k.d_origin, org.data(), sizeof(double) * org.size(), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(k.d_axis, joint_axis, sizeof(double) * 3 * n_frames, hipMemcpyHostToDevice));
-  if (n_links) HIP_TRY(c, hipMemcpy(k.d_link_frame, link_frame, sizeof(int32_t) * n_links, hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(k.d_link_offset, off.data(), sizeof(double) * off.size(), hipMemcpyHostToDevice));
   k.n_frames = n_frames;
   return RTUF_OK;
 }
@@ -986,34 +1104,6 @@ static hipEvent_t get_event(rtuf_context::Batch& b, size_t i)
     hipEvent_t ev; hipEventCreate(&ev); b.events.push_back(ev);
   }
   return b.events[i];
-}
-
-static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
-{
-  const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
-  uint32_t cap = c->capacity, fcap = c->fcapacity;
-  while (cap < needed) cap *= 2;
-  while (fcap < fneeded) fcap *= 2;
-  hipFree(c->d_bins); c->d_bins = nullptr;
-  hipFree(c->d_fbins); c->d_fbins = nullptr;
-  // (the old bins had to go first: together with the new ones they may not fit)  A failure from here on leaves
-  // the context without bins: it is marked unusable instead of running kernels on null pointers.
-  c->broken = true;
-  int G = c->group;
-  size_t free_b = 0, total_b = 0;
-  HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));        // (the old bins are freed already)
-  const size_t budget = std::max(free_b / 2, (size_t)1 << 30);
-  auto bytes = [&](int g) { return (size_t)g * tiles * ((size_t)cap * sizeof(PackedTri) + (size_t)fcap * sizeof(Frag)); };
-  while (G > 1 && bytes(G) > budget) G = (G + 1) / 2;
-  if (bytes(G) > ((size_t)160 << 30)) { return c->fail(RTUF_ERR_CAPACITY, "bin capacity %u/%u too large", cap, fcap); }
-  c->group = G;
-  c->capacity = cap;
-  c->fcapacity = fcap;
-  HIP_TRY(c, hipMalloc(&c->d_bins, (size_t)G * tiles * cap * sizeof(PackedTri)));
-  HIP_TRY(c, hipMalloc(&c->d_fbins, (size_t)G * tiles * fcap * sizeof(Frag)));
-  c->broken = false;
-  c->stats.regrowths++;
-  return RTUF_OK;
 }
 
 // Everything one batch launches, as plain argument blocks: built first, then either enqueued kernel by kernel or --
@@ -1165,18 +1255,19 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     memset(&gr.sa, 0, sizeof gr.sa); memset(&gr.ta, 0, sizeof gr.ta); memset(&gr.ca, 0, sizeof gr.ca);
     SetupArgs& sa = gr.sa;
     sa.cverts = c->d_cverts; sa.ctris = c->d_ctris; sa.corder = c->d_corder; sa.chunks = c->d_chunks; sa.mvp = b.d_mvp;
-    sa.model_mask = c->d_model_mask; sa.bg = b.d_bg; sa.bins = c->d_bins; sa.bin_count = c->d_bin_count;
-    sa.fbins = c->d_fbins; sa.fbin_count = c->d_fbin_count; sa.fcapacity = c->fcapacity;
+    sa.model_mask = c->d_model_mask; sa.bg = b.d_bg;
+    sa.bins = c->d_bins; sa.bin_hdr = c->d_bin_hdr; sa.fbins = c->d_fbins; sa.fbin_count = c->d_fbin_count; sa.fcapacity = c->fcapacity; sa.capacity = c->capacity;
     sa.clip_list = c->d_clip_list; sa.clip_spill = c->d_clip_spill; sa.big_list = c->d_big_list; sa.big_capacity = c->big_capacity; sa.counters = b.d_counters; sa.group_base = base; sa.group_size = gs;
     sa.n_draws = c->n_draws; sa.width = c->width; sa.height = c->height; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
-    sa.capacity = c->capacity; sa.clip_capacity = c->clip_capacity; sa.bg_chunk = c->bg_chunk;
+    sa.clip_capacity = c->clip_capacity; sa.bg_chunk = c->bg_chunk;
     sa.items = b.d_items; sa.n_chunks = c->n_chunks; sa.flags = c->params.flags;
     TileArgs& ta = gr.ta;
-    ta.bins = c->d_bins; ta.bin_count = c->d_bin_count;
-    ta.fbins = c->d_fbins; ta.fbin_count = c->d_fbin_count; ta.fcapacity = c->fcapacity; ta.depth = d_depth; ta.masked = d_masked; ta.mask = d_mask;
+    ta.bins = c->d_bins; ta.bin_hdr = c->d_bin_hdr; ta.fbins = c->d_fbins; ta.fbin_count = c->d_fbin_count; ta.fcapacity = c->fcapacity; ta.capacity = c->capacity;
+    ta.depth = d_depth; ta.masked = d_masked; ta.mask = d_mask;
     ta.zsurface = c->d_zsurface; ta.bg = b.d_bg; ta.counters = b.d_counters;
+    ta.big_list = c->d_big_list;
     ta.group_base = base; ta.group_size = gs; ta.width = c->width; ta.height = c->height;
-    ta.tiles_x = c->tiles_x; ta.tiles_y = c->tiles_y; ta.capacity = c->capacity; ta.flags = c->params.flags;
+    ta.tiles_x = c->tiles_x; ta.tiles_y = c->tiles_y; ta.flags = c->params.flags;
     ta.z_near = c->params.near_plane; ta.z_far = c->params.far_plane;
     ta.max_diff = c->params.depth_distance_threshold; ta.replace_value = c->params.filter_replace_value;
     ta.sc_num = sc_num; ta.sc_off = sc_off;
@@ -1201,7 +1292,9 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     const uint64_t h = plan.hash();
     hipGraphExec_t exec = nullptr;
     for (auto& g : b.graphs) if (g.exec && g.hash == h) exec = g.exec;
-    if (!exec) {
+    if (exec) c->graph_hits++;
+    else if (++c->graph_misses >= 32 && c->graph_misses > 2 * c->graph_hits) c->graphs_ok = false;     // thrashing: plain launches are cheaper
+    if (!exec && c->graphs_ok) {
       hipGraph_t graph = nullptr;
       // (the side stream joins the capture below: it must not still carry plain launches of an earlier batch)
       if (c->side_used_plain) { hipStreamSynchronize(c->side); c->side_used_plain = false; }
@@ -1288,7 +1381,8 @@ static int retire_oldest(rtuf_context* c)
     rtuf_context::Batch& b = c->batch[c->oldest];
     if (!c->pending || !b.active) { c->pending = 0; return RTUF_OK; }
     HIP_TRY(c, hipEventSynchronize(b.done));
-    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0; unsigned max_bin_fill = 0, max_fbin_fill = 0, clip_overflow = 0, uncovered = 0, max_big_fill = 0; } k;
+    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0, occluded = 0, raster_atomics = 0, drawn_pixels = 0;
+             unsigned max_bin_fill = 0, max_fbin_fill = 0, clip_overflow = 0, uncovered = 0, max_big_fill = 0, cover_tiles = 0, exact_tiles = 0, zero_items = 0; } k;
     c->items_hint = b.h_counters->work.n_items;      // sizes the next batches' set-up grid
     for (int i = 0; i < kCounterShards; i++) {
       const CounterShard& sh = b.h_counters->shard[i];
@@ -1296,6 +1390,8 @@ static int retire_oldest(rtuf_context* c)
       k.max_bin_fill = std::max(k.max_bin_fill, sh.max_bin_fill); k.clip_overflow |= sh.clip_overflow;
       k.max_fbin_fill = std::max(k.max_fbin_fill, sh.max_fbin_fill); k.frags += sh.frags; k.uncovered |= sh.uncovered;
       k.max_big_fill = std::max(k.max_big_fill, sh.max_big_fill);
+      k.occluded += sh.occluded; k.cover_tiles += sh.cover_tiles; k.exact_tiles += sh.exact_tiles; k.zero_items += sh.zero_items;
+      k.raster_atomics += sh.raster_atomics; k.drawn_pixels += sh.drawn_pixels;
     }
     c->stats.triangles_submitted = (uint64_t)c->n_tris * (uint64_t)b.n;
     c->stats.triangles_binned = k.tris_binned;
@@ -1305,6 +1401,9 @@ static int retire_oldest(rtuf_context* c)
     c->stats.bin_capacity = c->capacity;
     c->stats.fragments_binned = k.frags;
     c->stats.max_fbin_fill = k.max_fbin_fill;
+    c->stats.occluded_entries = k.occluded; c->stats.cover_tiles = k.cover_tiles; c->stats.exact_tiles = k.exact_tiles;
+    c->stats.work_items = b.h_counters->work.n_items; c->stats.zero_survivor_items = k.zero_items;
+    c->stats.raster_atomics = k.raster_atomics; c->stats.drawn_pixels = k.drawn_pixels;
     const bool bin_over = k.max_bin_fill > c->capacity || k.max_fbin_fill > c->fcapacity;
     const bool clip_over = k.clip_overflow != 0;
     const bool big_over = k.max_big_fill > c->big_capacity;
@@ -1358,21 +1457,24 @@ static int retire_oldest(rtuf_context* c)
     // overflow: wait for the later batches too, enlarge, and run everything in flight again in order
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->d2h) HIP_TRY(c, hipStreamSynchronize(c->d2h));
-    if (bin_over) { const int rc = grow_bins(c, k.max_bin_fill, k.max_fbin_fill); if (rc != RTUF_OK) { for (auto& o : c->batch) o.active = false; c->pending = 0; return rc; } }
+    auto give_up = [&](int rc) { for (auto& o : c->batch) o.active = false; c->pending = 0; return rc; };
+    if (bin_over) { const int rc = grow_bins(c, k.max_bin_fill, k.max_fbin_fill); if (rc != RTUF_OK) return give_up(rc); }
     if (clip_over) {
-      hipFree(c->d_clip_list); c->d_clip_list = nullptr;
-      c->clip_capacity *= 4;
-      HIP_TRY(c, hipMalloc(&c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
-      c->stats.regrowths++;
+      const uint32_t larger = c->clip_capacity * 4;
+      int rc = regrow(c, c->d_clip_list, (size_t)larger * kCounterShards * sizeof(ClipItem), "clip list");
+      if (rc == RTUF_OK && clip_spill_bytes(larger) != clip_spill_bytes(c->clip_capacity)) { rc = regrow(c, c->d_clip_spill, clip_spill_bytes(larger), "clip spill area"); c->stats.regrowths--; }
+      if (rc != RTUF_OK) return give_up(rc);
+      c->clip_capacity = larger;
     }
     if (big_over) {
-      hipFree(c->d_big_list); c->d_big_list = nullptr;
-      while (c->big_capacity < k.max_big_fill) c->big_capacity *= 2;
-      HIP_TRY(c, hipMalloc(&c->d_big_list, (size_t)c->big_capacity * kCounterShards * sizeof(BigRec)));
-      c->stats.regrowths++;
+      uint32_t larger = c->big_capacity;
+      while (larger < k.max_big_fill) larger *= 2;
+      const int rc = regrow(c, c->d_big_list, (size_t)larger * kCounterShards * sizeof(BigRec), "many-tile list");
+      if (rc != RTUF_OK) return give_up(rc);
+      c->big_capacity = larger;
     }
     const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
-    HIP_TRY(c, hipMemsetAsync(c->d_bin_count, 0, (size_t)c->group * tiles * 2 * sizeof(uint32_t), c->stream));
+    launch_init_headers(c->d_bin_hdr, (size_t)c->group * tiles, c->stream);
     HIP_TRY(c, hipMemsetAsync(c->d_fbin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->stream));
     for (int i = 0; i < c->pending; i++) {
       rtuf_context::Batch& r = c->batch[(c->oldest + i) % kMaxInflight];
@@ -1391,7 +1493,7 @@ static int submit_batch(rtuf_context* c, int n, const float* d_depth, float* d_m
   if (c->broken) return c->fail(RTUF_ERR_STATE, "context unusable: a bin regrowth failed (%s)", c->error.c_str());
   hipSetDevice(c->device);
   if ((c->params.flags & RTUF_FLAG_TWO_KERNEL) && !c->d_zsurface)
-    HIP_TRY(c, hipMalloc(&c->d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));
+    HIP_TRY(c, dev_alloc(c, &c->d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));
   // two-kernel mode keeps one z-surface: its batches do not overlap
   const int limit = (c->params.flags & RTUF_FLAG_TWO_KERNEL) ? 1 : kMaxInflight;
   while (c->pending >= limit) { const int rc = retire_oldest(c); if (rc != RTUF_OK) return rc; }
@@ -1505,7 +1607,7 @@ int rtuf_sync(rtuf_context* c)
   return RTUF_OK;
 }
 
-void* rtuf_stream(rtuf_context* c) { return c ? (void*)(c->kids.empty() ? c->stream : c->kids[0]->stream) : nullptr; }
+void* rtuf_stream(rtuf_context* c) { return (c && c->kids.empty()) ? (void*)c->stream : nullptr; }
 
 // ---- host planes -----------------------------------------------------------------------------------
 // The reference's filter() takes a host buffer and leaves host results (src/urdf_filter.cpp:233-234,
@@ -1529,17 +1631,17 @@ static int submit_host_batch(rtuf_context* c, int n, const void* const* depth_in
   rtuf_context::Batch& b = c->batch[(c->oldest + c->pending) % kMaxInflight];     // the slot submit_batch takes next
   const size_t plane = (size_t)c->width * c->height;
   if (b.st_streams < (size_t)n) {
-    if (b.st_depth) { hipFree(b.st_depth); hipFree(b.st_masked); hipFree(b.st_mask); b.st_depth = nullptr; b.st_masked = nullptr; b.st_mask = nullptr; }
+    dev_free(c, b.st_depth); dev_free(c, b.st_masked); dev_free(c, b.st_mask);
     b.st_streams = 0;
-    HIP_TRY(c, hipMalloc(&b.st_depth, (size_t)n * plane * sizeof(float)));     // float-sized: large enough for uint16 planes
-    HIP_TRY(c, hipMalloc(&b.st_masked, (size_t)n * plane * sizeof(float)));
-    HIP_TRY(c, hipMalloc(&b.st_mask, (size_t)n * plane));
+    HIP_TRY(c, dev_alloc(c, &b.st_depth, (size_t)n * plane * sizeof(float)));     // float-sized: large enough for uint16 planes
+    HIP_TRY(c, dev_alloc(c, &b.st_masked, (size_t)n * plane * sizeof(float)));
+    HIP_TRY(c, dev_alloc(c, &b.st_mask, (size_t)n * plane));
     b.st_streams = (size_t)n;
   }
   if (bits_out && b.st_bits_streams < (size_t)n) {
-    if (b.st_bits) { hipFree(b.st_bits); b.st_bits = nullptr; }
+    dev_free(c, b.st_bits);
     b.st_bits_streams = 0;
-    HIP_TRY(c, hipMalloc(&b.st_bits, (size_t)n * rtuf_mask_bits_words(c->width, c->height) * sizeof(uint32_t)));
+    HIP_TRY(c, dev_alloc(c, &b.st_bits, (size_t)n * rtuf_mask_bits_words(c->width, c->height) * sizeof(uint32_t)));
     b.st_bits_streams = (size_t)n;
   }
   if (!b.uploaded) HIP_TRY(c, hipEventCreateWithFlags(&b.uploaded, hipEventDisableTiming));
@@ -1692,7 +1794,8 @@ int rtuf_get_stats(rtuf_context* c, rtuf_stats* out)
     // counters and last-batch times of the pipeline that ran last; event sums and regrowths over all pipelines
     *out = c->kids[c->last_kid]->stats;
     out->bin_capacity = c->kids[c->last_kid]->capacity;
-    out->regrowths = 0; out->timed_batches = 0;
+    out->regrowths = 0; out->timed_batches = 0; out->device_bytes = 0;
+    for (const rtuf_context* k : c->kids) out->device_bytes += k->device_bytes;
     out->sum_ms_pose = out->sum_ms_setup = out->sum_ms_raster = out->sum_ms_compare = out->sum_ms_total = out->sum_ms_clip = 0;
     for (const rtuf_context* k : c->kids) {
       out->regrowths += k->stats.regrowths; out->timed_batches += k->stats.timed_batches;
@@ -1703,6 +1806,7 @@ int rtuf_get_stats(rtuf_context* c, rtuf_stats* out)
   }
   *out = c->stats;
   out->bin_capacity = c->capacity;
+  out->device_bytes = c->device_bytes;
   return RTUF_OK;
 }
 

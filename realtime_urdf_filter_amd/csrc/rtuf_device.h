@@ -14,7 +14,9 @@
 //     mvp    f32[N][D][16]  written by pose_kernel;  bg BgInfo[N];  items WorkItem[] written by cull_kernel
 //     depth  f32[N][H][W] in, masked f32[N][H][W] + mask u8[N][H][W] out
 //   rasteriser working set, per in-flight stream g and screen tile
-//     bin_count u32[G][tiles][2], bins PackedTri[G][tiles][capacity]  (32 B records: small boxes from the front, larger from the back)
+//     bin_hdr   BinHeader[G][tiles]   records binned from the front (small boxes) and from the back of the bin, and the tile's
+//                                     cover (nearest triangle that covers the WHOLE tile): 16 bytes, one scalar load in the tile kernel
+//     bins      PackedTri[G][tiles][capacity]  (32 B records: small boxes from the front, larger from the back)
 //     fbin_count u32[G][tiles], fbins Frag[G][tiles][fcapacity]    (pixels of small triangles, 8 B)
 //     clip_list ClipItem[shards][clip_capacity]   triangles that cross a frustum plane (set-up kernel -> clip kernel)
 //     big_list  BigRec[shards][big_capacity]      records over more than 4 tiles (set-up / clip kernel -> bigrec_kernel)
@@ -77,9 +79,14 @@ struct alignas(16) PackedTri {  // 32 B: what a triangle bin stores; the tile ke
   unsigned long long v01;       // (x0+bias) | (y0+bias) << 20 | (x1+bias) << 40   snapped 1/256-px coordinates,
   unsigned long long v12;       // (y1+bias) | (x2+bias) << 20 | (y2+bias) << 40   already oriented (area > 0)
   float a0, dzdx, dzdy;         // z plane
-  uint32_t order;
+  uint32_t order;               // draw-order key (29 bits) | kNearBit
 };
 static_assert(sizeof(PackedTri) == 32, "PackedTri must be 32 bytes");
+// Set in PackedTri.order when the record may produce a window z <= 0.5 somewhere in its box (geometry within about twice
+// the near distance of the camera), where the float z the shader sees is finer than the 24-bit depth: only such records
+// are looked at by the tile kernel's exact-z pass.
+constexpr uint32_t kNearBit = 1u << 31;
+constexpr uint32_t kOrderMask = (1u << 29) - 1u;
 
 // A record whose bounding box touches more than kCoopTiles tiles is not appended to its bins by the lane that made it
 // (a wave with a run of wall triangles would append hundreds of (record, tile) pairs one record after the other while
@@ -98,8 +105,18 @@ static_assert(sizeof(BigRec) == 48, "BigRec is three 16-byte stores");
 constexpr int kFragPosBits = 11;
 constexpr uint32_t kMaxOrder = (1u << (40 - kFragPosBits)) - 1u;    // draw-order keys must fit 29 bits
 static_assert(kTileW * kTileH <= (1 << kFragPosBits), "tile positions must fit the fragment's position field");
+static_assert(kMaxOrder == kOrderMask, "records and fragments carry the same 29-bit draw-order keys");
 struct alignas(8) Frag { unsigned long long v; };
 static_assert(sizeof(Frag) == 8, "Frag must be 8 bytes");
+
+// Per-bin header: the two fill counters of the record bin and the tile's cover -- the nearest triangle that covers the whole
+// tile (bigrec_kernel<0>): largest 24-bit depth it has there << 32 | its index in big_list; kNoCover = none.
+constexpr unsigned long long kNoCover = ~0ull;
+struct alignas(16) BinHeader {
+  uint32_t count[2];             // records binned from the front (boxes of at most kFrontArea pixel centres) / from the back
+  unsigned long long cover;
+};
+static_assert(sizeof(BinHeader) == 16, "one scalar load, one store");
 
 struct Chunk {                  // <= 256 consecutive triangles of one draw + their vertex list
   uint32_t tri_begin;           // into ctris
@@ -159,7 +176,13 @@ struct alignas(128) CounterShard {
   unsigned int uncovered;       // mask-bits output only: some pixel was reached by no fragment (see rtuf_filter_batch_bits*)
   unsigned int big_count;       // entries in this shard's segment of big_list (reset per in-flight group)
   unsigned int max_big_fill;    // largest big_count of the batch's groups (overflow detection)
-  unsigned int pad[19];
+  unsigned int cover_tiles;     // tiles whose initial depth keys came from a whole-cover triangle (statistics)
+  unsigned int exact_tiles;     // tiles that ran the exact-z pass (statistics)
+  unsigned int zero_items;      // set-up work items (chunk x <= 3 streams) none of whose triangles survived (statistics)
+  unsigned long long occluded;  // (record, tile) pairs not appended because they lie behind a whole-cover triangle (statistics)
+  unsigned long long raster_atomics;   // RTUF_COUNT builds only: depth tests issued by the tile kernel (LDS atomics)
+  unsigned long long drawn_pixels;     // RTUF_COUNT builds only: pixels whose final key is not the background's
+  unsigned int pad[10];
 };
 static_assert(sizeof(CounterShard) == 128, "CounterShard must be one 128-byte line");
 struct alignas(128) WorkCount { unsigned int n_items; unsigned int pad[31]; };
@@ -223,7 +246,7 @@ struct SetupArgs {
   const uint64_t* model_mask;    // [n_streams] bit m set: stream renders model m
   const BgInfo* bg;              // [n_streams]
   PackedTri* bins;               // [G][tiles][capacity]   triangles that are not resolved to fragments
-  uint32_t* bin_count;           // [G][tiles][2]  records binned from the front (small boxes) and from the back of the bin
+  BinHeader* bin_hdr;            // [G][tiles]
   Frag* fbins;                   // [G][tiles][fcapacity]  covered pixels of the small (<= 4x4, single-tile) boxes
   uint32_t* fbin_count;          // [G][tiles]
   uint32_t fcapacity;
@@ -246,7 +269,7 @@ struct SetupArgs {
 
 struct TileArgs {
   const PackedTri* bins;
-  uint32_t* bin_count;           // [G][tiles][2], reset to 0 by this kernel after use
+  BinHeader* bin_hdr;            // [G][tiles], reset to "nothing binned, no cover" by this kernel after use
   const Frag* fbins;
   uint32_t* fbin_count;          // reset to 0 by this kernel after use
   uint32_t fcapacity;
@@ -257,6 +280,7 @@ struct TileArgs {
   float* zsurface;               // [G][H][W]  (two-kernel mode)
   const BgInfo* bg;              // [n]
   Counters* counters;
+  const BigRec* big_list;        // the record a bin's cover entry points to
   int group_base, group_size;
   int width, height, tiles_x, tiles_y;
   uint32_t capacity;
@@ -298,9 +322,10 @@ void launch_pose(const PoseArgs& a, hipStream_t st);
 void launch_cull(const SetupArgs& a, hipStream_t st);
 uint32_t launch_setup(const SetupArgs& a, uint32_t items_hint, bool sweep, hipStream_t st);    // returns the main grid size
 void launch_clip(const SetupArgs& a, hipStream_t st);
-size_t clip_spill_bytes();
+size_t clip_spill_bytes(uint32_t clip_capacity);
 void launch_bigrec(const SetupArgs& a, hipStream_t st);
 void launch_reset_clip(Counters* c, hipStream_t st);
+void launch_init_headers(BinHeader* hdr, size_t n_bins, hipStream_t st);
 void launch_publish_counters(const Counters* src, Counters* host_dst, hipStream_t st);
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st);   // a.io_u16 selects the 16UC1 variant
 void launch_compare(const CompareArgs& a, hipStream_t st);

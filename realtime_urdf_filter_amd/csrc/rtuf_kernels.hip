@@ -482,6 +482,27 @@ __device__ __forceinline__ void z_plane(const Win& v0, const Win& v1, const Win&
   a0 = __fsub_rn(v0.z, __fadd_rn(__fmul_rn(dzdx, x0c), __fmul_rn(dzdy, y0c)));
 }
 
+// Smallest / largest value the z plane takes over an inclusive rectangle of pixel coordinates, evaluated exactly like
+// fragment() does: fma(dzdy, y, fma(dzdx, x, a0)) is monotonic in x and in y (rounding is monotonic), so the extreme is at
+// the corner the two slopes point away from / towards.  NaN when the plane is not finite there: callers treat NaN as
+// "unknown" (z24_of(NaN) = 0 never drops anything; a NaN maximum publishes no bound).
+__device__ __forceinline__ float plane_min(float a0, float dzdx, float dzdy, int x0, int x1, int y0, int y1)
+{
+  const float xm = (float)(dzdx < 0.0f ? x1 : x0), ym = (float)(dzdy < 0.0f ? y1 : y0);
+  return __fmaf_rn(dzdy, ym, __fmaf_rn(dzdx, xm, a0));
+}
+__device__ __forceinline__ float plane_max(float a0, float dzdx, float dzdy, int x0, int x1, int y0, int y1)
+{
+  const float xm = (float)(dzdx < 0.0f ? x0 : x1), ym = (float)(dzdy < 0.0f ? y0 : y1);
+  return __fmaf_rn(dzdy, ym, __fmaf_rn(dzdx, xm, a0));
+}
+// A record is "near" when its plane may reach window z <= 0.5 somewhere in its bounding box (the same margin as the
+// fragment path's hand-over: 0.51; a NaN counts as near).  Only near records take part in the tile kernel's exact-z pass.
+__device__ __forceinline__ uint32_t near_bit(float a0, float dzdx, float dzdy, int bx0, int bx1, int by0, int by1)
+{
+  return !(plane_min(a0, dzdx, dzdy, bx0, bx1, by0, by1) >= 0.51f) ? kNearBit : 0u;
+}
+
 __device__ __forceinline__ PackedTri pack_record(int x0, int y0, int x1, int y1, int x2, int y2, float a0, float dzdx,
                                                  float dzdy, uint32_t order)
 {
@@ -535,7 +556,8 @@ __device__ __forceinline__ bool make_record(Win v0, Win v1, Win v2, uint32_t ord
   // few 1/256 px outside that (their interpolation is rounded): 20 bits after the bias of kCoordBias
   pk.v01 = (unsigned long long)(uint32_t)(x0 + kCoordBias) | ((unsigned long long)(uint32_t)(y0 + kCoordBias) << 20) | ((unsigned long long)(uint32_t)(x1 + kCoordBias) << 40);
   pk.v12 = (unsigned long long)(uint32_t)(y1 + kCoordBias) | ((unsigned long long)(uint32_t)(x2 + kCoordBias) << 20) | ((unsigned long long)(uint32_t)(y2 + kCoordBias) << 40);
-  pk.a0 = r.a0; pk.dzdx = r.dzdx; pk.dzdy = r.dzdy; pk.order = order;
+  pk.a0 = r.a0; pk.dzdx = r.dzdx; pk.dzdy = r.dzdy;
+  pk.order = order | near_bit(r.a0, r.dzdx, r.dzdy, (int)(r.bbx & 0xffff), (int)(r.bbx >> 16), (int)(r.bby & 0xffff), (int)(r.bby >> 16));
   return true;
 }
 
@@ -545,7 +567,7 @@ __device__ __forceinline__ TriRec unpack_record(const PackedTri& pk, int width, 
   const int x0 = (int)(pk.v01 & 0xfffffu) - kCoordBias, y0 = (int)((pk.v01 >> 20) & 0xfffffu) - kCoordBias, x1 = (int)((pk.v01 >> 40) & 0xfffffu) - kCoordBias;
   const int y1 = (int)(pk.v12 & 0xfffffu) - kCoordBias, x2 = (int)((pk.v12 >> 20) & 0xfffffu) - kCoordBias, y2 = (int)((pk.v12 >> 40) & 0xfffffu) - kCoordBias;
   edges_from_snapped(x0, y0, x1, y1, x2, y2, width, height, r);
-  r.a0 = pk.a0; r.dzdx = pk.dzdx; r.dzdy = pk.dzdy; r.order = pk.order; r.pad = 0;
+  r.a0 = pk.a0; r.dzdx = pk.dzdx; r.dzdy = pk.dzdy; r.order = pk.order & kOrderMask; r.pad = pk.order >> 31;
   return r;
 }
 
@@ -624,7 +646,7 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slo
       pending &= ~m;
     }
     uint32_t base = 0;
-    if (act && lane == myleader) base = atomicAdd(&a.bin_count[bin], (uint32_t)__popcll(mymask));
+    if (act && lane == myleader) base = atomicAdd(&a.bin_hdr[bin >> 1].count[cls], (uint32_t)__popcll(mymask));
     base = __shfl(base, myleader);
     if (act) {
       const uint32_t pos = base + (uint32_t)__popcll(mymask & ((1ull << lane) - 1ull));
@@ -1033,6 +1055,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
   // -> 8-byte fragments; the z plane (one division) is only evaluated for triangles that actually
   // cover a pixel centre
   const uint32_t ntiny = s_ntiny, nsmall = s_nsmall;
+  if (tid == 0 && (ntiny | nsmall | s_nlist) == 0u) atomicAdd(&shard.zero_items, 1u);      // (statistics: an item the cull pass could have spared)
 #pragma unroll
   for (int cls = 0; cls < 2; cls++) {
     const uint32_t ncls = cls == 0 ? ntiny : nsmall;
@@ -1107,7 +1130,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
       if (have) {
         float a0, dzdx, dzdy;
         z_plane(v0, v1, v2, a0, dzdx, dzdy);
-        pk = pack_record(x0, y0, x1, y1, x2, y2, a0, dzdx, dzdy, a.corder[ch.tri_begin + t]);
+        pk = pack_record(x0, y0, x1, y1, x2, y2, a0, dzdx, dzdy, a.corder[ch.tri_begin + t] | near_bit(a0, dzdx, dzdy, bx0, bx1, by0, by1));
         bbx = (uint32_t)bx0 | ((uint32_t)bx1 << 16);
         bby = (uint32_t)by0 | ((uint32_t)by1 << 16);
       }
@@ -1160,7 +1183,7 @@ constexpr int kClipBlock = 128;          // threads per clip workgroup (16 KB of
 constexpr int kClipMaxV = 16;            // clip-space vertices per triangle: 3 + at most 2 new ones per frustum plane (+1 spare)
 constexpr int kClipLdsV = 8;             // ... of which this many live in LDS (a triangle that crosses one or two planes needs 5..7);
                                          // the rest, for the rare triangle that crosses three and more, in a per-thread global spill area
-constexpr int kClipGridWgs = 64;         // workgroups per counter shard (the spill area is sized for the grid)
+constexpr int kClipGridWgs = 64;         // workgroups per counter shard at most (the spill area is sized for the grid)
 constexpr int kClipMaxP = 12;            // polygon vertices (5-bit pool indices packed in one 64-bit register)
 
 // Per-thread polygon clipper.  The vertex pool lives in LDS (thread-interleaved float4s: conflict
@@ -1310,14 +1333,25 @@ __global__ __launch_bounds__(kClipBlock) void clip_kernel(SetupArgs a)
 }
 
 // ---------------------------------------------------------------------------------------
-// bigrec_kernel: one wave per many-tile record of the shards' lists.  The wave rebuilds the record's edge functions
-// (uniform work, as in the tile kernel), spreads the tiles of its bounding box over the lanes, drops the tiles the
-// triangle does not touch at all -- an edge function is largest at one corner of the tile's part of the box; not positive
-// there means no pixel centre of that tile is covered (half of the tiles of a clipped wall's box): the tile kernel would
-// classify such a record away anyway, so the image is the same with fewer bin entries -- and appends the record to the
-// back of the others' bins.  Up to four slot reservations per lane are in flight before the first store needs its answer.
+// bigrec_kernel: one wave per many-tile record of the shards' lists, in two launches.
+//   PHASE 0 (cover)   the wave rebuilds the record's edge functions (uniform work, as in the tile kernel), spreads the
+//                     tiles of its bounding box over the lanes and, for every tile the triangle covers COMPLETELY (all
+//                     three edge functions positive at their smallest corner of the tile), publishes the largest 24-bit
+//                     depth its plane has there: tile_cover[bin] = min over such records of {zmax24, list index}.  No key
+//                     of that tile can end up with a larger depth, and the winner of the min becomes the tile's initial
+//                     depth keys in the tile kernel (evaluated per pixel there; never walked, never appended).
+//   PHASE 1 (append)  drops the tiles the triangle does not touch at all -- an edge function is largest at one corner of
+//                     the tile's part of the box; not positive there means no pixel centre of that tile is covered (half
+//                     of the tiles of a clipped wall's box) -- and the tiles where the record lies entirely behind the
+//                     published cover (its smallest depth over the tile's part of its box is larger: it can win no pixel;
+//                     the back of a wall, the wall behind it, the robot's far side behind its own arm), and appends the
+//                     record to the back of the others' bins.  Up to four slot reservations per lane are in flight before
+//                     the first store needs its answer.
+// Exactness: a dropped (record, tile) pair could not have won any depth test of that tile (strictly larger 24-bit depth
+// than a fragment that is certainly there), so the keys -- and with them the image -- are the same.
 // ---------------------------------------------------------------------------------------
 constexpr int kBigWavesPerShard = 64;     // (32 / 128 waves per shard, 2 / 8 reservations in flight per lane: no difference)
+template <int PHASE>
 __global__ __launch_bounds__(256) void bigrec_kernel(SetupArgs a)
 {
   const int lane = threadIdx.x & 63;
@@ -1325,12 +1359,13 @@ __global__ __launch_bounds__(256) void bigrec_kernel(SetupArgs a)
   const int shard_id = wave % kCounterShards, first = wave / kCounterShards;
   CounterShard& shard = a.counters->shard[shard_id];
   const uint32_t count = shard.big_count;
-  if (first == 0 && lane == 0 && count > shard.max_big_fill) shard.max_big_fill = count;      // (this wave alone writes the field)
+  if (PHASE == 1 && first == 0 && lane == 0 && count > shard.max_big_fill) shard.max_big_fill = count;      // (this wave alone writes the field)
   const uint32_t n = min(count, a.big_capacity);
   const int tiles = a.tiles_x * a.tiles_y;
-  uint32_t mine = 0;
+  uint32_t mine = 0, dropped = 0;
   for (uint32_t j = (uint32_t)first; j < n; j += kBigWavesPerShard) {
-    const BigRec* rec = a.big_list + (size_t)shard_id * a.big_capacity + j;
+    const uint32_t my_id = (uint32_t)shard_id * a.big_capacity + j;
+    const BigRec* rec = a.big_list + my_id;
     PackedTri q;
     {
       const uint4* src = reinterpret_cast<const uint4*>(rec);
@@ -1343,6 +1378,26 @@ __global__ __launch_bounds__(256) void bigrec_kernel(SetupArgs a)
     const int tx0 = bx0 / kTileW, tx1 = bx1 / kTileW;
     const int ty0 = by0 / kTileH, ty1 = by1 / kTileH;
     const int tw = tx1 - tx0 + 1, ntile = tw * (ty1 - ty0 + 1);
+    if (PHASE == 0) {
+      for (int k = lane; k < ntile; k += 64) {
+        const int row = k / tw, tx = tx0 + k - row * tw, ty = ty0 + row;
+        // the tile's pixels inside the frame
+        const int X0 = tx * kTileW, X1 = min(X0 + kTileW, a.width) - 1, Y0 = ty * kTileH, Y1 = min(Y0 + kTileH, a.height) - 1;
+        if (bx0 > X0 || bx1 < X1 || by0 > Y0 || by1 < Y1) continue;
+        bool inside = true;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+          const int xi = r.A[e] > 0 ? X0 : X1, yi = r.B[e] > 0 ? Y0 : Y1;
+          inside = inside && (__mul24(r.A[e], xi) + __mul24(r.B[e], yi) + r.C[e]) > 0;
+        }
+        if (!inside) continue;
+        const float zmax = plane_max(r.a0, r.dzdx, r.dzdy, X0, X1, Y0, Y1);
+        if (!(zmax == zmax)) continue;
+        const int bin = __mul24(qslot, tiles) + __mul24(ty, a.tiles_x) + tx;
+        atomicMin(&a.bin_hdr[bin].cover, ((unsigned long long)z24_of(zmax) << 32) | my_id);
+      }
+      continue;
+    }
     constexpr int kPerRound = 4;
     for (int k0 = lane; k0 < ntile; k0 += 64 * kPerRound) {
       int bin[kPerRound];
@@ -1364,9 +1419,18 @@ __global__ __launch_bounds__(256) void bigrec_kernel(SetupArgs a)
             touches = touches && (__mul24(r.A[e], xa) + __mul24(r.B[e], ya) + r.C[e]) > 0;
           }
           if (touches) {
-            bin[jj] = __mul24(qslot, tiles) + __mul24(ty, a.tiles_x) + tx;
-            pos[jj] = atomicAdd(&a.bin_count[2 * bin[jj] + 1], 1u);          // many-tile records are large: back of the bin
-            mine++;
+            const int b = __mul24(qslot, tiles) + __mul24(ty, a.tiles_x) + tx;
+            const unsigned long long cv = a.bin_hdr[b].cover;
+            if (cv != kNoCover) {
+              // this record IS the tile's cover (it becomes the initial keys), or it lies behind the cover everywhere
+              const bool behind = z24_of(plane_min(r.a0, r.dzdx, r.dzdy, x0, x1, y0, y1)) > (uint32_t)(cv >> 32);
+              if ((uint32_t)cv == my_id || behind) { touches = false; dropped++; }
+            }
+            if (touches) {
+              bin[jj] = b;
+              pos[jj] = atomicAdd(&a.bin_hdr[b].count[1], 1u);          // many-tile records are large: back of the bin
+              mine++;
+            }
           }
         }
       }
@@ -1375,9 +1439,11 @@ __global__ __launch_bounds__(256) void bigrec_kernel(SetupArgs a)
         if (bin[jj] >= 0 && pos[jj] < a.capacity) store_record(a.bins + (size_t)bin[jj] * a.capacity + (a.capacity - 1u - pos[jj]), q);
     }
   }
+  if (PHASE == 0) return;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_down((int)mine, off);
+  for (int off = 32; off > 0; off >>= 1) { mine += (uint32_t)__shfl_down((int)mine, off); dropped += (uint32_t)__shfl_down((int)dropped, off); }
   if (lane == 0 && mine) atomicAdd(&shard.bin_entries, (unsigned long long)mine);
+  if (lane == 0 && dropped) atomicAdd(&shard.occluded, (unsigned long long)dropped);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1390,9 +1456,19 @@ constexpr unsigned long long kResolvedBit = 1ull << 63;
 
 // MODE 0: depth test (atomicMin of {z24, order});  MODE 1: write the exact float z of the
 // fragment that won (needed only for window z <= 0.5, where float z is finer than 24 bits).
+// Instrumented builds (-DRTUF_COUNT, scripts/overdraw.sh; never the product): every depth test the tile kernel issues and
+// every pixel that ends up drawn is counted through two LDS words per workgroup, summed into the batch's counters.
+#ifdef RTUF_COUNT
+__device__ __forceinline__ uint32_t* count_words() { __shared__ uint32_t s_cnt[2]; return s_cnt; }
+#define RTUF_COUNT_TEST() atomicAdd(&count_words()[0], 1u)
+#else
+#define RTUF_COUNT_TEST() ((void)0)
+#endif
+
 template <int MODE>
 __device__ __forceinline__ void fragment(unsigned long long* keys, const TriRec& r, int px, int py, int lidx)
 {
+  if (MODE == 0) RTUF_COUNT_TEST();
   const float z = __fmaf_rn(r.dzdy, (float)py, __fmaf_rn(r.dzdx, (float)px, r.a0));
   const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | r.order;
   if (MODE == 0) {
@@ -1418,7 +1494,11 @@ constexpr int kSmallArea = RTUF_SMALL_AREA;     // bounding boxes up to this man
 #endif
 constexpr int kWallArea = RTUF_WALL_AREA;         // ... larger bins only for boxes covering more of the tile than this
 constexpr int kParkBelow = RTUF_PARK_BELOW;       // bins of at most this many records use the cooperative whole-tile pass
-constexpr int kHugeMax = 255;
+constexpr int kHugeMax = 127;
+// Exact-z pass: which draw-order keys won a pixel that needs its exact float z -- a 4096-bit filter in LDS (one multiplicative
+// hash); records whose key is not in it cannot be a winner and are not walked a second time.
+constexpr int kWinnerWords = 128;
+__device__ __forceinline__ uint32_t winner_slot(uint32_t order) { return (order * 0x9E3779B1u) >> 20; }      // 12 bits
 constexpr int kQuarterArea = RTUF_QUARTER_AREA;   // up to this many by a quarter wave (4 triangles at a time), larger by the whole wave
 
 // The tile's part of a record's box (local lx0..ly1) against the three edges: an edge function is largest /
@@ -1469,23 +1549,34 @@ __device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriR
 // lane-per-triangle for small bounding boxes, a quarter wave each for the middle class; triangles
 // that cover a large part of the tile are parked and, after one workgroup barrier at the end, walked
 // by all waves together (all threads of the workgroup must call this function).
+// `zcover` is the tile's occlusion bound (24-bit depth no key of the tile can exceed; 0xffffffff = none, wave-uniform): records
+// that lie behind it over their whole part of the tile are dropped when they are loaded.  MODE 1 looks only at records the
+// set-up marked as near (kNearBit) and, of those, only at the ones that can reach the lower half of the depth range here.
+
 template <int MODE>
 __device__ __forceinline__ void raster_bin(unsigned long long* keys, const PackedTri* recs, uint32_t n,
                                            int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, uint32_t n_front, uint32_t capacity,
-                                           uint32_t* s_huge, TriRec* s_prec, uint4* s_pmeta, int dbg_skip = 0)
+                                           uint32_t* s_huge, TriRec* s_prec, uint4* s_pmeta, uint32_t zcover, const uint32_t* s_winners, uint32_t* s_zmax, int dbg_skip = 0)
 {
   const int lane = tid & 63;
+  const uint32_t zdrop = MODE == 1 ? min(zcover, 8388608u) : zcover;
   for (uint32_t base = 0; base < n; base += kTileThreads) {
     const uint32_t i = base + tid;
-    const bool have = i < n;
+    bool have = i < n;
     const uint32_t ri = i < n_front ? i : capacity - 1u - (i - n_front);      // small boxes from the front, larger ones from the back
     TriRec r;
     int lx0 = 0, lx1 = -1, ly0 = 0, ly1 = -1;
+    PackedTri pk;
     if (have) {
-      PackedTri pk;
       const uint4* src = reinterpret_cast<const uint4*>(recs + ri);
       uint4* dst = reinterpret_cast<uint4*>(&pk);
       dst[0] = src[0]; dst[1] = src[1];
+      if (MODE == 1) {          // only near records whose draw-order key won a pixel that needs resolving
+        const uint32_t h = winner_slot(pk.order & kOrderMask);
+        if (!(pk.order & kNearBit) || !((s_winners[h >> 5] >> (h & 31u)) & 1u)) have = false;
+      }
+    }
+    if (have) {
       r = unpack_record(pk, width, height);
       lx0 = max((int)(r.bbx & 0xffff) - x_base, 0);
       lx1 = min((int)(r.bbx >> 16) - x_base, kTileW - 1);
@@ -1493,10 +1584,13 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       ly1 = min((int)(r.bby >> 16) - y_base, kTileH - 1);
     } else {
 #pragma unroll
-      for (int k = 0; k < 16; k++) reinterpret_cast<int*>(&r)[k] = 0;
+      for (int q = 0; q < 16; q++) reinterpret_cast<int*>(&r)[q] = 0;
     }
     const int w = lx1 - lx0 + 1, h = ly1 - ly0 + 1;
     int area = (have && w > 0 && h > 0) ? w * h : 0;
+    if (zdrop != 0xffffffffu) {               // (uniform) behind the tile's cover / out of the exact-z range: cannot matter here
+      if (area > 0 && z24_of(plane_min(r.a0, r.dzdx, r.dzdy, x_base + lx0, x_base + lx1, y_base + ly0, y_base + ly1)) > zdrop) area = 0;
+    }
     if (dbg_load_only) { if (r.order == 0xdeadbeefu) keys[0] = 0; area = 0; }
     if (dbg_skip == 1 && area <= kSmallArea) area = 0;      // timing experiment: no lane-per-triangle walk
     if (dbg_skip == 2 && area > kSmallArea) area = 0;       // timing experiment: no quarter-wave walk
@@ -1619,7 +1713,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
   // records in every tile of a 720p frame that repetition was 30 % of the walls' cost).
   __syncthreads();
   const uint32_t nh = min(s_huge[0], (uint32_t)kHugeMax);
-  uint32_t zfull = 0xffffffffu;                  // largest depth any pixel of the tile can still have (24-bit)
+  uint32_t zfull = zcover;                       // largest depth any pixel of the tile can still have (24-bit)
   for (uint32_t hb = 0; hb < nh; hb += 64) {
     const bool have = hb + (uint32_t)lane < nh;
     if (tid < 64) {
@@ -1666,9 +1760,21 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     zfull = min(zfull, zf);
     unsigned long long m = __ballot(have && zmin24 <= zfull);
     const unsigned long long full = __ballot(have && meta.x == 2u);
+    int drawn = 0;                                     // pixels walked since the last look at the key tile (uniform)
     while (m) {
+#ifdef RTUF_EXP_NOSORT
       const int src = __ffsll((long long)m) - 1;
       m &= m - 1;
+#else
+      // nearest first (smallest depth in this tile): once the nearest one left lies behind everything drawn, so do all others
+      uint32_t sel = ((m >> lane) & 1ull) ? (min(zmin24, 0x00ffffffu) << 6) | (uint32_t)lane : 0xffffffffu;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sel = min(sel, (uint32_t)__shfl_xor((int)sel, o));
+      sel = (uint32_t)__builtin_amdgcn_readfirstlane((int)sel);
+      if ((sel >> 6) > zfull) break;
+      const int src = (int)(sel & 63u);
+      m &= ~(1ull << src);
+#endif
       const bool inside = ((full >> src) & 1ull) != 0;
       TriRec q;                                        // the record from LDS into scalar registers (same address in every lane)
       {
@@ -1694,6 +1800,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
           const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | q.order;
           const int lidx = ly * kTileW + lane;
           if (MODE == 0) {
+            RTUF_COUNT_TEST();
             atomicMin(&keys[lidx], key);
           } else {
             if (keys[lidx] == key) keys[lidx] = kResolvedBit | (unsigned long long)__float_as_uint(z);
@@ -1713,6 +1820,28 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
           raster_pair<MODE>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1);
         }
       }
+      // Occlusion by what has been drawn, whatever it took to cover the tile (the two triangles of a wall's face along
+      // their diagonal, a wall's border next to the robot): when about a tile's worth of pixels has been walked and more
+      // records wait, look at the key tile -- the largest depth any pixel of the frame holds now bounds every final key
+      // (keys only decrease), so records whose nearest depth here is larger are skipped by the test at the top of the loop.
+#ifndef RTUF_EXP_NORESCAN
+      if (MODE == 0) {
+        drawn += qw * (qy1 - qy0 + 1);
+        if (m && drawn >= kTileW * kTileH) {
+          drawn = kTileW * kTileH / 2;
+          if (tid == 0) *s_zmax = 0u;
+          __syncthreads();                             // the walks above have landed
+          uint32_t zm = 0;
+          for (int i = tid; i < kTileW * kTileH; i += kTileThreads)
+            if (x_base + i % kTileW < width && y_base + i / kTileW < height) zm = max(zm, (uint32_t)(keys[i] >> 32));
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) zm = max(zm, (uint32_t)__shfl_xor((int)zm, o));
+          if (lane == 0) atomicMax(s_zmax, zm);
+          __syncthreads();
+          zfull = min(zfull, *s_zmax);
+        }
+      }
+#endif
     }
     if (hb + 64 < nh) __syncthreads();               // (more than 64 parked: the next batch overwrites the LDS records)
   }
@@ -1720,13 +1849,23 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
 
 // Fragments of the small triangles: 8 bytes each, perfectly coalesced, one LDS atomic each.  They never
 // need the exact-float-z pass (the set-up kernel keeps anything with window z near 0.5 or below as a record).
-__device__ __forceinline__ void raster_frags(unsigned long long* keys, const unsigned long long* frags, uint32_t nf, int tid)
+__device__ __forceinline__ void raster_frags(unsigned long long* keys, const unsigned long long* frags, uint32_t nf, int tid, uint32_t zcover)
 {
+  if (zcover == 0xffffffffu) {                 // (uniform) no cover: nothing to test per fragment
+    for (uint32_t i = tid; i < nf; i += kTileThreads) {
+      const unsigned long long f = frags[i];
+      const int lidx = (int)((uint32_t)f & ((1u << kFragPosBits) - 1u));
+      const unsigned long long key = ((f >> 40) << 32) | ((f >> kFragPosBits) & (unsigned long long)kMaxOrder);
+      RTUF_COUNT_TEST();
+      atomicMin(&keys[lidx], key);
+    }
+    return;
+  }
   for (uint32_t i = tid; i < nf; i += kTileThreads) {
     const unsigned long long f = frags[i];
     const int lidx = (int)((uint32_t)f & ((1u << kFragPosBits) - 1u));
     const unsigned long long key = ((f >> 40) << 32) | ((f >> kFragPosBits) & (unsigned long long)kMaxOrder);
-    atomicMin(&keys[lidx], key);
+    if ((uint32_t)(f >> 40) <= zcover) { RTUF_COUNT_TEST(); atomicMin(&keys[lidx], key); }        // (behind the tile's cover: cannot win)
   }
 }
 
@@ -1786,6 +1925,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
 {
   __shared__ unsigned long long keys[kTileW * kTileH];
   __shared__ uint32_t s_huge[2 + kHugeMax];        // raster_bin's list of whole-tile triangles (+ count in front, area threshold behind)
+  __shared__ uint32_t s_winners[kWinnerWords];     // exact-z pass: filter of the draw-order keys that won a pixel in need
+  __shared__ uint32_t s_zmax;                      // raster_bin's cooperative pass: largest depth in the key tile
   __shared__ TriRec s_prec[64];                    // ... a batch of them unpacked by the first wave for all four,
   __shared__ uint4 s_pmeta[64];                    //     with {class, smallest depth, largest depth if it covers the whole tile}
 
@@ -1804,57 +1945,100 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   ShadeConsts sc;
   sc.num = a.sc_num; sc.off = a.sc_off; sc.max_diff = a.max_diff; sc.replace_value = a.replace_value;
 
-  const uint32_t count_front = a.bin_count[2 * bin], count_back = a.bin_count[2 * bin + 1], fcount = a.fbin_count[bin];
+  // the record bin's two fill counters and the tile's cover (the nearest triangle that covers this whole tile, if any:
+  // bound of every key's depth, and its plane) in ONE 16-byte scalar load, the fragment bin's counter in a second one
+  uint32_t count_front, count_back;
+  unsigned long long cover;
+  {
+    const uint4 h = *reinterpret_cast<const uint4*>(a.bin_hdr + bin);
+    count_front = h.x; count_back = h.y;
+    cover = ((unsigned long long)h.w << 32) | h.z;
+  }
+  const uint32_t fcount = a.fbin_count[bin];
   const uint32_t count = count_front + count_back;
-  // The sensor pixels this lane will resolve are requested before anything else so that their HBM
-  // latency overlaps the bin-counter round trip and all of the rasterisation.
+  const uint32_t zcover = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cover >> 32));      // (<= 0xffffff, or all ones: none)
+  const uint32_t cover_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cover);
+  const bool has_cover = zcover != 0xffffffffu;
+  // The sensor pixels this lane will resolve.  A tile without geometry requests them as soon as the bin header says so (that
+  // latency is all there is to such a tile); a tile with geometry requests them after the rasterisation: eight registers
+  // held across the walks do not fit the kernel's 80-register budget (they spill, and the spill waits for the load), and
+  // requesting them early AND late costs more in traffic than the early request hides (both measured, profiles/README.md).
   constexpr int kLanesPerRow = kTileW / 4, kRowsPerPass = kTileThreads / kLanesPerRow;
   constexpr int kPasses = (kTileH + kRowsPerPass - 1) / kRowsPerPass;      // resolve passes per tile (2 for 64x32)
   const bool vec = (a.width & 3) == 0;
   const int r_ly0 = tid / kLanesPerRow, r_lx = (tid % kLanesPerRow) * 4;
   const int r_px = x_base + r_lx;
   float4 sens_p[kPasses];
+  auto request_sensor = [&]() {
 #pragma unroll
-  for (int ps = 0; ps < kPasses; ps++) {
-    const int r_ly = r_ly0 + ps * kRowsPerPass, r_py = y_base + r_ly;
-    const bool r_valid = r_ly < kTileH && r_py < a.height && r_px < a.width;
-    // 64-bit part uniform (scalar), per-lane part 24-bit (W, H <= 2048)
-    const size_t gofs = (size_t)stream * ((size_t)a.height * a.width) + (uint32_t)(__mul24(r_py, a.width) + r_px);
-    sens_p[ps] = make_float4(0, 0, 0, 0);
-    if (!TWO_KERNEL && r_valid && vec) {
-      if (U16) {
-        const ushort4 q = *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(a.depth) + gofs);
-        sens_p[ps] = make_float4(u16_to_metres(q.x), u16_to_metres(q.y), u16_to_metres(q.z), u16_to_metres(q.w));
-      } else {
-        sens_p[ps] = *reinterpret_cast<const float4*>(a.depth + gofs);
+    for (int ps = 0; ps < kPasses; ps++) {
+      const int r_ly = r_ly0 + ps * kRowsPerPass, r_py = y_base + r_ly;
+      const bool r_valid = r_ly < kTileH && r_py < a.height && r_px < a.width;
+      // 64-bit part uniform (scalar), per-lane part 24-bit (W, H <= 2048)
+      const size_t gofs = (size_t)stream * ((size_t)a.height * a.width) + (uint32_t)(__mul24(r_py, a.width) + r_px);
+      sens_p[ps] = make_float4(0, 0, 0, 0);
+      if (!TWO_KERNEL && r_valid && vec) {
+        if (U16) {
+          const ushort4 q = *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(a.depth) + gofs);
+          sens_p[ps] = make_float4(u16_to_metres(q.x), u16_to_metres(q.y), u16_to_metres(q.z), u16_to_metres(q.w));
+        } else {
+          sens_p[ps] = *reinterpret_cast<const float4*>(a.depth + gofs);
+        }
       }
     }
-  }
+  };
   // (an over-full bin is detected from the counters and the batch run again; until then stay inside the array)
   const uint32_t n_front = min(count_front, a.capacity), n = n_front + min(count_back, a.capacity - n_front), nf = min(fcount, a.fcapacity);
   const PackedTri* recs = a.bins + (size_t)bin * a.capacity;
   const unsigned long long* frags = reinterpret_cast<const unsigned long long*>(a.fbins) + (size_t)bin * a.fcapacity;
   // (RTUF_ABLATE builds only: flags bits 8.. are timing experiments, e.g. 0x100 skip rasterisation, 0x200 skip pixel loops)
-  const bool empty = (n == 0 && nf == 0) || RTUF_ABL(a.flags, 0x100u);   // no geometry in this tile: pure streaming compare
+  const bool empty = (n == 0 && nf == 0 && !has_cover) || RTUF_ABL(a.flags, 0x100u);   // no geometry in this tile: pure streaming compare
   if (empty && RTUF_ABL(a.flags, 0x1000000u)) return;               // timing experiment: raster tiles only
+  if (empty) request_sensor();
   if (!empty) {
-    for (int i = tid; i < kTileW * kTileH; i += kTileThreads) keys[i] = bgkey;
+    // Initial depth keys: the background plane and, where a triangle covers the whole tile, that triangle's fragments --
+    // evaluated per pixel exactly as fragment() would (same two fused multiply-adds, same 24-bit conversion, its draw
+    // order), but written instead of min'ed: it is the first thing the tile sees, and bigrec_kernel<1> left it out of the bin.
+    // (the plane is fetched again by the rare exact-z pass below rather than kept in registers across the rasterisation)
+    struct CoverPlane { float a0, dzdx, dzdy; uint32_t order; };
+    auto cover_plane = [&]() {
+      const uint4 pl = reinterpret_cast<const uint4*>(a.big_list + cover_idx)[1];       // {a0, dzdx, dzdy, order}: same address in every lane
+      CoverPlane c;
+      c.a0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)pl.x));
+      c.dzdx = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)pl.y));
+      c.dzdy = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)pl.z));
+      c.order = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl.w) & kOrderMask;
+      return c;
+    };
+    if (has_cover) {
+      const CoverPlane c = cover_plane();
+      for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
+        const float z = __fmaf_rn(c.dzdy, (float)(y_base + i / kTileW), __fmaf_rn(c.dzdx, (float)(x_base + i % kTileW), c.a0));
+        const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | c.order;
+        keys[i] = min(key, bgkey);
+      }
+    } else {
+      for (int i = tid; i < kTileW * kTileH; i += kTileThreads) keys[i] = bgkey;
+    }
     if (tid == 0) { s_huge[0] = 0; s_huge[1 + kHugeMax] = n <= (uint32_t)kParkBelow ? (uint32_t)kQuarterArea : (uint32_t)kWallArea; }
+#ifdef RTUF_COUNT
+    if (tid < 2) count_words()[tid] = 0u;
+#endif
     __syncthreads();
     if (tid == 0) {
-      a.bin_count[2 * bin] = 0;             // ready for the next batch
-      a.bin_count[2 * bin + 1] = 0;
+      *reinterpret_cast<uint4*>(a.bin_hdr + bin) = make_uint4(0u, 0u, 0xffffffffu, 0xffffffffu);      // ready for the next batch: nothing binned, no cover
       a.fbin_count[bin] = 0;
       CounterShard& sh = a.counters->shard[bin % kCounterShards];
       if (count) atomicMax(&sh.max_bin_fill, count);
       if (fcount) atomicMax(&sh.max_fbin_fill, fcount);
+      if (has_cover) atomicAdd(&sh.cover_tiles, 1u);
     }
 #ifdef RTUF_ABLATE
-    if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, (int)((a.flags >> 12) & 3u));
-    if (!(a.flags & 0x400u)) raster_frags(keys, frags, nf, tid);
+    if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, &s_zmax, (int)((a.flags >> 12) & 3u));
+    if (!(a.flags & 0x400u)) raster_frags(keys, frags, nf, tid, zcover);
 #else
-    raster_bin<0>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta);
-    raster_frags(keys, frags, nf, tid);
+    raster_bin<0>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, &s_zmax);
+    raster_frags(keys, frags, nf, tid, zcover);
 #endif
     __syncthreads();
     if (tid == 0) s_huge[0] = 0;             // the exact-z pass below builds its list again
@@ -1867,9 +2051,30 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       if (k != bgkey && (uint32_t)(k >> 32) <= 8388608u) need = true;
     }
     if (__syncthreads_or(need)) {
-      raster_bin<1>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta);
+      // which draw-order keys won such a pixel: only their records are walked again
+      if (tid < kWinnerWords) s_winners[tid] = 0u;
+      if (tid == 0) atomicAdd(&a.counters->shard[bin % kCounterShards].exact_tiles, 1u);
+      __syncthreads();
+      for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
+        const unsigned long long k = keys[i];
+        if (k != bgkey && (uint32_t)(k >> 32) <= 8388608u) {
+          const uint32_t h = winner_slot((uint32_t)k & kOrderMask);
+          atomicOr(&s_winners[h >> 5], 1u << (h & 31u));
+        }
+      }
+      __syncthreads();
+      raster_bin<1>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, &s_zmax);
+      if (has_cover) {                       // ... and the cover triangle, which is in no bin
+        const CoverPlane c = cover_plane();
+        for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
+          const float z = __fmaf_rn(c.dzdy, (float)(y_base + i / kTileW), __fmaf_rn(c.dzdx, (float)(x_base + i % kTileW), c.a0));
+          const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | c.order;
+          if (keys[i] == key) keys[i] = kResolvedBit | (unsigned long long)__float_as_uint(z);
+        }
+      }
       __syncthreads();
     }
+    request_sensor();
   }
 
   // resolve: kLanesPerRow lanes x 4 pixels per tile row, kRowsPerPass rows per pass.  `finish` turns four
@@ -1946,6 +2151,9 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
           thr[j] = thr_bg;
           if (k == bgkey) { z[j] = bgz; frag[j] = analytic_bg; }
           else {                                        // the per-pixel division only runs where something was drawn
+#ifdef RTUF_COUNT
+            if (r_px + j < a.width) atomicAdd(&count_words()[1], 1u);
+#endif
             z[j] = (k & kResolvedBit) ? __uint_as_float((uint32_t)k) : __fmul_rn((float)((uint32_t)(k >> 32) + 1u), 5.9604644775390625e-08f);
             if (!TWO_KERNEL) thr[j] = shade_threshold(z[j], sc);
           }
@@ -1968,6 +2176,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
     }
   }
   if (BITS && __syncthreads_or(uncovered) && tid == 0) a.counters->shard[bin % kCounterShards].uncovered = 1u;
+#ifdef RTUF_COUNT
+  __syncthreads();
+  if (!empty && tid == 0) {
+    atomicAdd(&a.counters->shard[bin % kCounterShards].raster_atomics, (unsigned long long)count_words()[0]);
+    atomicAdd(&a.counters->shard[bin % kCounterShards].drawn_pixels, (unsigned long long)count_words()[1]);
+  }
+#endif
 }
 
 // (fused variants: held at 6 waves/SIMD = 80 VGPRs; left alone the compiler takes 84 = 5 waves/SIMD)
@@ -1976,10 +2191,8 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6)
 // mask-only output, one bit per pixel (rtuf_filter_batch_bits*): 4 (2) B/pixel in, 1/8 B/pixel out
 template <bool U16>
 __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6))) void tile_bits_kernel(TileArgs a) { tile_body<false, U16, true>(a); }
-// two-kernel mode writes the z-surface instead of resolving the compare: one register over 64 VGPRs without
-// the hint, i.e. 7 instead of 8 waves/SIMD (+10 % kernel time)
 template <>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(7))) void tile_kernel<true, false>(TileArgs a) { tile_body<true, false, false>(a); }      // (22.3 KB of LDS per workgroup: 7 fit a CU)
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6))) void tile_kernel<true, false>(TileArgs a) { tile_body<true, false, false>(a); }      // (at 7 waves/SIMD = 72 registers it spills 13 of them)
 
 // ---------------------------------------------------------------------------------------
 // compare_kernel (two-kernel mode): streaming, 13 B/pixel (4 sensor + 4 z + 4 masked + 1 mask)
@@ -2071,10 +2284,21 @@ __global__ void reset_clip_kernel(Counters* c)
   if (i == kCounterShards) c->work.n_items = 0;
 }
 
+// bin headers of a fresh (or regrown) working set: nothing binned, no cover
+__global__ void init_headers_kernel(BinHeader* hdr, size_t n_bins)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_bins) *reinterpret_cast<uint4*>(hdr + i) = make_uint4(0u, 0u, 0xffffffffu, 0xffffffffu);
+}
+
 // host-callable launchers ---------------------------------------------------------------
 void launch_publish_counters(const Counters* src, Counters* host_dst, hipStream_t st)
 {
   hipLaunchKernelGGL(publish_counters_kernel, dim3(1), dim3(256), 0, st, src, host_dst);
+}
+void launch_init_headers(BinHeader* hdr, size_t n_bins, hipStream_t st)
+{
+  hipLaunchKernelGGL(init_headers_kernel, dim3((unsigned)((n_bins + 255) / 256)), dim3(256), 0, st, hdr, n_bins);
 }
 void launch_reset_clip(Counters* c, hipStream_t st)
 {
@@ -2114,16 +2338,20 @@ uint32_t launch_setup(const SetupArgs& a, uint32_t items_hint, bool sweep, hipSt
   if (grid < worst && sweep) hipLaunchKernelGGL(setup_kernel<true>, dim3(256), dim3(kBlock), 0, st, a, (uint32_t)grid);
   return (uint32_t)grid;
 }
+// workgroups per counter shard: enough to take the shard's whole list in one pass, at most kClipGridWgs (a context of one
+// camera stream launches 8 per shard and holds an 8-MiB spill area instead of 64 MiB)
+static int clip_wgs_per_shard(uint32_t clip_capacity) { return (int)std::min<uint32_t>((clip_capacity + kClipBlock - 1) / kClipBlock, (uint32_t)kClipGridWgs); }
 void launch_clip(const SetupArgs& a, hipStream_t st)
 {
   // the item count lives on the device: fixed grid, grid-stride loop
-  hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * kClipGridWgs), dim3(kClipBlock), 0, st, a);
+  hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * clip_wgs_per_shard(a.clip_capacity)), dim3(kClipBlock), 0, st, a);
 }
-size_t clip_spill_bytes() { return (size_t)(kClipMaxV - kClipLdsV) * kCounterShards * kClipGridWgs * kClipBlock * sizeof(float4); }
+size_t clip_spill_bytes(uint32_t clip_capacity) { return (size_t)(kClipMaxV - kClipLdsV) * kCounterShards * clip_wgs_per_shard(clip_capacity) * kClipBlock * sizeof(float4); }
 void launch_bigrec(const SetupArgs& a, hipStream_t st)
 {
   // the list lengths live on the device: fixed grid, kBigWavesPerShard waves per shard, each strides over its shard's list
-  hipLaunchKernelGGL(bigrec_kernel, dim3(kCounterShards * kBigWavesPerShard / 4), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bigrec_kernel<0>, dim3(kCounterShards * kBigWavesPerShard / 4), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bigrec_kernel<1>, dim3(kCounterShards * kBigWavesPerShard / 4), dim3(256), 0, st, a);
 }
 void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st)
 {

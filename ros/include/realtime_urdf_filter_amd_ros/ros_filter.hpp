@@ -1,14 +1,16 @@
-// ros_filter.hpp -- ROS 1 adapter: the reference's node-handle-facing RealtimeURDFFilter (rosparams, TF,
-// image_transport, cv_bridge) over the MI355X façade.  UNBUILT HERE (no ROS in the image); see ros/README.md.
+// ros_filter.hpp -- ROS 1 adapter: rosparams, TF and image_transport in front of the MI355X façade.
+// UNBUILT HERE (no ROS in either container); see ros/README.md.
 //
-// Shape follows the reference so that launch files keep working:
-//   constructor      src/urdf_filter.cpp:43-118   (fixed_frame, camera_frame, camera_offset, depth_distance_threshold,
-//                                                  show_gui, filter_replace_value; subscribeCamera / advertiseCamera)
-//   loadModels       src/urdf_filter.cpp:127-197  (models: [{model, tf_prefix, geometry_type, scale, ignore}])
-//   filter_callback  src/urdf_filter.cpp:270-330  (32FC1 or 16UC1 in; output_depth in the input encoding, output_mask MONO8)
+// The contract it keeps, so that the reference's launch files and consumers keep working, is the interface only:
+//   private parameters  fixed_frame, camera_frame, camera_offset, depth_distance_threshold, show_gui, filter_replace_value,
+//                       models: [{model, tf_prefix, geometry_type, scale, ignore}]      (src/urdf_filter.cpp:43-197)
+//   topics              input_depth (+ camera_info) in; output_depth in the input's encoding and output_mask (MONO8) out
+//                                                                                         (src/urdf_filter.cpp:114-117, :270-330)
+// How a frame travels is this library's own: no cv_bridge and no CPU-side conversion -- 16UC1 frames go through the fused
+// 16UC1 kernels, results are written into the outgoing messages, a mask-only consumer costs one bit per pixel of
+// device-to-host traffic.
 #pragma once
 
-#include <cv_bridge/cv_bridge.h>
 #include <image_transport/image_transport.h>
 #include <ros/ros.h>
 #include <sensor_msgs/CameraInfo.h>
@@ -16,9 +18,13 @@
 #include <sensor_msgs/image_encodings.h>
 #include <tf/transform_listener.h>
 
+#include <boost/make_shared.hpp>
+#include <cstddef>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "realtime_urdf_filter_amd/urdf_filter.hpp"
 
@@ -49,126 +55,171 @@ class TfProvider : public rtuf_host::TransformProvider {
   ros::Time stamp_;
 };
 
+// What the private node handle must provide (names and meaning as in the reference's launch files; `device` is new).
+// One table instead of a sequence of getParam calls: the adapter's constructor walks it.
+struct RosParamSpec {
+  const char* name;
+  enum Kind { kString, kDouble, kBool, kInt } kind;
+  bool required;
+  size_t offset;                       // of the field in RosFilterConfig
+};
+struct RosFilterConfig {
+  std::string fixed_frame, camera_frame;
+  double depth_distance_threshold = 0.05, filter_replace_value = 0.0;
+  bool show_gui = false;               // accepted, ignored: there is no window system behind this back end
+  int device = 0;                      // which GPU
+};
+inline const std::vector<RosParamSpec>& ros_param_table()
+{
+  static const std::vector<RosParamSpec> table = {
+      {"fixed_frame", RosParamSpec::kString, true, offsetof(RosFilterConfig, fixed_frame)},
+      {"camera_frame", RosParamSpec::kString, true, offsetof(RosFilterConfig, camera_frame)},
+      {"depth_distance_threshold", RosParamSpec::kDouble, true, offsetof(RosFilterConfig, depth_distance_threshold)},
+      {"filter_replace_value", RosParamSpec::kDouble, false, offsetof(RosFilterConfig, filter_replace_value)},
+      {"show_gui", RosParamSpec::kBool, false, offsetof(RosFilterConfig, show_gui)},
+      {"device", RosParamSpec::kInt, false, offsetof(RosFilterConfig, device)},
+  };
+  return table;
+}
+
 class RosFilter {
  public:
   RosFilter(ros::NodeHandle& nh, int /*argc*/, char** /*argv*/) : nh_(nh), image_transport_(nh)
   {
-    FilterParameters prm;
-    if (!nh_.getParam("fixed_frame", prm.fixed_frame)) ROS_FATAL("fixed_frame paramter!");
-    ROS_INFO("using fixed frame %s", prm.fixed_frame.c_str());
-    if (!nh_.getParam("camera_frame", prm.camera_frame)) ROS_FATAL("need a camera_frame paramter!");
-    ROS_INFO("using camera frame %s", prm.camera_frame.c_str());
-    XmlRpc::XmlRpcValue v;
-    if (nh_.getParam("camera_offset", v)) {
-      ROS_ASSERT(v.getType() == XmlRpc::XmlRpcValue::TypeStruct && v.hasMember("translation") && v.hasMember("rotation"));
-      XmlRpc::XmlRpcValue vec = v["translation"];
-      ROS_ASSERT(vec.getType() == XmlRpc::XmlRpcValue::TypeArray && vec.size() == 3);
-      for (int i = 0; i < 3; i++) prm.camera_offset_translation[i] = (double)vec[i];
-      vec = v["rotation"];
-      ROS_ASSERT(vec.getType() == XmlRpc::XmlRpcValue::TypeArray && vec.size() == 4);
-      for (int i = 0; i < 4; i++) prm.camera_offset_rotation[i] = (double)vec[i];          // x y z w
-    }
-    if (!nh_.getParam("depth_distance_threshold", prm.depth_distance_threshold)) ROS_FATAL("need a depth_distance_threshold paramter!");
-    nh_.param<bool>("show_gui", prm.show_gui, false);                 // accepted, ignored: no window system
-    nh_.param<double>("filter_replace_value", prm.filter_replace_value, 0.0);
-    int device = 0;
-    nh_.param<int>("device", device, 0);                              // which GPU (new; the reference has one GL context)
-
-    // models: the URDF XML is resolved here (getParam, then searchParam, like the reference) and handed to the
-    // façade through its string map
-    std::map<std::string, std::string> param_server;
-    XmlRpc::XmlRpcValue models;
-    nh_.getParam("models", models);
-    if (models.getType() == XmlRpc::XmlRpcValue::TypeArray) {
-      for (int i = 0; i < models.size(); ++i) {
-        XmlRpc::XmlRpcValue elem = models[i];
-        ROS_ASSERT(elem.getType() == XmlRpc::XmlRpcValue::TypeStruct);
-        ModelParameter mp;
-        mp.model = static_cast<std::string>(elem["model"]);
-        mp.tf_prefix = static_cast<std::string>(elem["tf_prefix"]);
-        mp.geometry_type = static_cast<std::string>(elem["geometry_type"]);
-        mp.scale = elem.hasMember("scale") ? (double)elem["scale"] : 1.0;
-        if (elem.hasMember("ignore")) {
-          if (elem["ignore"].getType() == XmlRpc::XmlRpcValue::TypeArray)
-            for (int k = 0; k < elem["ignore"].size(); k++) mp.ignore.insert(static_cast<std::string>(elem["ignore"][k]));
-          else if (elem["ignore"].getType() == XmlRpc::XmlRpcValue::TypeString)
-            mp.ignore.insert(static_cast<std::string>(elem["ignore"]));
-          else
-            ROS_FATAL_STREAM("invalid ignore list format: use either single string or list of strings");
-        }
-        std::string content, loc;
-        if (!nh_.getParam(mp.model, content)) {
-          if (nh_.searchParam(mp.model, loc)) nh_.getParam(loc, content);
-          else { ROS_ERROR("Parameter [%s] does not exist, and was not found by searchParam()", mp.model.c_str()); continue; }
-        }
-        param_server[mp.model] = content;
-        prm.models.push_back(mp);
+    RosFilterConfig cfg;
+    for (const RosParamSpec& spec : ros_param_table()) {
+      char* field = reinterpret_cast<char*>(&cfg) + spec.offset;
+      bool found = false;
+      switch (spec.kind) {
+        case RosParamSpec::kString: found = nh_.getParam(spec.name, *reinterpret_cast<std::string*>(field)); break;
+        case RosParamSpec::kDouble: found = nh_.getParam(spec.name, *reinterpret_cast<double*>(field)); break;
+        case RosParamSpec::kBool: found = nh_.getParam(spec.name, *reinterpret_cast<bool*>(field)); break;
+        case RosParamSpec::kInt: found = nh_.getParam(spec.name, *reinterpret_cast<int*>(field)); break;
       }
-    } else {
-      ROS_ERROR("models parameter must be an array!");
+      if (!found && spec.required) ROS_FATAL("private parameter ~%s is required", spec.name);
     }
-    filter_.reset(new RealtimeURDFFilter(prm, tf_, param_server, device, &RosFilter::resolve_mesh, nullptr));
+    FilterParameters prm;
+    prm.fixed_frame = cfg.fixed_frame; prm.camera_frame = cfg.camera_frame;
+    prm.depth_distance_threshold = cfg.depth_distance_threshold; prm.filter_replace_value = cfg.filter_replace_value;
+    prm.show_gui = cfg.show_gui;
+    read_camera_offset(prm);
+    std::map<std::string, std::string> urdf_by_param;
+    read_models(prm, urdf_by_param);
+    filter_.reset(new RealtimeURDFFilter(prm, tf_, urdf_by_param, cfg.device, &RosFilter::resolve_mesh, nullptr));
 
-    depth_sub_ = image_transport_.subscribeCamera("input_depth", 10, &RosFilter::filter_callback, this);
+    depth_sub_ = image_transport_.subscribeCamera("input_depth", 10, &RosFilter::on_frame, this);
     depth_pub_ = image_transport_.advertiseCamera("output_depth", 10);
     mask_pub_ = image_transport_.advertiseCamera("output_mask", 10);
   }
 
-  // callback function that gets ROS images and does everything (src/urdf_filter.cpp:270-330)
-  void filter_callback(const sensor_msgs::ImageConstPtr& ros_depth_image, const sensor_msgs::CameraInfo::ConstPtr& camera_info)
+  // One depth frame in, what the subscribers want out.  The frame reaches the GPU in the encoding it arrived in
+  // (16UC1 millimetres or 32FC1 metres: the conversions are fused into the kernels), the results are written straight
+  // into the messages to publish, and only what somebody listens to is produced: masked depth + mask, masked depth
+  // alone, or -- when only output_mask has subscribers -- one bit per pixel over the bus, expanded on the host.
+  // (The reference converts with cv::Mat::convertTo on the CPU before and after filter(), src/urdf_filter.cpp:280-312.)
+  void on_frame(const sensor_msgs::ImageConstPtr& frame, const sensor_msgs::CameraInfo::ConstPtr& camera_info)
   {
-    cv_bridge::CvImageConstPtr orig_depth_img;
-    cv::Mat depth_image;
-    const bool is_u16 = ros_depth_image->encoding != sensor_msgs::image_encodings::TYPE_32FC1;
-    try {
-      if (!is_u16) {
-        orig_depth_img = cv_bridge::toCvShare(ros_depth_image, sensor_msgs::image_encodings::TYPE_32FC1);
-        depth_image = orig_depth_img->image;
-      } else {
-        orig_depth_img = cv_bridge::toCvShare(ros_depth_image, sensor_msgs::image_encodings::TYPE_16UC1);
-        orig_depth_img->image.convertTo(depth_image, CV_32F, 0.001);
-      }
-    } catch (const cv_bridge::Exception& e) {
-      ROS_ERROR("cv_bridge Exception: %s", e.what());
+    namespace enc = sensor_msgs::image_encodings;
+    const bool u16 = frame->encoding == enc::TYPE_16UC1 || frame->encoding == enc::MONO16;
+    if (!u16 && frame->encoding != enc::TYPE_32FC1) {
+      ROS_ERROR_THROTTLE(5.0, "input_depth: encoding %s is neither 32FC1 nor 16UC1", frame->encoding.c_str());
       return;
     }
-    if (!depth_image.isContinuous()) depth_image = depth_image.clone();
+    const bool wants_depth = depth_pub_.getNumSubscribers() > 0, wants_mask = mask_pub_.getNumSubscribers() > 0;
+    if (!wants_depth && !wants_mask) return;
+    const size_t bpp = u16 ? 2 : 4, row = (size_t)frame->width * bpp;
+    if (frame->is_bigendian) { ROS_ERROR_THROTTLE(5.0, "input_depth: big-endian images are not supported"); return; }
+    // rows must be dense for the device upload; a padded image is compacted once
+    const uint8_t* pixels = frame->data.data();
+    if (frame->step != row) {
+      dense_.resize(row * frame->height);
+      for (uint32_t y = 0; y < frame->height; y++) std::memcpy(&dense_[y * row], &frame->data[(size_t)y * frame->step], row);
+      pixels = dense_.data();
+    }
     CameraInfo info;
     info.width = (int)camera_info->width;
     info.height = (int)camera_info->height;
     for (int i = 0; i < 12; i++) info.P[i] = camera_info->P[i];
-    double projection_matrix[16];
-    filter_->getProjectionMatrix(info, projection_matrix);
-    filter_->need_mask_ = mask_pub_.getNumSubscribers() > 0;          // src/urdf_filter.cpp:226-230
-    tf_.set_stamp(ros_depth_image->header.stamp);
+    double projection[16];
+    filter_->getProjectionMatrix(info, projection);
+    tf_.set_stamp(frame->header.stamp);
+
+    sensor_msgs::ImagePtr depth_msg, mask_msg;
+    if (wants_depth) {
+      depth_msg = boost::make_shared<sensor_msgs::Image>();
+      depth_msg->header = frame->header; depth_msg->encoding = frame->encoding;
+      depth_msg->width = frame->width; depth_msg->height = frame->height; depth_msg->step = (uint32_t)row; depth_msg->is_bigendian = 0;
+      depth_msg->data.resize(row * frame->height);
+    }
+    if (wants_mask) {
+      mask_msg = boost::make_shared<sensor_msgs::Image>();
+      mask_msg->header = frame->header; mask_msg->encoding = enc::MONO8;
+      mask_msg->width = frame->width; mask_msg->height = frame->height; mask_msg->step = frame->width; mask_msg->is_bigendian = 0;
+      mask_msg->data.resize((size_t)frame->width * frame->height);
+    }
+    bool done = false;
     try {
-      filter_->filter(depth_image.data, projection_matrix, depth_image.cols, depth_image.rows, ros_depth_image->header.stamp.toSec());
+      done = filter_->filter_into(pixels, u16, projection, (int)frame->width, (int)frame->height, frame->header.stamp.toSec(),
+                                  wants_depth ? depth_msg->data.data() : nullptr, wants_mask ? mask_msg->data.data() : nullptr);
     } catch (const std::runtime_error& e) {
       ROS_ERROR_STREAM(e.what());
       return;
     }
-    const float* masked = filter_->getMaskedDepth();
-    if (!masked) return;                                              // no transform yet: nothing rendered
-    if (depth_pub_.getNumSubscribers() > 0) {
-      cv::Mat masked_depth_image(camera_info->height, camera_info->width, CV_32FC1, const_cast<float*>(masked));
-      cv_bridge::CvImage out_masked_depth;
-      out_masked_depth.header = ros_depth_image->header;
-      out_masked_depth.encoding = ros_depth_image->encoding;
-      if (is_u16) masked_depth_image.convertTo(out_masked_depth.image, CV_16U, 1000.0);
-      else out_masked_depth.image = masked_depth_image;
-      depth_pub_.publish(out_masked_depth.toImageMsg(), camera_info);
-    }
-    if (mask_pub_.getNumSubscribers() > 0 && filter_->mask_) {
-      cv::Mat mask_image(camera_info->height, camera_info->width, CV_8UC1, const_cast<uint8_t*>(filter_->mask_));
-      cv_bridge::CvImage out_mask;
-      out_mask.header = ros_depth_image->header;
-      out_mask.encoding = sensor_msgs::image_encodings::MONO8;
-      out_mask.image = mask_image;
-      mask_pub_.publish(out_mask.toImageMsg(), camera_info);
-    }
+    if (!done) return;                      // camera transform not available yet
+    if (wants_depth) depth_pub_.publish(depth_msg, boost::make_shared<sensor_msgs::CameraInfo>(*camera_info));
+    if (wants_mask) mask_pub_.publish(mask_msg, boost::make_shared<sensor_msgs::CameraInfo>(*camera_info));
   }
 
  private:
+  // ~camera_offset: {translation: [x, y, z], rotation: [x, y, z, w]}
+  void read_camera_offset(FilterParameters& prm)
+  {
+    XmlRpc::XmlRpcValue v;
+    if (!nh_.getParam("camera_offset", v)) return;
+    auto numbers = [&](const char* key, double* dst, int n) {
+      if (v.getType() != XmlRpc::XmlRpcValue::TypeStruct || !v.hasMember(key) || v[key].getType() != XmlRpc::XmlRpcValue::TypeArray || v[key].size() != n) {
+        ROS_FATAL("~camera_offset/%s must be a list of %d numbers", key, n);
+        return;
+      }
+      for (int i = 0; i < n; i++) dst[i] = v[key][i].getType() == XmlRpc::XmlRpcValue::TypeInt ? (double)(int)v[key][i] : (double)v[key][i];
+    };
+    numbers("translation", prm.camera_offset_translation, 3);
+    numbers("rotation", prm.camera_offset_rotation, 4);
+  }
+
+  // ~models: [{model: <name of the parameter holding the URDF>, tf_prefix, geometry_type, scale, ignore}]
+  void read_models(FilterParameters& prm, std::map<std::string, std::string>& urdf_by_param)
+  {
+    XmlRpc::XmlRpcValue models;
+    if (!nh_.getParam("models", models) || models.getType() != XmlRpc::XmlRpcValue::TypeArray) {
+      ROS_ERROR("~models must be a list of {model, tf_prefix, geometry_type[, scale][, ignore]} entries");
+      return;
+    }
+    for (int i = 0; i < models.size(); ++i) {
+      XmlRpc::XmlRpcValue& e = models[i];
+      if (e.getType() != XmlRpc::XmlRpcValue::TypeStruct || !e.hasMember("model")) { ROS_ERROR("~models[%d] is not a struct with a model entry", i); continue; }
+      ModelParameter mp;
+      mp.model = static_cast<std::string>(e["model"]);
+      if (e.hasMember("tf_prefix")) mp.tf_prefix = static_cast<std::string>(e["tf_prefix"]);
+      if (e.hasMember("geometry_type")) mp.geometry_type = static_cast<std::string>(e["geometry_type"]);
+      if (e.hasMember("scale")) mp.scale = e["scale"].getType() == XmlRpc::XmlRpcValue::TypeInt ? (double)(int)e["scale"] : (double)e["scale"];
+      if (e.hasMember("ignore")) {
+        XmlRpc::XmlRpcValue& ig = e["ignore"];
+        if (ig.getType() == XmlRpc::XmlRpcValue::TypeString) mp.ignore.insert(static_cast<std::string>(ig));
+        else if (ig.getType() == XmlRpc::XmlRpcValue::TypeArray) for (int k = 0; k < ig.size(); k++) mp.ignore.insert(static_cast<std::string>(ig[k]));
+        else ROS_ERROR("~models[%d]/ignore: a link name or a list of link names", i);
+      }
+      // the URDF itself: the named parameter in this namespace, else wherever searchParam finds it (robot_description usually lives above)
+      std::string xml, where;
+      if (!nh_.getParam(mp.model, xml) && !(nh_.searchParam(mp.model, where) && nh_.getParam(where, xml))) {
+        ROS_ERROR("~models[%d]: no parameter %s in reach of this node", i, mp.model.c_str());
+        continue;
+      }
+      urdf_by_param[mp.model] = xml;
+      prm.models.push_back(mp);
+    }
+  }
+
   // package:// and file:// mesh URIs -> file contents (resource_retriever in the reference, src/renderable.cpp:306-322)
   static bool resolve_mesh(const std::string& uri, std::string& data, void* /*user*/);
 
@@ -179,6 +230,7 @@ class RosFilter {
   image_transport::CameraPublisher depth_pub_;
   image_transport::CameraPublisher mask_pub_;
   std::unique_ptr<RealtimeURDFFilter> filter_;
+  std::vector<uint8_t> dense_;          // compacted copy of an input image whose rows are padded
 };
 
 }  // namespace realtime_urdf_filter

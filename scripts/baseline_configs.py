@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import realtime_urdf_filter_amd as R                      # noqa: E402
-from realtime_urdf_filter_amd import workloads as WL      # noqa: E402
+from bench_support import workloads as WL      # noqa: E402
 from oracle import bindings as O                          # noqa: E402
 
 

@@ -12,7 +12,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import scenes as S
 import realtime_urdf_filter_amd as R
-from realtime_urdf_filter_amd import geometry as G, synthetic
+from realtime_urdf_filter_amd import geometry as G
+from bench_support import synthetic
 from realtime_urdf_filter_amd.filter import depth_f32_to_u16, depth_u16_to_f32
 from oracle import bindings as O
 

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import realtime_urdf_filter_amd as R                      # noqa: E402
-from realtime_urdf_filter_amd import workloads as WL      # noqa: E402
+from bench_support import workloads as WL      # noqa: E402
 from realtime_urdf_filter_amd.filter import depth_f32_to_u16, depth_u16_to_f32   # noqa: E402
 
 

@@ -32,7 +32,7 @@ WORKLOADS = {
 
 
 def build_workload(name, frames):
-    from realtime_urdf_filter_amd import workloads as WL
+    from bench_support import workloads as WL
     if name == "C1":
         wl = WL.example_workload(640, 480)
         return wl, 1

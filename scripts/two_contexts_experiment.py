@@ -4,7 +4,7 @@ import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import realtime_urdf_filter_amd as R
-from realtime_urdf_filter_amd import workloads as WL
+from bench_support import workloads as WL
 
 n, W, H, steps = 256, 640, 480, int(sys.argv[1]) if len(sys.argv) > 1 else 40
 variants = [WL.pr2_workload(n, W, H, 250000, first_state_seed=1000 + 100000 * v) for v in range(2)]

@@ -23,7 +23,7 @@ import scenes as S  # noqa: E402
 from oracle.ref_gl import harness as HN  # noqa: E402
 from oracle import bindings as O  # noqa: E402
 from realtime_urdf_filter_amd import geometry as G  # noqa: E402
-from realtime_urdf_filter_amd import synthetic, workloads  # noqa: E402
+from bench_support import synthetic, workloads  # noqa: E402
 
 NAN_CODE, INF_CODE = 65535, 65534
 

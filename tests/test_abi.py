@@ -29,8 +29,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_struct_sizes():
     lib = R.load_library()
-    assert lib.rtuf_abi_version() == R.ABI_VERSION == 3
-    assert ctypes.sizeof(_capi.Params) == 48 and ctypes.sizeof(_capi.Stats) == 136
+    assert lib.rtuf_abi_version() == R.ABI_VERSION == 4
+    assert ctypes.sizeof(_capi.Params) == 48 and ctypes.sizeof(_capi.Stats) == 184
     p = R.default_params()
     assert abs(p.near_plane - 0.1) < 1e-7 and p.far_plane == 8.0 and abs(p.depth_distance_threshold - 0.05) < 1e-7
     assert p.filter_replace_value == 0.0 and p.flags == 0
@@ -70,6 +70,26 @@ def test_product_package_never_touches_the_oracle():
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "oracle" not in txt.replace("the oracle", "").replace("oracle/", "").lower() or "import oracle" not in txt, f
                 assert "from oracle" not in txt and "import oracle" not in txt and "librtuf_oracle" not in txt, f
+                # ... and nothing of the benchmark's world (robot generator, workloads, per-GPU shares) ships in it
+                assert "bench_support" not in txt, f
+
+
+def test_product_package_has_no_checker_helpers():
+    """No module, class or function of the product package is named after the oracle (helpers that prepare the
+    checker's inputs live in bench_support/), and the package does not contain the benchmark's modules."""
+    import importlib
+    import inspect
+    import pkgutil
+    import realtime_urdf_filter_amd as R
+    names = [m.name for m in pkgutil.iter_modules(R.__path__)]
+    assert not {"synthetic", "workloads", "configs"} & set(names), names
+    for name in names:
+        mod = importlib.import_module("realtime_urdf_filter_amd." + name)
+        for attr, obj in vars(mod).items():
+            assert "oracle" not in attr.lower(), (name, attr)
+            if inspect.isclass(obj) and obj.__module__ == mod.__name__:
+                for meth in vars(obj):
+                    assert "oracle" not in meth.lower(), (name, attr, meth)
 
 
 def test_one_hip_runtime_per_process_in_either_import_order():

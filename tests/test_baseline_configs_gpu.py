@@ -6,8 +6,8 @@ import numpy as np
 import pytest
 
 import realtime_urdf_filter_amd as R
-from realtime_urdf_filter_amd import configs as CF
-from realtime_urdf_filter_amd import workloads as WL
+from bench_support import configs as CF
+from bench_support import workloads as WL
 from oracle import bindings as O
 
 pytestmark = pytest.mark.gpu
@@ -173,6 +173,116 @@ def test_config5_per_gpu_share_8_urdfs_x_128_streams():
     streams = [g.first + j for g in share.groups for j in (3, 127)]
     check_against_oracle(share, 0, streams, depth, masked, mask, link_dev, cam_dev)
     ctx.close()
+
+
+def run_share(share, k, oracle_streams, variant=0):
+    """One step of a share through the device-plane call; returns what check_* need."""
+    import torch
+    n, W, H = share.n, share.width, share.height
+    ctx = R.Context(W, H, n, 0, params(share.wl0))
+    share.load(ctx)
+    dev = torch.device("cuda:0")
+    depth = share.depth_host(variant)
+    d_depth = torch.from_numpy(depth).to(dev)
+    d_masked = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+    d_mask = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+    for kk in (k - 1, k):          # two steps: the second one sizes its set-up grid from the first
+        share.stage(ctx, kk)
+        ctx.filter_batch_device(n, d_depth.data_ptr(), d_masked.data_ptr(), d_mask.data_ptr())
+        ctx.sync()
+    masked, mask = d_masked.cpu().numpy(), d_mask.cpu().numpy()
+    check_properties(depth, masked, mask, share.wl0.replace_value)
+    link_dev, cam_dev = ctx.read_poses(n, share.n_links_total)
+    check_against_oracle(share, k, oracle_streams, depth, masked, mask, link_dev, cam_dev)
+    st = ctx.stats()
+    ctx.close()
+    return mask, st
+
+
+def test_config3_forearm_in_front_of_the_lens_256_streams():
+    """The self-filter's own normal case: the robot's arm right in front of the sensor.  All 256
+    streams of the headline workload pose the right forearm 0.1 - 0.35 m in front of the head camera (window z on both
+    sides of 0.5: the exact-z pass runs, the gripper crosses the near plane, the arm covers whole tiles and hides the
+    robot behind it).  Properties on every stream, 8 streams against the oracle."""
+    share = CF.build("c3", 1, 0, near_arm=True)
+    assert share.n == 256 and share.wl0.n_triangles() > 240000
+    mask, st = run_share(share, 1, [0, 37, 74, 111, 148, 185, 222, 255], variant=1)
+    assert (mask > 0).mean() > 0.3           # the arm fills a good part of every view
+    assert st["exact_tiles"] > 1000          # (the arm's mesh is fine: no single triangle covers a whole tile, cover_tiles stays 0)
+
+
+@pytest.mark.parametrize("workload,rank", [("c4", 5), ("c5", 3)])
+def test_other_ranks_shares_of_the_8_gpu_configs(workload, rank):
+    """Shares other than rank 0's of BASELINE configs 4 and 5 (other global stream numbers -> other joint states,
+    for c5 other URDFs: 3, 11, ..., 59) at their full per-GPU size, two streams each against the oracle."""
+    share = CF.build(workload, 8, rank)
+    if workload == "c4":
+        assert (share.n, share.width, share.height) == (64, 1280, 720) and share.groups[0].global_first == 5 * 64
+        streams = [7, 60]
+    else:
+        assert share.n == 1024 and [g.robot_index for g in share.groups] == list(range(3, 64, 8))
+        streams = [share.groups[2].first + 5, share.groups[7].first + 100]
+    run_share(share, 1, streams)
+
+
+def _multi_gpu_example():
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "bin", "multi_gpu_filter")
+    if not os.path.exists(exe):
+        subprocess.check_call([os.path.join(root, "realtime_urdf_filter_amd", "csrc", "build_facade.sh")])
+    return exe
+
+
+@pytest.mark.parametrize("mode,masks", [("block", "direct"), ("block", "rccl"), ("model", "direct")])
+def test_cpp_multi_device_host_with_rccl_gather(tmp_path, mode, masks):
+    """examples/multi_gpu_filter.cpp over include/realtime_urdf_filter_amd/multi_gpu.hpp: the C++ host of SURVEY.md
+    section 8e -- one thread and one rtuf_context per device, block shares (configs 3 / 4) or URDF m on device m % N
+    (config 5), forward kinematics on the device, ncclCommInitAll + one ncclAllGather of {frames, seconds, mismatches}
+    and the all-gather of the bit-packed masks (peer-to-peer copies or ncclAllGather).  Runs on every device the box
+    has (one here); a dumped stream is checked against the oracle fed the matrices the device rendered with."""
+    import json
+    import subprocess
+    import scene_file
+    if mode == "block":
+        share = CF.build("c4", 1, 0, streams=6, triangles=20000, width=640, height=360)      # robot + walls, 6 streams
+        pick = 4
+    else:
+        share = CF.build("c5", 1, 0, streams=3, urdfs=3, triangles=15000)                     # 3 robots x 3 cameras
+        pick = 7
+    scene = tmp_path / "scene.bin"
+    depth = scene_file.write_scene(str(scene), share, k=0)
+    out = subprocess.run([_multi_gpu_example(), str(scene), "--mode", mode, "--steps", "3", "--masks", masks, "--dump", str(pick), str(tmp_path / "s")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["streams"] == share.n and rep["frames"] == share.n * 3 and rep["bits_vs_bytes_mismatches"] == 0
+    assert rep["gathered_masks_equal_sources"] == 1 and sum(d["streams"] for d in rep["per_device"]) == share.n
+    W, H = share.width, share.height
+    masked = np.fromfile(tmp_path / "s.masked.f32", np.float32).reshape(H, W)
+    mask = np.fromfile(tmp_path / "s.mask.u8", np.uint8).reshape(H, W)
+    link_tf = np.fromfile(tmp_path / "s.link_tf.f64", np.float64).reshape(-1, 16)
+    cam_tf = np.fromfile(tmp_path / "s.cam_tf.f64", np.float64)
+    order = [int(x) for x in (tmp_path / "s.models.txt").read_text().split()]
+    # the oracle's draw list of that stream: the models its device loaded, in that order, with the device's matrices
+    g = share.group_of(pick)
+    wl = g.variants[0]
+    job_models = [(gg, mi) for gg in share.groups for mi in range(len(gg.variants[0].models))]
+    draws, row = [], 0
+    for gm in order:
+        gg, mi = job_models[gm]
+        links = gg.variants[0].models[mi]
+        if gg is g:
+            for li, dl in enumerate(links):
+                for d in dl:
+                    draws.append((link_tf[row + li], d.pre_op, d.op, d.verts, d.tris))
+        row += len(links)
+    j = pick - g.first
+    om, ok = O.filter_frame(depth[pick % len(depth)], wl.projection[j], draws, wl.offset_inv[j], cam_tf,
+                            max_diff=wl.max_diff, replace_value=wl.replace_value)
+    assert (ok != mask).sum() == 0 and bits_equal(om, masked)
+    assert 0.01 < (mask > 0).mean() < 0.99
 
 
 def test_launch_group_of_1024_streams_that_all_see_the_whole_model():

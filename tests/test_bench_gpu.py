@@ -42,6 +42,22 @@ def test_bench_line_contract():
     assert cb["all_cores"]["cores"] >= 1 and cb["all_cores"]["value"] > 0
 
 
+def test_bench_nccl_world1():
+    """torch.distributed.run with ONE rank and the real backend: bench.py's RCCL lines -- init_process_group("nccl"), the
+    barriers, the MAX all-reduces and the all-gathers of the per-rank counts -- execute on hardware (the test box has one
+    GPU; the two-rank rehearsals below share it over gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RTUF_BENCH_BACKEND", "RTUF_BENCH_DEVICE")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["collectives"]["world"] == 1 and "rccl" in d["collectives"]["backend"]
+    pr = d["parity"]["per_rank"]
+    assert len(pr) == 1 and pr[0]["frames"] == 8 * d["timed_steps"] and pr[0]["mismatching_values"] == 0
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
 def _two_ranks(extra, port):
     env = dict(os.environ, RTUF_BENCH_BACKEND="gloo", RTUF_BENCH_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

@@ -1,9 +1,10 @@
-"""CPU: the per-rank shares of BASELINE configs 3-5 (realtime_urdf_filter_amd/configs.py) partition the job with no
+"""CPU: the per-rank shares of BASELINE configs 3-5 (bench_support/configs.py) partition the job with no
 overlap -- disjoint streams, disjoint joint states, disjoint URDFs -- and the union over the ranks is the whole job."""
 import numpy as np
 import pytest
 
-from realtime_urdf_filter_amd import configs as CF, sharding
+from realtime_urdf_filter_amd import sharding
+from bench_support import configs as CF
 
 
 def test_shard_helpers():

@@ -23,7 +23,8 @@ def _worker(rank, world, port, n_streams, out_q):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    from realtime_urdf_filter_amd import sharding, workloads as WL
+    from realtime_urdf_filter_amd import sharding
+    from bench_support import workloads as WL
     from oracle import bindings as O
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -44,7 +45,7 @@ def _worker(rank, world, port, n_streams, out_q):
 
 def test_two_rank_sharding_equals_single_process():
     import torch.multiprocessing as mp
-    from realtime_urdf_filter_amd import workloads as WL
+    from bench_support import workloads as WL
     from oracle import bindings as O
     n = 5
     ctx = mp.get_context("spawn")

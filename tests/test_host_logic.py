@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 from realtime_urdf_filter_amd import geometry as G
-from realtime_urdf_filter_amd import sharding, synthetic, urdf, workloads
+from realtime_urdf_filter_amd import sharding, urdf
+from bench_support import synthetic, workloads
 from realtime_urdf_filter_amd.filter import (URDFRenderer, depth_f32_to_u16, depth_u16_to_f32, RenderableBox)
 
 

@@ -10,7 +10,7 @@ import pytest
 import golden_io
 import scenes as S
 import realtime_urdf_filter_amd as R
-from realtime_urdf_filter_amd import workloads as WL
+from bench_support import workloads as WL
 from realtime_urdf_filter_amd import _capi, urdf
 from realtime_urdf_filter_amd.filter import CameraInfo, FilterParameters, RealtimeURDFFilter, depth_f32_to_u16, depth_u16_to_f32
 from oracle import bindings as O
@@ -48,10 +48,10 @@ def test_golden_fixture(name, two_kernel):
     ctx.close()
 
 
-def run_soups(W, H, n_streams, seed, two_kernel=False, **pkw):
+def run_soups(W, H, n_streams, seed, two_kernel=False, tris_per_link=50, **pkw):
     rng = np.random.default_rng(seed)
     P = S.projection(525.0 * W / 640, 525.0 * W / 640, (W - 1) / 2, (H - 1) / 2, W, H)
-    geo = S.soup_geometry(rng, n_links=7, tris_per_link=50)
+    geo = S.soup_geometry(rng, n_links=7, tris_per_link=tris_per_link)
     ctx = R.Context(W, H, n_streams, 0, params(5.0, 0.05, two_kernel, **pkw))
     m = ctx.add_model()
     for pre, op, v, t in geo:
@@ -98,13 +98,13 @@ def test_need_mask_false():
 
 
 def test_bin_regrowth_and_inflight_groups():
-    """Tiny bins + 2 streams per in-flight group: the batch overflows, is re-run with larger bins and
-    still comes out exact."""
-    ctx, P, geo, depth, per = run_soups(320, 240, 5, seed=9, bin_capacity=8, max_inflight_streams=2)
+    """Bins of one record + 2 streams per in-flight group: the batch overflows, is re-run with bins sized from what it
+    asked for and still comes out exact."""
+    ctx, P, geo, depth, per = run_soups(320, 240, 5, seed=9, bin_capacity=1, max_inflight_streams=2)
     masked, mask = ctx.filter_batch(depth)
     check_vs_oracle(masked, mask, P, geo, depth, per)
     st = ctx.stats()
-    assert st["regrowths"] >= 1 and st["bin_capacity"] > 8
+    assert st["regrowths"] >= 1 and st["bin_capacity"] > 1 and st["bin_capacity"] % 256 == 0
     masked2, mask2 = ctx.filter_batch(depth)        # second batch: no further regrowth, same answer
     assert bits_equal(masked, masked2) and np.array_equal(mask, mask2)
     ctx.close()
@@ -114,7 +114,7 @@ def test_many_streams_in_one_launch_group():
     """600 small streams: more than the 256 a launch group used to hold, fewer than the 1024 it holds now;
     too-small bins force a regrowth of the large group as well."""
     n = 600
-    ctx, P, geo, depth, per = run_soups(96, 64, n, seed=21, bin_capacity=8)
+    ctx, P, geo, depth, per = run_soups(96, 64, n, seed=21, bin_capacity=1)
     masked, mask = ctx.filter_batch(depth)
     pick = list(range(0, n, 53)) + [255, 256, 257, n - 1]
     sub = [per[s] for s in pick]
@@ -498,7 +498,7 @@ def test_two_batches_in_flight_and_regrowth_reruns_both():
     d_depth = torch.from_numpy(depth).to(dev)
     outs = [(torch.empty((n, H, W), dtype=torch.float32, device=dev), torch.empty((n, H, W), dtype=torch.uint8, device=dev)) for _ in range(3)]
     torch.cuda.synchronize()
-    for cap in (0, 16):                      # default capacity, then bins that must grow
+    for cap in (0, 1):                       # default capacity, then bins that must grow
         ctx = R.Context(W, H, n, 0, params(A.replace_value, A.max_diff, bin_capacity=cap))
         ids = A.load_into(ctx)
         A.load_kinematics(ctx, ids)
@@ -511,16 +511,16 @@ def test_two_batches_in_flight_and_regrowth_reruns_both():
             want = refs[0] if wl is A else refs[1]
             assert np.array_equal(outs[i][1].cpu().numpy(), want[1]) and bits_equal(outs[i][0].cpu().numpy(), want[0]), (cap, i)
         st = ctx.stats()
-        assert (st["regrowths"] > 0) == (cap == 16)
+        assert (st["regrowths"] > 0) == (cap == 1)
         ctx.close()
 
 
-@pytest.mark.parametrize("cap", [0, 16])
+@pytest.mark.parametrize("cap", [0, 1])
 def test_asynchronous_host_planes(cap):
     """rtuf_filter_batch_async / _u16_async: host planes go up and come back on copy streams while another
     batch computes.  Three batches with different joint states and sensor images are enqueued without a wait
     in between (pinned memory, then pageable memory with planes that are not adjacent); every output must
-    be the oracle's, also when too-small bins force both batches in flight to run again (cap=16)."""
+    be the oracle's, also when too-small bins force both batches in flight to run again (cap=1)."""
     n, W, H = 4, 320, 240
     wls = [WL.pr2_workload(n, W, H, total_triangles=8000, first_state_seed=seed) for seed in (1000, 2000)]
     A = wls[0]
@@ -550,7 +550,7 @@ def test_asynchronous_host_planes(cap):
         for s in range(n):
             om, ok = oracle(order[i], depths[i], s)
             assert np.array_equal(ok, pin_mask[i][s]) and bits_equal(om, pin_out[i][s]), (cap, i, s)
-    assert (ctx.stats()["regrowths"] > 0) == (cap == 16)
+    assert (ctx.stats()["regrowths"] > 0) == (cap == 1)
 
     # pageable planes scattered in memory, no mask for stream 1, through the raw C ABI
     lib = R.load_library()
@@ -743,10 +743,11 @@ def test_clipper_vertex_just_outside_the_frustum():
 
 
 def test_fragment_bin_and_clip_list_overflow_regrow():
-    """Capacity stress: (a) 60,000 two-pixel triangles piled onto one 64x32 tile overflow that tile's fragment
-    bin (and its record bin), (b) 120,000 triangles that all cross the near plane overflow the clip list; both
-    (c) 90,000 slivers that each touch more than four tiles overflow the many-tile lists; all are detected from the
-    batch's counters, the buffers grow, the batch runs again and matches the oracle."""
+    """Capacity stress: (a) 60,000 two-pixel triangles piled onto one 64x32 tile overflow that tile's fragment bin (and
+    its record bin), (b) 120,000 triangles that all cross the near plane overflow the clip list, (c) 90,000 slivers that
+    each touch more than four tiles overflow the many-tile lists, (d) 30,000 small triangles of one size class on one
+    tile overflow its record bin from the front; all are detected from the batch's counters, the buffers grow to what the
+    batch asked for, the batch runs again and matches the oracle."""
     W, H = 256, 128
     P = S.projection(210.0, 210.0, (W - 1) / 2, (H - 1) / 2, W, H)
     I = S.gl(np.eye(4))
@@ -770,7 +771,11 @@ def test_fragment_bin_and_clip_list_overflow_regrow():
     b3 = a3 + np.stack([0.9 * np.cos(ang), 0.9 * np.sin(ang), rng.normal(scale=0.05, size=n3)], axis=1)
     c3 = a3 + rng.normal(scale=0.004, size=(n3, 3))
     vc = np.stack([a3, b3, c3], axis=1).reshape(-1, 3).astype(np.float32)
-    for verts in (va, vb, vc):
+    # (d) 6 - 9 pixel wide triangles (records of the small-box class, never fragments) all inside one tile
+    n4 = 30000
+    c4 = np.stack([rng.uniform(-0.07, -0.04, n4), rng.uniform(-0.10, -0.05, n4), rng.uniform(0.95, 1.05, n4)], axis=1)
+    vd = (c4[:, None, :] + rng.uniform(-0.022, 0.022, size=(n4, 3, 3)) * np.array([1.0, 0.3, 1.0])).reshape(-1, 3).astype(np.float32)
+    for case, verts in (("a", va), ("b", vb), ("c", vc), ("d", vd)):
         tris = np.arange(len(verts), dtype=np.uint32).reshape(-1, 3)
         om, ok = O.filter_frame(depth, P, [(I, 0, [0.0, 0.0, 0.0], verts, tris)], I, I, replace_value=5.0)
         ctx = R.Context(W, H, 1, 0, params(5.0, 0.05))
@@ -781,10 +786,11 @@ def test_fragment_bin_and_clip_list_overflow_regrow():
         ctx.set_link_poses(0, m, np.stack([I]))
         masked, mask = ctx.filter_batch(depth[None])
         st = ctx.stats()
-        assert st["regrowths"] >= 1, st
-        assert (ok != mask[0]).sum() == 0 and bits_equal(om, masked[0])
+        assert st["regrowths"] >= 1, (case, st)
+        assert (ok != mask[0]).sum() == 0 and bits_equal(om, masked[0]), case
         masked, mask = ctx.filter_batch(depth[None])                 # steady state: no further growth, same result
-        assert ctx.stats()["regrowths"] == st["regrowths"] and (ok != mask[0]).sum() == 0 and bits_equal(om, masked[0])
+        assert ctx.stats()["regrowths"] == st["regrowths"], (case, st, ctx.stats())
+        assert (ok != mask[0]).sum() == 0 and bits_equal(om, masked[0]), case
         ctx.close()
 
 
@@ -837,6 +843,96 @@ def test_screen_filling_layers(size):
     masked, mask = ctx.filter_batch(depth)
     check_vs_oracle(masked, mask, P, geo, depth, per)
     assert mask[0].astype(bool).mean() > 0.5          # the layers really fill the view
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["fused", "two_kernel", "bits"])
+@pytest.mark.parametrize("size", [(640, 480), (1280, 720), (200, 150)])
+def test_whole_tile_cover_planes_near_and_far(size, mode):
+    """A triangle that covers a whole tile becomes that tile's initial depth keys and hides what lies behind it
+    (bigrec_kernel<0> / <1>, tile kernel): many-tile records behind it are never appended, bin records and fragments
+    behind it are dropped when loaded.  Layers in the exact-z range (window z <= 0.5: closer than ~0.2 m, where the
+    cover's float z has to be written by the exact-z pass although it is in no bin), a tilted layer that crosses
+    z = 0.5 inside the image, coincident layers (draw order decides), layers a 24-bit step apart, partial layers,
+    and dust of small triangles (fragments and lane-walk records) in front of, inside and behind all of them.
+    Every pixel must be the oracle's."""
+    W, H = size
+    fx = 525.0 * W / 640
+    P = S.projection(fx, fx, (W - 1) / 2, (H - 1) / 2, W, H)
+    rng = np.random.default_rng(W + len(mode))
+
+    def quad(z, u0=-0.2, u1=1.2, v0=-0.2, v1=1.2, flip=False):
+        pts = []
+        for (u, v), zz in zip(((u0, v0), (u1, v0), (u0, v1), (u1, v1)), z):
+            pts.append(((u * W - (W - 1) / 2) / fx * zz, (v * H - (H - 1) / 2) / fx * zz, zz))
+        v = np.array(pts, np.float32)
+        t = np.array([[0, 1, 2], [2, 1, 3]] if not flip else [[0, 1, 3], [0, 3, 2]], np.uint32)
+        return v, t
+
+    def dust(n, z_lo, z_hi, size_px):
+        """n small triangles (about size_px pixels across) at depths z_lo..z_hi all over the image"""
+        z = rng.uniform(z_lo, z_hi, n)
+        cx, cy = rng.uniform(0, W, n), rng.uniform(0, H, n)
+        d = rng.uniform(-size_px, size_px, (n, 3, 2))
+        v = np.zeros((n, 3, 3), np.float32)
+        for k in range(3):
+            v[:, k, 0] = (cx + d[:, k, 0] - (W - 1) / 2) / fx * z
+            v[:, k, 1] = (cy + d[:, k, 1] - (H - 1) / 2) / fx * z
+            v[:, k, 2] = z * (1.0 + 0.01 * rng.uniform(-1, 1, n))
+        return v.reshape(-1, 3), np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+
+    cases = {
+        "far walls, dust everywhere": [quad((2.0,) * 4), quad((3.0,) * 4, flip=True), quad((2.0,) * 4, flip=True), quad((1.5, 2.5, 1.5, 2.5)),
+                                       dust(3000, 0.5, 4.0, 2.0), dust(600, 0.5, 4.0, 9.0)],
+        "cover inside the exact-z range": [quad((0.15,) * 4), quad((0.17,) * 4, flip=True), quad((0.15,) * 4, flip=True),
+                                           dust(2000, 0.11, 0.3, 3.0), dust(500, 0.11, 0.3, 12.0), quad((0.12,) * 4, u0=0.3, u1=0.6)],
+        "tilted cover across window z = 0.5": [quad((0.17, 0.24, 0.17, 0.24)), quad((0.24, 0.17, 0.30, 0.2), flip=True), quad((0.1975,) * 4),
+                                               dust(2500, 0.12, 0.5, 2.5), dust(400, 0.12, 0.5, 10.0)],
+        "one 24-bit step apart": [quad((2.0,) * 4), quad((2.0000002,) * 4, flip=True), quad((1.9999998,) * 4), dust(1500, 1.99, 2.01, 4.0)],
+    }
+    n = len(cases)
+    geo, owner = [], []
+    for ci, layers in enumerate(cases.values()):
+        for v, t in layers:
+            geo.append((0, [0.0, 0.0, 0.0], v, t))
+            owner.append(ci)
+    kw = dict(two_kernel=True) if mode == "two_kernel" else {}
+    ctx = R.Context(W, H, n, 0, params(**kw))
+    # one model per case, every stream renders its own case
+    models = [ctx.add_model() for _ in range(n)]
+    for (pre, op, v, t), ci in zip(geo, owner):
+        l = ctx.add_link(models[ci])
+        ctx.add_draw(models[ci], l, v, t, pre, op)
+    ctx.finalize_models()
+    ident = np.eye(4).T.reshape(16)
+    depth = np.stack([S.sensor_depth(W, H, 0.4 * s) for s in range(n)])
+    depth[1] *= 0.08          # sensor values around the near layers, so that both outcomes of the compare occur
+    depth[2] *= 0.1
+    for s in range(n):
+        ctx.set_stream_models(s, [models[s]])
+        ctx.set_camera(s, P, None, None)
+        for ci in range(n):
+            nl = owner.count(ci)
+            ctx.set_link_poses(s, models[ci], np.stack([ident] * nl))
+    if mode == "bits":
+        pin_in = ctx.host_alloc((n, H, W), np.float32)
+        pin_bits = ctx.host_alloc((n, ctx.mask_bits_words()), np.uint32)
+        pin_in[...] = depth
+        ctx.filter_batch_bits_async(pin_in, pin_bits)
+        ctx.sync()
+        both = [R.expand_mask_bits(depth[s], pin_bits[s], 5.0) for s in range(n)]
+        masked, mask = np.stack([b[0] for b in both]), np.stack([b[1] for b in both])
+    else:
+        masked, mask = ctx.filter_batch(depth)
+    for s in range(n):
+        draws = [(ident,) + g for g, ci in zip(geo, owner) if ci == s]
+        om, ok = O.filter_frame(depth[s], P, draws, None, None, replace_value=5.0)
+        assert (ok != mask[s]).sum() == 0, "case %d (%s): %d mask pixels differ" % (s, list(cases)[s], int((ok != mask[s]).sum()))
+        assert bits_equal(om, masked[s]), "case %d (%s): masked depth differs" % (s, list(cases)[s])
+    st = ctx.stats()
+    if "cover_tiles" in st:
+        assert st["cover_tiles"] > 0 and st["occluded_entries"] > 0
+    assert 0.05 < mask.astype(bool).mean() < 0.999
     ctx.close()
 
 
@@ -1182,11 +1278,11 @@ def test_general_forward_kinematics_kernel_for_trees_of_more_than_256_frames():
     ctx.close()
 
 
-@pytest.mark.parametrize("cap", [0, 16])
+@pytest.mark.parametrize("cap", [0, 1])
 def test_staging_next_link_matrices_while_batches_are_in_flight(cap):
     """The TF-driven shape of the reference at many streams: cameras and link matrices from the host every frame.  Their
     staging is a ring of sets (one per batch in flight + one being written), so frame k+1's matrices are staged while
-    frames k and k-1 are still on the GPU, nothing waits in between -- and a bin regrowth (cap=16), which re-runs the
+    frames k and k-1 are still on the GPU, nothing waits in between -- and a bin regrowth (cap=1), which re-runs the
     batches in flight, must re-read each batch's own set, not what was staged since."""
     import torch
     n, W, H = 5, 320, 240
@@ -1229,7 +1325,7 @@ def test_staging_next_link_matrices_while_batches_are_in_flight(cap):
             om, ok = O.filter_frame(depths[k][s], wl.projection[s], wl.oracle_draws(s), wl.offset_inv[s], wl.cam_tf[s],
                                     max_diff=wl.max_diff, replace_value=wl.replace_value)
             assert np.array_equal(ok, mask[s]) and bits_equal(om, masked[s]), (cap, k, s)
-    assert (ctx.stats()["regrowths"] > 0) == (cap == 16)
+    assert (ctx.stats()["regrowths"] > 0) == (cap == 1)
     ctx.close()
 
 
