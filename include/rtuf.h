@@ -290,6 +290,9 @@ typedef struct {
   uint32_t exact_tiles;             /* tiles that ran the exact-z pass (a winner with window z <= 0.5)                 */
   uint32_t work_items;              /* set-up work items (chunk x up to 3 streams that see it) of the last batch       */
   uint32_t zero_survivor_items;     /* ... of which no triangle survived the clip / sub-pixel culls                    */
+  uint32_t cover_pass;              /* 1: the last batch ran the cover pass (on while scenes have whole-tile triangles,
+                                       switched off after three batches without one, probed again every 64th batch)     */
+  uint32_t reserved0;
   uint64_t raster_atomics;          /* instrumented builds (-DRTUF_COUNT) only: depth tests the tile kernel issued      */
   uint64_t drawn_pixels;            /* instrumented builds only: pixels whose final depth key is not the background's   */
 } rtuf_stats;

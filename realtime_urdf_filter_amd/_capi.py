@@ -52,10 +52,11 @@ class Stats(ctypes.Structure):
                 ("device_bytes", ctypes.c_uint64), ("occluded_entries", ctypes.c_uint64),
                 ("cover_tiles", ctypes.c_uint32), ("exact_tiles", ctypes.c_uint32),
                 ("work_items", ctypes.c_uint32), ("zero_survivor_items", ctypes.c_uint32),
+                ("cover_pass", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
                 ("raster_atomics", ctypes.c_uint64), ("drawn_pixels", ctypes.c_uint64)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
 
 
 class RtufError(RuntimeError):

@@ -148,6 +148,7 @@ struct rtuf_context {
     struct { uint64_t hash = 0; hipGraphExec_t exec = nullptr; } graphs[kGraphs];
     int graph_next = 0;
     uint32_t setup_grid = 0xffffffffu;       // work items the set-up launch covered (single-group batches)
+    bool cover_pass = true;                  // this batch runs the cover pass (decided when it is first enqueued, kept for re-runs)
     int timing = 0;                          // event timing of this batch: 0 none, 1 every stage, 2 tile/compare kernel only
     // Host-plane batches (rtuf_filter_batch*): device staging of this slot, the caller's planes, and the
     // events that order upload -> kernels -> download across the copy streams.
@@ -169,6 +170,12 @@ struct rtuf_context {
   bool graphs_ok = false;
   uint32_t graph_hits = 0, graph_misses = 0; // replays / captures: a caller that never repeats an argument set (fresh output buffers
                                              // every frame) would pay a capture + instantiate per batch -- then graphs are switched off
+  // The cover pass (bigrec_kernel<0> + the cover-aware tile kernel) pays where triangles cover whole tiles -- walls, anything
+  // close to the lens -- and costs 3 % where none do (a finely tessellated robot at arm's length).  It is an optimisation
+  // only (the image is the same with and without), so the context switches it by what the batches show: three batches in a
+  // row without a single cover tile turn it off, every 64th batch runs it again as a probe.
+  bool cover_on = true;
+  int cover_idle = 0, cover_sleep = 0;
   int oldest = 0;                            // ring index of the oldest batch in flight
   int pending = 0;                           // batches in flight
 
@@ -1114,6 +1121,7 @@ struct BatchPlan {
   PoseArgs pa{};
   struct Group { SetupArgs sa{}; TileArgs ta{}; CompareArgs ca{}; bool compare = false; };
   std::vector<Group> groups;
+  bool cover_pass = true;
   uint64_t hash() const
   {
     uint64_t h = 1469598103934665603ull;
@@ -1121,7 +1129,7 @@ struct BatchPlan {
     for (const FkArgs& f : fks) mix(&f, sizeof f);
     mix(&pa, sizeof pa);
     for (const Group& g : groups) { mix(&g.sa, sizeof g.sa); mix(&g.ta, sizeof g.ta); if (g.compare) mix(&g.ca, sizeof g.ca); }
-    return h ^ (uint64_t)fks.size() << 56 ^ (uint64_t)groups.size() << 48;
+    return h ^ (uint64_t)fks.size() << 56 ^ (uint64_t)groups.size() << 48 ^ (uint64_t)cover_pass << 47;
   }
 };
 
@@ -1153,9 +1161,9 @@ static int issue_plan(rtuf_context* c, rtuf_context::Batch& b, const BatchPlan& 
     b.setup_grid = single_group ? grid : 0xffffffffu;
     if (b.timing >= 2) hipEventRecord(get_event(b, ev++), st);
     launch_clip(gr.sa, st);
-    launch_bigrec(gr.sa, st);            // appends the many-tile records the two kernels above listed
+    launch_bigrec(gr.sa, plan.cover_pass, st);      // appends the many-tile records the two kernels above listed (after the cover pass, if it is on)
     if (b.timing) hipEventRecord(get_event(b, ev++), st);
-    launch_tile(gr.ta, two, st);
+    launch_tile(gr.ta, two, plan.cover_pass, st);
     if (b.timing) hipEventRecord(get_event(b, ev++), st);
     if (gr.compare) launch_compare(gr.ca, st);
     if (b.timing == 1 || (b.timing == 2 && gr.compare)) hipEventRecord(get_event(b, ev++), st);
@@ -1206,6 +1214,8 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
   b.uploaded_streams = std::max(b.uploaded_streams, n);
   c->mask_uploaded_streams = std::max(c->mask_uploaded_streams, n);
   BatchPlan plan;
+  if (!rerun) b.cover_pass = c->cover_on;
+  plan.cover_pass = b.cover_pass;
   // on-device forward kinematics overwrites the link matrices (and camera) of the streams that use it
   for (HostModel& m : c->models) {
     Kinematics& k = m.kin;
@@ -1404,6 +1414,7 @@ static int retire_oldest(rtuf_context* c)
     c->stats.occluded_entries = k.occluded; c->stats.cover_tiles = k.cover_tiles; c->stats.exact_tiles = k.exact_tiles;
     c->stats.work_items = b.h_counters->work.n_items; c->stats.zero_survivor_items = k.zero_items;
     c->stats.raster_atomics = k.raster_atomics; c->stats.drawn_pixels = k.drawn_pixels;
+    c->stats.cover_pass = b.cover_pass ? 1u : 0u;
     const bool bin_over = k.max_bin_fill > c->capacity || k.max_fbin_fill > c->fcapacity;
     const bool clip_over = k.clip_overflow != 0;
     const bool big_over = k.max_big_fill > c->big_capacity;
@@ -1445,6 +1456,12 @@ static int retire_oldest(rtuf_context* c)
         c->stats.timed_batches = c->acc_batches;
         c->stats.sum_ms_pose = c->acc_ms[0]; c->stats.sum_ms_setup = c->acc_ms[1]; c->stats.sum_ms_raster = c->acc_ms[2];
         c->stats.sum_ms_compare = c->acc_ms[3]; c->stats.sum_ms_total = c->acc_ms[4]; c->stats.sum_ms_clip = c->acc_ms[5];
+      }
+      if (b.cover_pass) {
+        if (k.cover_tiles) c->cover_idle = 0;
+        else if (++c->cover_idle >= 3) { c->cover_on = false; c->cover_sleep = 64; c->cover_idle = 2; }      // (idle = 2: one empty probe sends it back to sleep)
+      } else if (--c->cover_sleep <= 0) {
+        c->cover_on = true;
       }
       b.active = false;
       c->oldest = (c->oldest + 1) % kMaxInflight;

@@ -323,11 +323,11 @@ void launch_cull(const SetupArgs& a, hipStream_t st);
 uint32_t launch_setup(const SetupArgs& a, uint32_t items_hint, bool sweep, hipStream_t st);    // returns the main grid size
 void launch_clip(const SetupArgs& a, hipStream_t st);
 size_t clip_spill_bytes(uint32_t clip_capacity);
-void launch_bigrec(const SetupArgs& a, hipStream_t st);
+void launch_bigrec(const SetupArgs& a, bool cover_pass, hipStream_t st);      // cover_pass: bigrec_kernel<0> runs first (and launch_tile gets the same flag)
 void launch_reset_clip(Counters* c, hipStream_t st);
 void launch_init_headers(BinHeader* hdr, size_t n_bins, hipStream_t st);
 void launch_publish_counters(const Counters* src, Counters* host_dst, hipStream_t st);
-void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st);   // a.io_u16 selects the 16UC1 variant
+void launch_tile(const TileArgs& a, bool two_kernel, bool cover_pass, hipStream_t st);   // a.io_u16 selects the 16UC1 variant
 void launch_compare(const CompareArgs& a, hipStream_t st);
 
 }  // namespace rtuf

@@ -1556,7 +1556,7 @@ __device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriR
 template <int MODE>
 __device__ __forceinline__ void raster_bin(unsigned long long* keys, const PackedTri* recs, uint32_t n,
                                            int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, uint32_t n_front, uint32_t capacity,
-                                           uint32_t* s_huge, TriRec* s_prec, uint4* s_pmeta, uint32_t zcover, const uint32_t* s_winners, uint32_t* s_zmax, int dbg_skip = 0)
+                                           uint32_t* s_huge, TriRec* s_prec, uint4* s_pmeta, uint32_t zcover, const uint32_t* s_winners, int dbg_skip = 0)
 {
   const int lane = tid & 63;
   const uint32_t zdrop = MODE == 1 ? min(zcover, 8388608u) : zcover;
@@ -1760,21 +1760,9 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     zfull = min(zfull, zf);
     unsigned long long m = __ballot(have && zmin24 <= zfull);
     const unsigned long long full = __ballot(have && meta.x == 2u);
-    int drawn = 0;                                     // pixels walked since the last look at the key tile (uniform)
     while (m) {
-#ifdef RTUF_EXP_NOSORT
       const int src = __ffsll((long long)m) - 1;
       m &= m - 1;
-#else
-      // nearest first (smallest depth in this tile): once the nearest one left lies behind everything drawn, so do all others
-      uint32_t sel = ((m >> lane) & 1ull) ? (min(zmin24, 0x00ffffffu) << 6) | (uint32_t)lane : 0xffffffffu;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) sel = min(sel, (uint32_t)__shfl_xor((int)sel, o));
-      sel = (uint32_t)__builtin_amdgcn_readfirstlane((int)sel);
-      if ((sel >> 6) > zfull) break;
-      const int src = (int)(sel & 63u);
-      m &= ~(1ull << src);
-#endif
       const bool inside = ((full >> src) & 1ull) != 0;
       TriRec q;                                        // the record from LDS into scalar registers (same address in every lane)
       {
@@ -1820,28 +1808,6 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
           raster_pair<MODE>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1);
         }
       }
-      // Occlusion by what has been drawn, whatever it took to cover the tile (the two triangles of a wall's face along
-      // their diagonal, a wall's border next to the robot): when about a tile's worth of pixels has been walked and more
-      // records wait, look at the key tile -- the largest depth any pixel of the frame holds now bounds every final key
-      // (keys only decrease), so records whose nearest depth here is larger are skipped by the test at the top of the loop.
-#ifndef RTUF_EXP_NORESCAN
-      if (MODE == 0) {
-        drawn += qw * (qy1 - qy0 + 1);
-        if (m && drawn >= kTileW * kTileH) {
-          drawn = kTileW * kTileH / 2;
-          if (tid == 0) *s_zmax = 0u;
-          __syncthreads();                             // the walks above have landed
-          uint32_t zm = 0;
-          for (int i = tid; i < kTileW * kTileH; i += kTileThreads)
-            if (x_base + i % kTileW < width && y_base + i / kTileW < height) zm = max(zm, (uint32_t)(keys[i] >> 32));
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) zm = max(zm, (uint32_t)__shfl_xor((int)zm, o));
-          if (lane == 0) atomicMax(s_zmax, zm);
-          __syncthreads();
-          zfull = min(zfull, *s_zmax);
-        }
-      }
-#endif
     }
     if (hb + 64 < nh) __syncthreads();               // (more than 64 parked: the next batch overwrites the LDS records)
   }
@@ -1920,13 +1886,14 @@ __device__ __forceinline__ float shade(float sensor, float z, const ShadeConsts&
   return filt ? k.replace_value : sensor;
 }
 
-template <bool TWO_KERNEL, bool U16, bool BITS>
+// COVER: the batch ran the cover pass (bigrec_kernel<0>), so a bin's header may name a cover.  Without it (the host skips the
+// pass while no scene has triangles that cover whole tiles) the cover code is compiled out: it costs the headline workload 3 %.
+template <bool TWO_KERNEL, bool U16, bool BITS, bool COVER>
 __device__ __forceinline__ void tile_body(const TileArgs& a)
 {
   __shared__ unsigned long long keys[kTileW * kTileH];
   __shared__ uint32_t s_huge[2 + kHugeMax];        // raster_bin's list of whole-tile triangles (+ count in front, area threshold behind)
   __shared__ uint32_t s_winners[kWinnerWords];     // exact-z pass: filter of the draw-order keys that won a pixel in need
-  __shared__ uint32_t s_zmax;                      // raster_bin's cooperative pass: largest depth in the key tile
   __shared__ TriRec s_prec[64];                    // ... a batch of them unpacked by the first wave for all four,
   __shared__ uint4 s_pmeta[64];                    //     with {class, smallest depth, largest depth if it covers the whole tile}
 
@@ -1938,13 +1905,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   const int stream = a.group_base + slot;
   const int x_base = txi * kTileW, y_base = tyi * kTileH;
 
-  const BgInfo bi = a.bg[stream];
-  const bool analytic_bg = bi.mode != 0;
-  const float bgz = bi.z, thr_bg = bi.thr;
-  const unsigned long long bgkey = analytic_bg ? ((unsigned long long)bi.z24 << 32) : kNoFragment;
-  ShadeConsts sc;
-  sc.num = a.sc_num; sc.off = a.sc_off; sc.max_diff = a.max_diff; sc.replace_value = a.replace_value;
-
   // the record bin's two fill counters and the tile's cover (the nearest triangle that covers this whole tile, if any:
   // bound of every key's depth, and its plane) in ONE 16-byte scalar load, the fragment bin's counter in a second one
   uint32_t count_front, count_back;
@@ -1952,10 +1912,18 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   {
     const uint4 h = *reinterpret_cast<const uint4*>(a.bin_hdr + bin);
     count_front = h.x; count_back = h.y;
-    cover = ((unsigned long long)h.w << 32) | h.z;
+    cover = COVER ? ((unsigned long long)h.w << 32) | h.z : kNoCover;
   }
   const uint32_t fcount = a.fbin_count[bin];
   const uint32_t count = count_front + count_back;
+  // (the stream's background entry after the bin's header in program order: the compiler then issues the three scalar loads
+  // together -- with the background first it waited for it before it even computed the header's address)
+  const BgInfo bi = a.bg[stream];
+  const bool analytic_bg = bi.mode != 0;
+  const float bgz = bi.z, thr_bg = bi.thr;
+  const unsigned long long bgkey = analytic_bg ? ((unsigned long long)bi.z24 << 32) : kNoFragment;
+  ShadeConsts sc;
+  sc.num = a.sc_num; sc.off = a.sc_off; sc.max_diff = a.max_diff; sc.replace_value = a.replace_value;
   const uint32_t zcover = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cover >> 32));      // (<= 0xffffff, or all ones: none)
   const uint32_t cover_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cover);
   const bool has_cover = zcover != 0xffffffffu;
@@ -2034,10 +2002,10 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       if (has_cover) atomicAdd(&sh.cover_tiles, 1u);
     }
 #ifdef RTUF_ABLATE
-    if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, &s_zmax, (int)((a.flags >> 12) & 3u));
+    if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, (int)((a.flags >> 12) & 3u));
     if (!(a.flags & 0x400u)) raster_frags(keys, frags, nf, tid, zcover);
 #else
-    raster_bin<0>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, &s_zmax);
+    raster_bin<0>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners);
     raster_frags(keys, frags, nf, tid, zcover);
 #endif
     __syncthreads();
@@ -2063,7 +2031,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
         }
       }
       __syncthreads();
-      raster_bin<1>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, &s_zmax);
+      raster_bin<1>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners);
       if (has_cover) {                       // ... and the cover triangle, which is in no bin
         const CoverPlane c = cover_plane();
         for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
@@ -2185,14 +2153,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
 #endif
 }
 
-// (fused variants: held at 6 waves/SIMD = 80 VGPRs; left alone the compiler takes 84 = 5 waves/SIMD)
-template <bool TWO_KERNEL, bool U16>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6))) void tile_kernel(TileArgs a) { tile_body<TWO_KERNEL, U16, false>(a); }
+// (held at 6 waves/SIMD = 80 VGPRs; left alone the compiler takes 84 = 5 waves/SIMD; the two-kernel variant spills 13
+// registers at 7 waves/SIMD = 72)
+template <bool TWO_KERNEL, bool U16, bool COVER>
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6))) void tile_kernel(TileArgs a) { tile_body<TWO_KERNEL, U16, false, COVER>(a); }
 // mask-only output, one bit per pixel (rtuf_filter_batch_bits*): 4 (2) B/pixel in, 1/8 B/pixel out
-template <bool U16>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6))) void tile_bits_kernel(TileArgs a) { tile_body<false, U16, true>(a); }
-template <>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6))) void tile_kernel<true, false>(TileArgs a) { tile_body<true, false, false>(a); }      // (at 7 waves/SIMD = 72 registers it spills 13 of them)
+template <bool U16, bool COVER>
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6))) void tile_bits_kernel(TileArgs a) { tile_body<false, U16, true, COVER>(a); }
 
 // ---------------------------------------------------------------------------------------
 // compare_kernel (two-kernel mode): streaming, 13 B/pixel (4 sensor + 4 z + 4 masked + 1 mask)
@@ -2347,21 +2314,27 @@ void launch_clip(const SetupArgs& a, hipStream_t st)
   hipLaunchKernelGGL(clip_kernel, dim3(kCounterShards * clip_wgs_per_shard(a.clip_capacity)), dim3(kClipBlock), 0, st, a);
 }
 size_t clip_spill_bytes(uint32_t clip_capacity) { return (size_t)(kClipMaxV - kClipLdsV) * kCounterShards * clip_wgs_per_shard(clip_capacity) * kClipBlock * sizeof(float4); }
-void launch_bigrec(const SetupArgs& a, hipStream_t st)
+void launch_bigrec(const SetupArgs& a, bool cover_pass, hipStream_t st)
 {
   // the list lengths live on the device: fixed grid, kBigWavesPerShard waves per shard, each strides over its shard's list
-  hipLaunchKernelGGL(bigrec_kernel<0>, dim3(kCounterShards * kBigWavesPerShard / 4), dim3(256), 0, st, a);
+  if (cover_pass) hipLaunchKernelGGL(bigrec_kernel<0>, dim3(kCounterShards * kBigWavesPerShard / 4), dim3(256), 0, st, a);
   hipLaunchKernelGGL(bigrec_kernel<1>, dim3(kCounterShards * kBigWavesPerShard / 4), dim3(256), 0, st, a);
 }
-void launch_tile(const TileArgs& a, bool two_kernel, hipStream_t st)
+template <bool COVER>
+static void launch_tile_variant(const TileArgs& a, bool two_kernel, hipStream_t st)
 {
   const dim3 grid(a.tiles_x, a.tiles_y, a.group_size);
   if (a.bits) {
-    if (a.io_u16) hipLaunchKernelGGL((tile_bits_kernel<true>), grid, dim3(kTileThreads), 0, st, a);
-    else hipLaunchKernelGGL((tile_bits_kernel<false>), grid, dim3(kTileThreads), 0, st, a);
-  } else if (two_kernel) hipLaunchKernelGGL((tile_kernel<true, false>), grid, dim3(kTileThreads), 0, st, a);
-  else if (a.io_u16) hipLaunchKernelGGL((tile_kernel<false, true>), grid, dim3(kTileThreads), 0, st, a);
-  else hipLaunchKernelGGL((tile_kernel<false, false>), grid, dim3(kTileThreads), 0, st, a);
+    if (a.io_u16) hipLaunchKernelGGL((tile_bits_kernel<true, COVER>), grid, dim3(kTileThreads), 0, st, a);
+    else hipLaunchKernelGGL((tile_bits_kernel<false, COVER>), grid, dim3(kTileThreads), 0, st, a);
+  } else if (two_kernel) hipLaunchKernelGGL((tile_kernel<true, false, COVER>), grid, dim3(kTileThreads), 0, st, a);
+  else if (a.io_u16) hipLaunchKernelGGL((tile_kernel<false, true, COVER>), grid, dim3(kTileThreads), 0, st, a);
+  else hipLaunchKernelGGL((tile_kernel<false, false, COVER>), grid, dim3(kTileThreads), 0, st, a);
+}
+void launch_tile(const TileArgs& a, bool two_kernel, bool cover_pass, hipStream_t st)
+{
+  if (cover_pass) launch_tile_variant<true>(a, two_kernel, st);
+  else launch_tile_variant<false>(a, two_kernel, st);
 }
 void launch_compare(const CompareArgs& a, hipStream_t st)
 {

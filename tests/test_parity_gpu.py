@@ -936,6 +936,46 @@ def test_whole_tile_cover_planes_near_and_far(size, mode):
     ctx.close()
 
 
+def test_cover_pass_switches_itself_off_and_on():
+    """The cover pass (bigrec_kernel<0> + the cover-aware tile kernel) is an optimisation the context switches by what the
+    batches show: a robot without any triangle that covers a whole tile runs three batches with it, then without (probing
+    every 64th batch); when walls come into the picture the next probe finds covers and it stays on.  Every batch -- with the
+    pass, without it, at the switches -- must be the oracle's."""
+    n, W, H = 2, 640, 360
+    wl = WL.pr2_workload(n, W, H, total_triangles=12000, walls=True)
+    ctx = R.Context(W, H, n, 0, params(wl.replace_value, wl.max_diff))
+    ids = wl.load_into(ctx)
+    wl.stage(ctx, ids)
+    depth = wl.depth_batch()
+    far = wl.link_tf[1].copy()
+    far[:, :, 14] += 100.0                      # the walls 100 m away along z: outside the frustum
+
+    def run(walls_tf):
+        ctx.set_link_poses_batch(0, ids[1], walls_tf)
+        masked, mask = ctx.filter_batch(depth)
+        st = ctx.stats()
+        for s in range(n):
+            draws = []
+            for mi, links in enumerate(wl.models):
+                tfm = wl.link_tf[0] if mi == 0 else walls_tf
+                for li, dl in enumerate(links):
+                    for d in dl:
+                        draws.append((tfm[s, li], d.pre_op, d.op, d.verts, d.tris))
+            om, ok = O.filter_frame(depth[s], wl.projection[s], draws, wl.offset_inv[s], wl.cam_tf[s], max_diff=wl.max_diff, replace_value=wl.replace_value)
+            assert (ok != mask[s]).sum() == 0 and bits_equal(om, masked[s]), (s, st["cover_pass"])
+        return st
+
+    passes = [run(far)["cover_pass"] for _ in range(6)]
+    assert passes == [1, 1, 1, 0, 0, 0], passes                     # three idle batches, then off
+    seen = []
+    for k in range(70):                                             # walls in view: used from the next probe on
+        st = run(wl.link_tf[1])
+        seen.append((st["cover_pass"], st["cover_tiles"] > 0))
+    first_on = [i for i, (p, _) in enumerate(seen) if p][0]
+    assert 50 <= first_on <= 64 and all(p and c for p, c in seen[first_on:]), (first_on, seen[first_on:first_on + 4])
+    ctx.close()
+
+
 def test_config_c4_720p_pr2_plus_walls():
     """BASELINE config 4 shape: 1280x720, PR2-like robot + two static wall URDFs (full-screen boxes incl.
     quirk Q1: exercises the large-triangle path), several streams."""
