@@ -1484,8 +1484,9 @@ static int retire_oldest(rtuf_context* c)
       c->clip_capacity = larger;
     }
     if (big_over) {
+      // (half as much again as this run asked for: poses move, and a list that just fits overflows on the next batch)
       uint32_t larger = c->big_capacity;
-      while (larger < k.max_big_fill) larger *= 2;
+      while (larger < k.max_big_fill + k.max_big_fill / 2) larger *= 2;
       const int rc = regrow(c, c->d_big_list, (size_t)larger * kCounterShards * sizeof(BigRec), "many-tile list");
       if (rc != RTUF_OK) return give_up(rc);
       c->big_capacity = larger;

@@ -588,11 +588,10 @@ constexpr int kCoopTiles = 4;            // (8: the same; 2: +20 us of bigrec_ke
 #define RTUF_FRONT_AREA 24
 #endif
 constexpr int kFrontArea = RTUF_FRONT_AREA;      // boxes up to this many pixel centres are binned from the front of a bin
-__device__ __forceinline__ void list_big_records_wave(const SetupArgs& a, int slot, bool big, const PackedTri& pk)
+__device__ __forceinline__ void list_big_records_wave(const SetupArgs& a, int shard_id, int slot, bool big, const PackedTri& pk)
 {
   const int lane = threadIdx.x & 63;
   const unsigned long long bm = __ballot(big);
-  const int shard_id = (int)(blockIdx.x % kCounterShards);
   const int leader = __ffsll((long long)bm) - 1;
   uint32_t base = 0;
   if (lane == leader) base = atomicAdd(&a.counters->shard[shard_id].big_count, (uint32_t)__popcll(bm));
@@ -612,7 +611,7 @@ __device__ __forceinline__ void list_big_records_wave(const SetupArgs& a, int sl
 // atomicAdd in the SAME instruction, so a wave pays one atomic round trip per tile index
 // instead of one per distinct bin; group members get consecutive slots, which makes the
 // 32-byte record stores of neighbouring mesh triangles contiguous.
-__device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slot, bool have, uint32_t bbx, uint32_t bby, const PackedTri& pk)
+__device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int shard_id, int slot, bool have, uint32_t bbx, uint32_t bby, const PackedTri& pk)
 {
   const int lane = threadIdx.x & 63;
   int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
@@ -627,7 +626,7 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int slo
   // lane-per-triangle walk runs as long as the largest box in the wave).
   const int cls = ((int)(bbx >> 16) - (int)(bbx & 0xffff) + 1) * ((int)(bby >> 16) - (int)(bby & 0xffff) + 1) > kFrontArea ? 1 : 0;
   const bool big = have && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kCoopTiles;
-  if (__ballot(big)) list_big_records_wave(a, slot, big, pk);          // (their bin entries are counted by bigrec_kernel)
+  if (__ballot(big)) list_big_records_wave(a, shard_id, slot, big, pk);          // (their bin entries are counted by bigrec_kernel)
   have = have && !big;
   int tx = tx0, ty = ty0;                  // walks the touched tiles row by row
   for (;;) {
@@ -925,6 +924,10 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
   // the item carries the chunk's ranges, so the geometry loads depend on it alone
   struct { uint32_t tri_begin, vert_begin, draw, tri_count, vert_count; } ch;
   uint32_t slots01, slots23;
+  // The shard whose clip list and many-tile list take this item's triangles comes from the item's CONTENT, not from the
+  // workgroup that happens to run it: the cull kernel lists the items in the order its atomics land, so a shard chosen by
+  // workgroup index filled differently on every run of the same batch (and a list sized to one run overflowed on the next).
+  int list_shard;
   {
     const uint4* src = reinterpret_cast<const uint4*>(&a.items[item_id]);
     uint4 w0 = src[0], w1 = src[1];
@@ -934,10 +937,12 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
     w0.z = __builtin_amdgcn_readfirstlane(w0.z); w0.w = __builtin_amdgcn_readfirstlane(w0.w);
     w1.x = __builtin_amdgcn_readfirstlane(w1.x); w1.y = __builtin_amdgcn_readfirstlane(w1.y);
     w1.z = __builtin_amdgcn_readfirstlane(w1.z); w1.w = __builtin_amdgcn_readfirstlane(w1.w);
-    ch.tri_begin = w0.y; ch.vert_begin = w0.z;          // (w0.x: chunk id, not needed here)
+    ch.tri_begin = w0.y; ch.vert_begin = w0.z;
     ch.draw = w1.x; ch.tri_count = w1.y & 0xffffu; ch.vert_count = w1.y >> 16;
     slots01 = w1.z; slots23 = w1.w;
+    list_shard = (int)((w0.x + (w1.z & 0xffffu)) % (uint32_t)kCounterShards);      // chunk id + first stream slot
   }
+  CounterShard& lshard = a.counters->shard[list_shard];
   auto item_slot = [&](int k) { return (int)(((k < 2 ? slots01 : slots23) >> (16 * (k & 1))) & 0xffffu); };
 
   float4 pv = make_float4(0, 0, 0, 1);
@@ -1010,16 +1015,16 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
     if (cmk) {
       const int leader = __ffsll((long long)cmk) - 1;
       uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(&shard.clip_count, (uint32_t)__popcll(cmk));
+      if (lane == leader) base = atomicAdd(&lshard.clip_count, (uint32_t)__popcll(cmk));
       base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
       if (needs_clip) {
         const uint32_t kk = base + (uint32_t)__popcll(cmk & ((1ull << lane) - 1ull));
         if (kk < a.clip_capacity) {
-          uint4* dst = reinterpret_cast<uint4*>(&a.clip_list[(size_t)shard_id * a.clip_capacity + kk]);
+          uint4* dst = reinterpret_cast<uint4*>(&a.clip_list[(size_t)list_shard * a.clip_capacity + kk]);
           dst[0] = make_uint4((uint32_t)slot, ch.draw, ch.vert_begin, packed);
           dst[1] = make_uint4(a.corder[ch.tri_begin + tid], 0u, 0u, 0u);
         } else {
-          shard.clip_overflow = 1u;
+          lshard.clip_overflow = 1u;
         }
       }
     }
@@ -1136,7 +1141,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
       }
     }
     if (__ballot(have) && !RTUF_ABL(a.flags, 0x20000u)) {
-      entries += emit_record_wave(a, slot, have, bbx, bby, pk);
+      entries += emit_record_wave(a, list_shard, slot, have, bbx, bby, pk);
       binned += have ? 1u : 0u;
     }
   }
@@ -1293,7 +1298,7 @@ __device__ __forceinline__ void clip_one(const SetupArgs& a, const ClipItem it, 
       wprev = wi;
     }
     binned += have ? 1u : 0u;
-    if (__ballot(have) && !RTUF_ABL(a.flags, 0x800000u)) entries += emit_record_wave(a, slot, have, r.bbx, r.bby, pk);      // (0x800000: timing experiment)
+    if (__ballot(have) && !RTUF_ABL(a.flags, 0x800000u)) entries += emit_record_wave(a, shard_id, slot, have, r.bbx, r.bby, pk);      // (0x800000: timing experiment)
   }
   // statistics: one atomic pair per wave (per-lane atomics on a shard's counters serialise at one L2
   // atomic unit -- that alone used to be three quarters of this kernel's time)

@@ -39,7 +39,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
         for k in range(3):
             masked, mask = ctx.filter_batch(depth[None])
             st = ctx.stats()
-            cur = {x: st.get(x) for x in keys}
+            cur = dict(st)
             if prev is not None and cur["regrowths"] != prev["regrowths"]:
                 print("iteration", it, "case", name, "batch", k, "\n   before", prev, "\n   after ", cur, flush=True)
             prev = cur

@@ -4,7 +4,8 @@
 #   usage (GPU box): scripts/overdraw.sh > profiles/overdraw.json
 here="$(cd "$(dirname "$0")/.." && pwd)"
 lib=$here/realtime_urdf_filter_amd/lib/variants/librtuf_count.so
-if [ ! -f $lib ]; then
+src=$here/realtime_urdf_filter_amd/csrc
+if [ ! -f $lib ] || [ $src/rtuf_kernels.hip -nt $lib ] || [ $src/rtuf_api.cpp -nt $lib ] || [ $src/rtuf_device.h -nt $lib ] || [ $here/include/rtuf.h -nt $lib ]; then
   (cd $here/realtime_urdf_filter_amd/csrc && mkdir -p ../lib/variants && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -I../../include -I. \
      -Wno-unused-value -Wno-unused-result -DRTUF_COUNT rtuf_kernels.hip rtuf_api.cpp -o $lib) || exit 1
 fi

@@ -4,7 +4,7 @@
 #   bench.py reads: pmc_counters.json, valu_peak.json; llvmpipe_baseline.json comes from the development container)
 # rocprofv3 passes are separate runs: --kernel-trace --stats, then one --pmc pass per counter group (never together
 # with other trace domains).
-tag=${1:-r02}
+tag=${1:-r03}
 export TMPDIR=/tmp
 root=$PWD
 out=$root/gpurun_out/profiles
@@ -26,6 +26,10 @@ $B --cpu-seconds 0 --host-poses > $out/${tag}_bench_host_poses.json 2>> $out/ben
 $B --cpu-seconds 0 --pipelines 2 > $out/${tag}_bench_pipelines2.json 2>> $out/bench.err
 $B --cpu-seconds 0 --workload c4 --shard-of 8 --steps 50 > $out/${tag}_bench_c4_share.json 2>> $out/bench.err
 $B --cpu-seconds 0 --workload c5 --shard-of 8 --steps 30 > $out/${tag}_bench_c5_share.json 2>> $out/bench.err
+$B --cpu-seconds 0 --near-arm --steps 40 > $out/${tag}_bench_near_arm.json 2>> $out/bench.err      # every stream: forearm 0.1-0.35 m in front of the lens
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29561 $root/bench.py --gpus 1 --cpu-seconds 0 > $out/${tag}_bench_rccl_world1.json 2>> $out/bench.err
+python $root/scripts/clip_stress.py > $out/${tag}_clip_stress.txt 2>> $out/bench.err
+bash $root/scripts/overdraw.sh > $out/overdraw.json 2>> $out/bench.err
 python $root/scripts/host_planes_rate.py > $out/${tag}_host_planes.json 2>> $out/bench.err
 
 # ---- 2. kernel traces -------------------------------------------------------------------------------------------
@@ -38,6 +42,7 @@ trace "" ""
 trace "_two_kernel" "--two-kernel"
 trace "_two_kernel_1024" "--two-kernel --streams 1024 --steps 30"
 trace "_c4_share" "--workload c4 --shard-of 8 --steps 50"
+trace "_near_arm" "--near-arm --steps 40"
 
 # ---- 3. counters (one pass per group) ---------------------------------------------------------------------------
 pmc() {     # output file, bench args, counters...
@@ -79,7 +84,7 @@ cd $root
 python scripts/pmc_to_json.py $out $tag > $out/pmc_to_json.log 2>&1
 python scripts/valu_mix.py $out/valu_peak.json > $out/valu_mix.log 2>&1 || true
 (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5) > $out/${tag}_gpu_tests.txt
-{ python scripts/fuzz_parity.py 10000 $((20260928 + RANDOM)) 2>&1 | tail -2; python scripts/fuzz_features.py 6000 $((20270000 + RANDOM)) 2>&1 | tail -2; FUZZ_BIG=1 python scripts/fuzz_parity.py 150 $((333 + RANDOM)) 2>&1 | tail -2; } > $out/${tag}_fuzz.txt
+{ python scripts/fuzz_parity.py 6000 $((20260928 + RANDOM)) 2>&1 | tail -2; python scripts/fuzz_features.py 3000 $((20270000 + RANDOM)) 2>&1 | tail -2; FUZZ_BIG=1 python scripts/fuzz_parity.py 150 $((333 + RANDOM)) 2>&1 | tail -2; } > $out/${tag}_fuzz.txt
 ls -la $out; cat $out/pmc_to_json.log; tail -c 400 $out/bench.err
 for f in $out/${tag}_bench*.json; do python - $f <<'PY'
 import json, sys
