@@ -27,7 +27,7 @@ $B --cpu-seconds 0 --pipelines 2 > $out/${tag}_bench_pipelines2.json 2>> $out/be
 $B --cpu-seconds 0 --workload c4 --shard-of 8 --steps 50 > $out/${tag}_bench_c4_share.json 2>> $out/bench.err
 $B --cpu-seconds 0 --workload c5 --shard-of 8 --steps 30 > $out/${tag}_bench_c5_share.json 2>> $out/bench.err
 $B --cpu-seconds 0 --near-arm --steps 40 > $out/${tag}_bench_near_arm.json 2>> $out/bench.err      # every stream: forearm 0.1-0.35 m in front of the lens
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29561 $root/bench.py --gpus 1 --cpu-seconds 0 > $out/${tag}_bench_rccl_world1.json 2>> $out/bench.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29561 $root/bench.py --gpus 1 --cpu-seconds 0 2>> $out/bench.err | grep '^{' | tail -1 > $out/${tag}_bench_rccl_world1.json      # (RCCL prints its banner on stdout)
 python $root/scripts/clip_stress.py > $out/${tag}_clip_stress.txt 2>> $out/bench.err
 bash $root/scripts/overdraw.sh > $out/overdraw.json 2>> $out/bench.err
 python $root/scripts/host_planes_rate.py > $out/${tag}_host_planes.json 2>> $out/bench.err
