@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--triangles", type=int, default=250000, help="triangle budget of the PR2-like model")
     ap.add_argument("--variants", type=int, default=2, help="distinct input batches rotated through the steps")
     ap.add_argument("--pipelines", type=int, default=1, help="contexts (HIP stream + bins each) per GPU that the batches alternate between: with 2 or 3, one batch's small and low-occupancy kernels overlap another's heavy ones, but kernels then share the GPU and per-launch times (roofline) no longer describe one kernel; default 1")
+    ap.add_argument("--launch-group", type=int, default=0, help="rtuf_params.max_inflight_streams: streams rasterised per internal launch group (0 = automatic: the whole batch up to 1024); smaller groups shrink the tile bins and cost a kernel sequence per group")
     ap.add_argument("--overlap-pipelines", type=int, default=2, help="after the main measurement (one pipeline, clean per-kernel roofline) time the same steps once more on a second context with rtuf_params.pipelines = this, reported as `overlapped` (N=1 only; 0 disables)")
     ap.add_argument("--two-kernel", action="store_true", help="rasteriser + separate compare kernel")
     ap.add_argument("--host-poses", action="store_true", help="stage explicit link matrices from the host instead of joint positions + on-device forward kinematics")
@@ -131,6 +132,7 @@ def main():
         p.flags |= R.FLAG_TWO_KERNEL
     p.flags |= args.debug_flags
     p.bin_capacity = args.bin_capacity
+    p.max_inflight_streams = args.launch_group
     P = max(1, args.pipelines)
     p.pipelines = P if P > 1 else 0          # rtuf_params.pipelines: the library alternates the batches between P internal pipelines
     ctx = R.Context(W, H, n, local_rank, p)
