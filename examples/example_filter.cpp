@@ -65,11 +65,14 @@ int main(int argc, char** argv)
     for (float f : v) { uint32_t u; std::memcpy(&u, &f, 4); std::printf("%08x\n", u); }
     return 0;
   }
-  if (argc != 12) { std::fprintf(stderr, "usage: %s urdf depth.f32 W H fx fy cx cy replace out_masked out_mask\n", argv[0]); return 2; }
+  // (a 12th argument "into16": the same frame once more through filter_into -- what the ROS adapter's callback uses -- as
+  //  16UC1 with the caller's output planes, and mask-only through the bit-packed path; depth file then holds uint16 millimetres)
+  const bool into16 = argc == 13 && std::string(argv[12]) == "into16";
+  if (argc != 12 && !into16) { std::fprintf(stderr, "usage: %s urdf depth.f32 W H fx fy cx cy replace out_masked out_mask [into16]\n", argv[0]); return 2; }
   const std::string xml = slurp(argv[1]);
   const int W = std::atoi(argv[3]), H = std::atoi(argv[4]);
   std::string depth_bytes = slurp(argv[2]);
-  if (depth_bytes.size() != (size_t)W * H * 4) { std::fprintf(stderr, "depth file has the wrong size\n"); return 2; }
+  if (depth_bytes.size() != (size_t)W * H * (into16 ? 2 : 4)) { std::fprintf(stderr, "depth file has the wrong size\n"); return 2; }
 
   // TF: fixed frame /world, links under the tf_prefix, camera optical frame at the world origin
   rtuf_host::StaticTransformProvider tf;
@@ -98,6 +101,17 @@ int main(int argc, char** argv)
     info.P[0] = std::atof(argv[5]); info.P[5] = std::atof(argv[6]); info.P[2] = std::atof(argv[7]); info.P[6] = std::atof(argv[8]); info.P[10] = 1;
     double P[16];
     filter.getProjectionMatrix(info, P);
+    if (into16) {
+      std::vector<uint16_t> masked16((size_t)W * H);
+      std::vector<uint8_t> mask((size_t)W * H), mask_only((size_t)W * H);
+      const bool a = filter.filter_into(depth_bytes.data(), true, P, W, H, 0.0, masked16.data(), mask.data());
+      const bool b = filter.filter_into(depth_bytes.data(), true, P, W, H, 0.0, nullptr, mask_only.data());      // mask bits over the bus
+      if (!a || !b) { std::fprintf(stderr, "no output\n"); return 1; }
+      std::ofstream(argv[10], std::ios::binary).write(reinterpret_cast<const char*>(masked16.data()), (std::streamsize)W * H * 2);
+      std::ofstream(argv[11], std::ios::binary).write(reinterpret_cast<const char*>(mask.data()), (std::streamsize)W * H);
+      std::printf("filter_into: mask-only path %s the full path's mask\n", mask == mask_only ? "equals" : "DIFFERS FROM");
+      return mask == mask_only ? 0 : 1;
+    }
     filter.filter(reinterpret_cast<unsigned char*>(&depth_bytes[0]), P, W, H);
     const float* masked = filter.getMaskedDepth();
     if (!masked || !filter.mask_) { std::fprintf(stderr, "no output\n"); return 1; }

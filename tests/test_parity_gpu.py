@@ -394,6 +394,30 @@ def test_cpp_facade_example_matches_reference(tmp_path):
     fx.check(masked, mask)
 
 
+def test_cpp_facade_filter_into_16uc1_and_mask_only(tmp_path):
+    """RealtimeURDFFilter::filter_into (what the ROS adapter's callback calls): 16UC1 in, masked 16UC1 + byte mask written into
+    the caller's planes, and mask-only through the bit-packed path -- against the oracle on the frame the millimetre values
+    stand for, with the reference's convertTo roundings on the way in and out (src/urdf_filter.cpp:287-288, :309-312)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "bin", "example_filter")
+    if not os.path.exists(exe):
+        subprocess.check_call([os.path.join(root, "realtime_urdf_filter_amd", "csrc", "build_facade.sh")])
+    fx = golden_io.Fixture("example_urdf_640x480")
+    mm = depth_f32_to_u16(np.nan_to_num(fx.depth, nan=0.0, posinf=0.0))
+    (tmp_path / "m.urdf").write_text(WL.EXAMPLE_URDF)
+    mm.tofile(tmp_path / "d.u16")
+    r = subprocess.run([exe, str(tmp_path / "m.urdf"), str(tmp_path / "d.u16"), "640", "480", "525", "525", "319.5", "239.5", "5.0",
+                        str(tmp_path / "o.u16"), str(tmp_path / "o.u8"), "into16"], capture_output=True, text=True)
+    assert r.returncode == 0 and "equals" in r.stdout, (r.stdout, r.stderr)
+    masked16 = np.fromfile(tmp_path / "o.u16", np.uint16).reshape(480, 640)
+    mask = np.fromfile(tmp_path / "o.u8", np.uint8).reshape(480, 640)
+    om, ok = O.filter_frame(depth_u16_to_f32(mm), fx.projection, fx.draws, fx.offset_inv, fx.cam_tf, max_diff=0.05, replace_value=5.0)
+    assert np.array_equal(mask, ok) and np.array_equal(masked16, depth_f32_to_u16(om))
+    assert mask.any() and masked16[ok > 0].min() == 5000 and masked16[ok > 0].max() == 5000
+
+
 def test_on_device_forward_kinematics():
     """Joint positions in, link matrices + head-camera transform computed on the GPU: the matrices agree
     with the host-side forward kinematics to 1e-12 and the filter output is what the oracle computes
