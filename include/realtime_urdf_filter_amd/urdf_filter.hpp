@@ -160,6 +160,11 @@ struct FilterParameters {
   bool show_gui = false;                             // accepted, ignored (no window system)
   double filter_replace_value = 0.0;
   std::vector<ModelParameter> models;
+  // The reference's compile-time switch USE_OWN_CALIBRATION (src/urdf_filter.cpp:38, :462-472) as a run-time parameter: with
+  // it, getProjectionMatrix ignores the CameraInfo's P (only width and height are used) and takes these intrinsics instead
+  // -- the reference's hard-coded Kinect values by default -- and leaves camera_tx_ / camera_ty_ alone, as the #ifdef does.
+  bool use_own_calibration = false;
+  double own_calibration[4] = {585.260, 585.028, 317.387, 239.264};      // fx fy cx cy
 };
 
 // ---- urdf_filter.h --------------------------------------------------------------------------
@@ -234,6 +239,12 @@ class RealtimeURDFFilter {
   // compute Projection matrix from CameraInfo message (src/urdf_filter.cpp:459-501)
   void getProjectionMatrix(const CameraInfo& info, double* glTf)
   {
+    if (params_.use_own_calibration) {          // (P[3] = P[7] = 0 into a scratch pair: the members keep their values)
+      const double* k = params_.own_calibration;
+      double tx = 0, ty = 0;
+      rtuf_projection_from_intrinsics((float)k[0], (float)k[1], (float)k[2], (float)k[3], 0.0, 0.0, info.width, info.height, near_plane_, far_plane_, glTf, &tx, &ty);
+      return;
+    }
     rtuf_projection_from_intrinsics(info.P[0], info.P[5], info.P[2], info.P[6], info.P[3], info.P[7], info.width, info.height, near_plane_, far_plane_, glTf,
                                     &camera_tx_, &camera_ty_);
   }

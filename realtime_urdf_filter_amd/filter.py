@@ -163,7 +163,8 @@ class FilterParameters:
 
     def __init__(self, fixed_frame, camera_frame, models, depth_distance_threshold,
                  camera_offset_translation=(0.0, 0.0, 0.0), camera_offset_rotation=(0.0, 0.0, 0.0, 1.0),
-                 show_gui=False, filter_replace_value=0.0):
+                 show_gui=False, filter_replace_value=0.0, use_own_calibration=False,
+                 own_calibration=(585.260, 585.028, 317.387, 239.264)):
         self.fixed_frame = fixed_frame
         self.camera_frame = camera_frame
         self.models = models                 # list of dicts: model, tf_prefix, geometry_type, [scale], [ignore]
@@ -172,13 +173,18 @@ class FilterParameters:
         self.camera_offset_rotation = tuple(camera_offset_rotation)     # x y z w
         self.show_gui = bool(show_gui)       # accepted and ignored: there is no window system here
         self.filter_replace_value = float(filter_replace_value)
+        # the reference's compile-time USE_OWN_CALIBRATION (src/urdf_filter.cpp:38, :462-472) as a parameter: fx fy cx cy used
+        # instead of the CameraInfo's P (the reference's hard-coded values by default; they pass through float there)
+        self.use_own_calibration = bool(use_own_calibration)
+        self.own_calibration = tuple(float(np.float32(v)) for v in own_calibration)
 
     @staticmethod
     def from_dict(d):
         off = d.get("camera_offset", {})
         return FilterParameters(d["fixed_frame"], d["camera_frame"], d.get("models", []), d["depth_distance_threshold"],
                                 off.get("translation", (0.0, 0.0, 0.0)), off.get("rotation", (0.0, 0.0, 0.0, 1.0)),
-                                d.get("show_gui", False), d.get("filter_replace_value", 0.0))
+                                d.get("show_gui", False), d.get("filter_replace_value", 0.0),
+                                d.get("use_own_calibration", False), d.get("own_calibration", (585.260, 585.028, 317.387, 239.264)))
 
 
 class RealtimeURDFFilter:
@@ -265,6 +271,10 @@ class RealtimeURDFFilter:
     # ---- camera --------------------------------------------------------------------------
     def getProjectionMatrix(self, info):
         """src/urdf_filter.cpp:459-501; sets camera_tx_/camera_ty_ as a side effect."""
+        if self.params.use_own_calibration:      # the #ifdef branch: own intrinsics, camera_tx_ / camera_ty_ untouched
+            fx, fy, cx, cy = self.params.own_calibration
+            P, _, _ = _capi.projection_from_intrinsics(fx, fy, cx, cy, info.width, info.height, self.near_plane_, self.far_plane_, 0.0, 0.0)
+            return P
         P, tx, ty = _capi.projection_from_intrinsics(info.P[0], info.P[5], info.P[2], info.P[6], info.width, info.height,
                                                      self.near_plane_, self.far_plane_, info.P[3], info.P[7])
         self.camera_tx_, self.camera_ty_ = tx, ty

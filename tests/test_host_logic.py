@@ -482,3 +482,25 @@ def test_cpp_facade_resolves_package_uris_by_default(tmp_path):
     env = dict(os.environ, ROS_PACKAGE_PATH="/nonexistent:" + str(tmp_path / "ws"))
     out = subprocess.check_output([exe, "--parse", str(f)], env=env, stderr=subprocess.DEVNULL).decode().strip()
     assert out.startswith("renderables=3 draws=2 triangles=%d " % (3 + 4)), out
+
+
+def test_use_own_calibration_switch():
+    """The reference's compile-time USE_OWN_CALIBRATION (src/urdf_filter.cpp:38, :462-472) as a run-time parameter of the host
+    mirror: the CameraInfo's P is ignored (width / height still count), the hard-coded intrinsics -- floats in the reference --
+    are used, and camera_tx_ / camera_ty_ keep their values (the #ifdef skips their assignment)."""
+    from realtime_urdf_filter_amd.filter import CameraInfo, FilterParameters, RealtimeURDFFilter
+    import realtime_urdf_filter_amd as R
+    info = CameraInfo(640, 480, [525.0, 0, 319.5, -39.4, 0, 526.0, 239.5, 2.0, 0, 0, 1, 0])
+    f = RealtimeURDFFilter(FilterParameters("/world", "/cam", [], 0.05), None)
+    P = np.asarray(f.getProjectionMatrix(info))
+    assert f.camera_tx_ == 39.4 / 525.0 and f.camera_ty_ == -2.0 / 526.0
+    own = RealtimeURDFFilter(FilterParameters("/world", "/cam", [], 0.05, use_own_calibration=True), None)
+    own.camera_tx_ = 0.25
+    Q = np.asarray(own.getProjectionMatrix(info))
+    fx, fy, cx, cy = (float(np.float32(v)) for v in (585.260, 585.028, 317.387, 239.264))
+    want, _, _ = R.projection_from_intrinsics(fx, fy, cx, cy, 640, 480, 0.1, 8.0)
+    assert np.array_equal(Q, np.asarray(want)) and not np.array_equal(Q, P) and own.camera_tx_ == 0.25 and own.camera_ty_ == 0.0
+    assert Q[0] == -2.0 * fx / 640 and Q[5] == 2.0 * fy / 480
+    d = FilterParameters.from_dict({"fixed_frame": "/w", "camera_frame": "/c", "depth_distance_threshold": 0.1, "use_own_calibration": True,
+                                    "own_calibration": [500.0, 501.0, 320.0, 240.0]})
+    assert d.use_own_calibration and d.own_calibration == (500.0, 501.0, 320.0, 240.0)
