@@ -324,7 +324,7 @@ def main():
         peak = 8000.0
         # Off-line counter data of this same command (rocprofv3 --pmc passes cannot run inside the timed region):
         # used only when the committed measurement is of this exact workload, and labelled as such.
-        default_cmd = (args.workload == "c3" and n == 256 and (W, H) == (640, 480) and not args.no_mask and not args.u16 and args.triangles == 250000)
+        default_cmd = (args.workload == "c3" and n == 256 and (W, H) == (640, 480) and not args.no_mask and not args.u16 and args.triangles == 250000 and not args.near_arm and not args.host_poses)
         pmc = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters.json")))
