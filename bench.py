@@ -325,6 +325,9 @@ def main():
         # Off-line counter data of this same command (rocprofv3 --pmc passes cannot run inside the timed region):
         # used only when the committed measurement is of this exact workload, and labelled as such.
         default_cmd = (args.workload == "c3" and n == 256 and (W, H) == (640, 480) and not args.no_mask and not args.u16 and args.triangles == 250000 and not args.near_arm and not args.host_poses)
+        # (config 4's per-GPU share -- the other workload whose counters are committed, profiles/r03_pmc_workload_c4_shard_of_8.txt)
+        c4_share_cmd = (args.workload == "c4" and args.shard_of == 8 and n == 64 and (W, H) == (1280, 720) and not args.no_mask and not args.u16
+                        and args.triangles == 250000 and not args.near_arm and not args.host_poses and not args.two_kernel)
         pmc = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters.json")))
@@ -346,9 +349,11 @@ def main():
             if name == "compare_kernel" and 4 * px * n < 2 * (256 << 20):
                 e["note"] = "HBM + MALL figure: the %d MB z-surface this kernel reads was written by the kernel before it and partly sits in the 256 MiB Infinity Cache; with --streams 1024 (z-surface 1.26 GB) the same kernel measures pure HBM" % (4 * px * n // 1000000)
             rec = (pmc or {}).get("kernels", {}).get(name) if (pmc and default_cmd and P == 1) else None
+            if rec is None and pmc and c4_share_cmd and P == 1:
+                rec = (pmc.get("c4_share") or {}).get("kernels", {}).get(name)
             if rec:
                 e["traffic"] = rec.get("hbm_bytes_per_launch")
-                e["traffic_source"] = "OFFLINE: " + pmc.get("source", "profiles/pmc_counters.json") + " (rocprofv3 --pmc passes of this same command; not measured in this run)"
+                e["traffic_source"] = "OFFLINE: " + (pmc.get("c4_share", {}).get("source") if (c4_share_cmd and not default_cmd) else pmc.get("source", "profiles/pmc_counters.json")) + " (rocprofv3 --pmc passes of this same command; not measured in this run)"
                 cnt = rec.get("wave64_valu_instructions_per_launch")
                 if cnt and dur_ms > 0:
                     g = cnt / (dur_ms * 1e-3) / 1e9

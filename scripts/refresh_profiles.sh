@@ -51,12 +51,13 @@ pmc() {     # output file, bench args, counters...
   { echo "## $*"; python $root/scripts/pmc_summary.py $(find /tmp/rp -name '*counter_collection.csv' | head -1); } >> $f
 }
 hdr="# rocprofv3 --kernel-trace --pmc <group> (one pass per '##' group), command: python bench.py $PROF_ARGS"
-for mode in "" "--two-kernel" "--two-kernel --streams 1024"; do
+for mode in "" "--two-kernel" "--two-kernel --streams 1024" "--workload c4 --shard-of 8"; do
   suffix=$(echo "$mode" | sed 's/--//g; s/ /_/g; s/-/_/g'); suffix=${suffix:+_$suffix}
   f=$out/${tag}_pmc${suffix}.txt
   echo "$hdr $mode   (values per launch, averaged over the launches of the run; FETCH_SIZE / WRITE_SIZE in KiB)" > $f
   pmc $f "$mode" FETCH_SIZE
   pmc $f "$mode" WRITE_SIZE
+  if [ "$mode" = "--workload c4 --shard-of 8" ]; then pmc $f "$mode" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES; fi
   if [ -z "$mode" ]; then
     pmc $f "$mode" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES
     pmc $f "$mode" SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES
