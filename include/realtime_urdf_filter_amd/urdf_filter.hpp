@@ -172,9 +172,9 @@ class RealtimeURDFFilter {
  public:
   RealtimeURDFFilter(const FilterParameters& params, const TransformProvider& tf,
                      std::map<std::string, std::string> param_server, int device = 0, MeshResolver resolve = nullptr, void* resolve_user = nullptr)
-      : tf_(tf), params_(params), param_server_(std::move(param_server)), device_(device), resolve_(resolve), resolve_user_(resolve_user),
-        fixed_frame_(params.fixed_frame), cam_frame_(params.camera_frame), show_gui_(params.show_gui),
-        depth_distance_threshold_(params.depth_distance_threshold), filter_replace_value_(params.filter_replace_value)
+      : tf_(tf), fixed_frame_(params.fixed_frame), cam_frame_(params.camera_frame), show_gui_(params.show_gui),
+        depth_distance_threshold_(params.depth_distance_threshold), filter_replace_value_(params.filter_replace_value),
+        params_(params), param_server_(std::move(param_server)), device_(device), resolve_(resolve), resolve_user_(resolve_user)
   {
   }
   ~RealtimeURDFFilter() { if (ctx_) rtuf_destroy(ctx_); }

@@ -1,5 +1,5 @@
 // ros_filter.hpp -- ROS 1 adapter: rosparams, TF and image_transport in front of the MI355X façade.
-// UNBUILT HERE (no ROS in either container); see ros/README.md.
+// Never built against ROS (none in either container); compiled against tests/ros_mock and the callback tested there, see ros/README.md.
 //
 // The contract it keeps, so that the reference's launch files and consumers keep working, is the interface only:
 //   private parameters  fixed_frame, camera_frame, camera_offset, depth_distance_threshold, show_gui, filter_replace_value,

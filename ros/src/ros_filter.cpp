@@ -1,4 +1,4 @@
-// Mesh URI resolution for the ROS adapter (UNBUILT HERE, see ros/README.md): resource_retriever does what the
+// Mesh URI resolution for the ROS adapter (never built against ROS; compiled against tests/ros_mock, see ros/README.md): resource_retriever does what the
 // reference's Assimp IOSystem wrapper does (src/renderable.cpp:173-304).
 #include "realtime_urdf_filter_amd_ros/ros_filter.hpp"
 

@@ -1,4 +1,4 @@
-// Stand-alone node (shape of the reference's src/realtime_urdf_filter.cpp:36-53).  UNBUILT HERE, see ros/README.md.
+// Stand-alone node (shape of the reference's src/realtime_urdf_filter.cpp:36-53).  Never built against ROS (compiles against tests/ros_mock), see ros/README.md.
 #include <ros/ros.h>
 
 #include "realtime_urdf_filter_amd_ros/ros_filter.hpp"

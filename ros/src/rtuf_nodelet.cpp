@@ -1,6 +1,6 @@
 // Nodelet (shape of the reference's src/realtime_urdf_filter_nodelet.cpp:35-75; same plugin class name, so
 // `nodelet load realtime_urdf_filter/RealtimeURDFFilterNodelet <manager>` keeps working).  No argv juggling: there
-// is no GLUT to initialise.  UNBUILT HERE, see ros/README.md.
+// is no GLUT to initialise.  Never built against ROS (compiles against tests/ros_mock), see ros/README.md.
 #include <nodelet/nodelet.h>
 #include <pluginlib/class_list_macros.h>
 
