@@ -65,6 +65,7 @@ int main(int argc, char** argv)
       tf::mock_transforms()[{t.first, s.first}] = st;
     }
 
+  if (const char* drop = std::getenv("RTUF_MOCK_DROP_PARAM")) P.erase(drop);       // (test of the required-parameter check)
   ros::NodeHandle nh("~");
   RosFilter filter(nh, argc, argv);
   auto& topics = image_transport::mock_topics();

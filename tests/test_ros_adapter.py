@@ -33,12 +33,12 @@ def test_adapter_sources_compile_against_the_mock(source):
     assert r.returncode == 0, r.stderr[-3000:]
 
 
-def run(tmp_path, depth, encoding, mode, pad=0):
+def run(tmp_path, depth, encoding, mode, pad=0, env=None):
     (tmp_path / "m.urdf").write_text(WL.EXAMPLE_URDF)
     depth.tofile(tmp_path / "d.bin")
     cmd = [harness(), str(tmp_path / "m.urdf"), str(tmp_path / "d.bin"), "640", "480", "525", "525", "319.5", "239.5", "5.0", encoding,
            str(tmp_path / "o.depth"), str(tmp_path / "o.mask"), mode] + ([str(pad)] if pad else [])
-    return subprocess.run(cmd, capture_output=True, text=True)
+    return subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **(env or {})))
 
 
 def test_nobody_listens_nothing_runs(tmp_path):
@@ -49,6 +49,13 @@ def test_nobody_listens_nothing_runs(tmp_path):
     r = run(tmp_path, np.nan_to_num(fx.depth, nan=0.0, posinf=0.0).astype(np.float32), "32FC1", "nobody")
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "published depth 0 mask 0" in r.stdout and "log " not in r.stdout
+
+
+def test_missing_required_parameter_is_reported(tmp_path):
+    """A required private parameter that is absent is reported (ROS_FATAL in the reference too, src/urdf_filter.cpp:63-75)."""
+    fx = golden_io.Fixture("example_urdf_640x480")
+    r = run(tmp_path, fx.depth.astype(np.float32), "32FC1", "nobody", env={"RTUF_MOCK_DROP_PARAM": "~camera_frame"})
+    assert "log FATAL: private parameter ~camera_frame is required" in r.stdout, (r.stdout, r.stderr)
 
 
 @pytest.mark.gpu
