@@ -67,14 +67,21 @@ class DeviceGroup {
         d_report_(devices.size(), nullptr)
   {
     if (devices.empty() || streams_per_device.size() != devices.size()) throw std::invalid_argument("device / stream lists differ in length");
+    try {
+      build(width, height, streams_per_device, params);
+    } catch (...) {
+      destroy();                                         // (a constructor that throws runs no destructor: nothing may stay behind)
+      throw;
+    }
+  }
+
+ private:
+  void build(int width, int height, const std::vector<int>& streams_per_device, const rtuf_params& params)
+  {
     for (size_t i = 0; i < devices_.size(); i++) {
       if (streams_per_device[i] <= 0) continue;          // (a device without a share keeps no context but still takes part in the collectives)
       const int rc = rtuf_create(&ctx_[i], devices_[i], width, height, streams_per_device[i], &params);
-      if (rc != RTUF_OK) {
-        const std::string msg = rtuf_last_error(nullptr);
-        destroy();
-        throw std::runtime_error("rtuf_create on device " + std::to_string(devices_[i]) + ": " + msg);
-      }
+      if (rc != RTUF_OK) throw std::runtime_error("rtuf_create on device " + std::to_string(devices_[i]) + ": " + rtuf_last_error(nullptr));
     }
     // single-process communicator set: one rank per device, in the order of `devices`
     check_nccl(ncclCommInitAll(comm_.data(), (int)devices_.size(), devices_.data()), "ncclCommInitAll");
@@ -84,6 +91,8 @@ class DeviceGroup {
       check_hip(hipMalloc(&d_report_[i], sizeof(double) * 3 * (1 + devices_.size())), "hipMalloc(report)");
     }
   }
+
+ public:
   DeviceGroup(const DeviceGroup&) = delete;
   DeviceGroup& operator=(const DeviceGroup&) = delete;
   ~DeviceGroup() { destroy(); }
@@ -116,10 +125,11 @@ class DeviceGroup {
   {
     const size_t n = devices_.size();
     if (mine.size() != n) throw std::invalid_argument("one report per device");
+    std::vector<double> up(3 * n);                       // (outlives the asynchronous uploads: synchronised below)
     for (size_t i = 0; i < n; i++) {
       check_hip(hipSetDevice(devices_[i]), "hipSetDevice");
-      const double v[3] = {mine[i].frames, mine[i].seconds, mine[i].mismatches};
-      check_hip(hipMemcpyAsync(d_report_[i], v, sizeof v, hipMemcpyHostToDevice, stream_[i]), "report upload");
+      up[3 * i] = mine[i].frames; up[3 * i + 1] = mine[i].seconds; up[3 * i + 2] = mine[i].mismatches;
+      check_hip(hipMemcpyAsync(d_report_[i], &up[3 * i], sizeof(double) * 3, hipMemcpyHostToDevice, stream_[i]), "report upload");
     }
     check_nccl(ncclGroupStart(), "ncclGroupStart");
     for (size_t i = 0; i < n; i++)
@@ -145,7 +155,8 @@ class DeviceGroup {
   // All-gather of the bit-packed masks (rtuf_filter_batch_device_bits output): device i holds `streams[i]` frames of
   // `words` 32-bit words at d_bits[i]; afterwards d_all[i] on EVERY device holds all frames, device 0's first.
   // direct = true : every device writes its slice into each peer's buffer (hipMemcpyPeerAsync: point to point over xGMI)
-  // direct = false: ncclAllGather; RCCL needs equal contributions, so slices are padded to the largest share and d_all
+  // direct = false: ncclAllGather; RCCL needs equal contributions: EVERY d_bits[i] must be readable for max(streams) frames
+  //                 (a device with a smaller share hands in a padded copy, as examples/multi_gpu_filter.cpp does) and d_all
   //                 must hold size() * max(streams) frames (slice i starts at i * max(streams) frames)
   void all_gather_mask_bits(const std::vector<const uint32_t*>& d_bits, const std::vector<int>& streams, size_t words,
                             const std::vector<uint32_t*>& d_all, bool direct)
