@@ -19,7 +19,15 @@ streams with no data-path collective; RCCL carries the barriers around the timed
 elapsed time and the tiny end-of-run gather of per-rank frame and parity counts.
 
 Timed region: exactly `--steps` steps, repeated back to back until at least `--min-seconds` have passed (repetitions
-are whole multiples of `--steps`; `timed_steps` in the output says how many steps were timed in total).
+are whole multiples of `--steps`; `timed_steps` in the output says how many steps were timed in total).  The default, 6 s,
+is long enough for an outside sampler (amd-smi every 5 s) to land inside it.
+
+`value` comes from ONE default-configured context: two raster lanes, a batch split into four launch groups whose kernels
+overlap (rtuf_params.raster_lanes).  Overlapping kernels share the GPU, so their per-launch times describe no single
+kernel; the `roofline` object is therefore measured live in the same run on a second context with ONE lane (every kernel
+alone on the GPU, the whole batch per launch, HIP events over its own timed region), and `roofline.in_headline_run`
+carries the per-launch figures of the two-lane run beside it.  `with_host_copies` (never `value`) is the same workload
+with the planes in pinned host memory (upload + kernels + read-back, what the reference's own timer wraps).
 
 Prints ONE JSON line on rank 0.
 """
@@ -65,7 +73,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--min-seconds", type=float, default=0.5, help="the timed region repeats the --steps steps until it is at least this long")
+    ap.add_argument("--min-seconds", type=float, default=6.0, help="the timed region repeats the --steps steps until it is at least this long")
     ap.add_argument("--workload", choices=["c3", "c4", "c5"], default="c3", help="BASELINE.json config: c3 (headline, weak scaling), c4, c5 (fixed totals, sharded)")
     ap.add_argument("--streams", type=int, default=None, help="c3: concurrent camera streams per GPU (256); c4: streams in total (512); c5: cameras per URDF (128)")
     ap.add_argument("--urdfs", type=int, default=64, help="c5: distinct URDFs in total")
@@ -75,8 +83,11 @@ def main():
     ap.add_argument("--triangles", type=int, default=250000, help="triangle budget of the PR2-like model")
     ap.add_argument("--variants", type=int, default=2, help="distinct input batches rotated through the steps")
     ap.add_argument("--pipelines", type=int, default=1, help="contexts (HIP stream + bins each) per GPU that the batches alternate between: with 2 or 3, one batch's small and low-occupancy kernels overlap another's heavy ones, but kernels then share the GPU and per-launch times (roofline) no longer describe one kernel; default 1")
-    ap.add_argument("--launch-group", type=int, default=0, help="rtuf_params.max_inflight_streams: streams rasterised per internal launch group (0 = automatic: the whole batch up to 1024); smaller groups shrink the tile bins and cost a kernel sequence per group")
-    ap.add_argument("--overlap-pipelines", type=int, default=2, help="after the main measurement (one pipeline, clean per-kernel roofline) time the same steps once more on a second context with rtuf_params.pipelines = this, reported as `overlapped` (N=1 only; 0 disables)")
+    ap.add_argument("--launch-group", type=int, default=0, help="rtuf_params.max_inflight_streams: streams rasterised per internal launch group (0 = automatic: a quarter of the streams with two raster lanes, the whole batch up to 1024 with one); smaller groups shrink the tile bins and cost a kernel sequence per group")
+    ap.add_argument("--overlap-pipelines", type=int, default=0, help="(obsolete, ignored: the overlap is the library default now, rtuf_params.raster_lanes; kept so that older command lines still run)")
+    ap.add_argument("--lanes", type=int, default=0, help="rtuf_params.raster_lanes of the headline context (0 = the library's default, 2: launch groups alternate between two HIP streams with bins of their own; 1: one lane)")
+    ap.add_argument("--isolated-seconds", type=float, default=2.0, help="length of the one-lane leg the roofline is measured on (N=1 only; 0 disables: the roofline then carries the headline run's per-launch times)")
+    ap.add_argument("--host-copy-seconds", type=float, default=3.0, help="length of each with_host_copies leg (planes in pinned host memory; N=1 only; 0 disables)")
     ap.add_argument("--two-kernel", action="store_true", help="rasteriser + separate compare kernel")
     ap.add_argument("--host-poses", action="store_true", help="stage explicit link matrices from the host instead of joint positions + on-device forward kinematics")
     ap.add_argument("--u16", action="store_true", help="16UC1 depth in/out (uint16 millimetres) with the conversions fused into the kernels")
@@ -85,7 +96,7 @@ def main():
     ap.add_argument("--bin-capacity", type=int, default=0, help="rtuf_params.bin_capacity (records per tile bin; 0 = the library's default, grown on overflow)")
     ap.add_argument("--debug-flags", type=lambda x: int(x, 0), default=0, help="timing experiments only (needs the RTUF_ABLATE build; results are wrong)")
     ap.add_argument("--near-arm", action="store_true", help="c3 / c4: every stream poses the robot's right forearm 0.1-0.35 m in front of the lens (exact-z pass, near-plane clipping, whole-tile occluders)")
-    ap.add_argument("--check-frames", type=int, default=16, help="frames of the last step verified against the oracle (per rank)")
+    ap.add_argument("--check-frames", type=int, default=-1, help="frames of the last step verified against the oracle, per rank (-1 = every stream; the oracle runs on all host cores)")
     args = ap.parse_args()
 
     import torch
@@ -133,6 +144,7 @@ def main():
     p.flags |= args.debug_flags
     p.bin_capacity = args.bin_capacity
     p.max_inflight_streams = args.launch_group
+    p.raster_lanes = args.lanes
     P = max(1, args.pipelines)
     p.pipelines = P if P > 1 else 0          # rtuf_params.pipelines: the library alternates the batches between P internal pipelines
     ctx = R.Context(W, H, n, local_rank, p)
@@ -222,43 +234,29 @@ def main():
     sts = [c.stats() for c in ctxs]
     timed = sum(st["timed_batches"] for st in sts)
     assert timed >= 1 and timed >= timed_steps // 8, ([st["timed_batches"] for st in sts], timed_steps)
-    setup_ms = sum(st["sum_ms_setup"] for st in sts) / timed          # set-up kernel alone
-    clip_ms = sum(st["sum_ms_clip"] for st in sts) / timed
-    raster_ms = sum(st["sum_ms_raster"] for st in sts) / timed
-    compare_ms = sum(st["sum_ms_compare"] for st in sts) / timed
-    # stage-by-stage breakdown: a few extra steps on one pipeline, one batch in flight, every stage bracketed
-    # by events, outside the timed region (kernel times without another batch sharing the GPU)
-    ctx.enable_timing(1)
-    extra = 3 * V       # a multiple of the variant cycle
-    acc = {"ms_pose": 0.0, "ms_setup": 0.0, "ms_raster": 0.0, "ms_compare": 0.0, "ms_total": 0.0}
-    k_after = k0 + timed_steps
-    k_after += (-k_after) % V          # so that the last extra step is variant V-1 and k_last below is well defined
-    for j in range(extra):
-        isolated_step(k_after + j)
-        st = ctx.stats()
-        for key in acc:
-            acc[key] += st[key]
-    breakdown = {key: v / extra for key, v in acc.items()}
-    # ... and the raster stage's kernels one by one under the same conditions (timing mode 2)
-    ctx.enable_timing(2)
-    iso = {"ms_setup": 0.0, "ms_clip": 0.0, "ms_raster": 0.0, "ms_compare": 0.0}
-    for j in range(extra):
-        isolated_step(k_after + extra + j)
-        st = ctx.stats()
-        for key in iso:
-            iso[key] += st[key] / extra
-    k_last = k_after + 2 * extra - 1
-    groups_per_batch = 1
+    st = ctx.stats()
+    lanes, groups_per_batch = st["raster_lanes"], max(1, st["groups_last_batch"])
+    # per-launch averages of the headline run: the library sums a batch's launch groups, so divide by their number
+    head = {k: sum(x["sum_ms_" + k] for x in sts) / timed / groups_per_batch for k in ("setup", "clip", "raster", "compare")}
+    overlapping = lanes > 1 or P > 1              # kernels of different groups / batches share the GPU
+    k_last = k0 + timed_steps - 1
     frames_rank = n * timed_steps
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    st = ctx.stats()
 
-    # ---- parity spot check on every rank (oracle = checker only) -----------------------------------
+    # ---- parity on every rank: by default EVERY stream of the last timed step (oracle = checker only) ----------------
     from oracle import bindings as O
     from realtime_urdf_filter_amd.filter import depth_f32_to_u16, depth_u16_to_f32
+    host_threads = len(os.sched_getaffinity(0))
+    quota = None
+    try:        # a container's CPU quota (cgroup v2): the cores the threads below can really use at once
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        quota = None
+    threads = max(1, min(host_threads, int(quota))) if quota else host_threads
     v_last = k_last % V
     d_masked, d_mask = d_masked_set[k_last % n_sets], d_mask_set[k_last % n_sets]
     link_dev = cam_dev = None
@@ -267,28 +265,34 @@ def main():
         # the oracle is fed the very matrices the GPU's forward kinematics produced
         link_dev, cam_dev = ctx.read_poses(n, share.n_links_total)
         fk_err = share.host_fk_error(k_last, link_dev, cam_dev)
-    check = sorted(set(int(x) for x in np.linspace(0, n - 1, num=min(max(args.check_frames, 0), n)))) if args.check_frames > 0 else []
+    n_check = n if args.check_frames < 0 else min(args.check_frames, n)
+    check = sorted(set(int(x) for x in np.linspace(0, n - 1, num=n_check))) if n_check > 0 else []
+    h_masked_all = d_masked.cpu().numpy()
+    h_mask_all = d_mask.cpu().numpy() if d_mask is not None else None
+    h_depth_all = d_depth[v_last].cpu().numpy()
 
     def fetch(s):
-        hm = d_masked[s].cpu().numpy()
-        hk = d_mask[s].cpu().numpy() if d_mask is not None else None
-        hd = d_depth[v_last][s].cpu().numpy()
+        hm, hd = h_masked_all[s], h_depth_all[s]
+        hk = h_mask_all[s] if h_mask_all is not None else None
         if args.u16:
             hm = hm.view(np.uint16)
             hd = depth_u16_to_f32(hd.view(np.uint16))
         return hd, hm, hk
 
-    def oracle(s, hd):
-        proj, draws, off, cam = share.oracle_frame(k_last, s, link_dev, cam_dev)
-        return O.filter_frame(hd, proj, draws, off, cam, max_diff=wl0.max_diff, replace_value=wl0.replace_value)
-
-    bad_mask = bad_depth = 0
+    t_par = time.perf_counter()
+    prepared_check = []
     for s in check:
-        hd, hm, hk = fetch(s)
-        om, ok = oracle(s, hd)
+        hd, _, _ = fetch(s)
+        proj, draws, off, cam = share.oracle_frame(k_last, s, link_dev, cam_dev)
+        prepared_check.append(O.PreparedFrame(hd, proj, draws, off, cam, max_diff=wl0.max_diff, replace_value=wl0.replace_value))
+    O.run_prepared(prepared_check, threads)
+    bad_mask = bad_depth = 0
+    for s, pf in zip(check, prepared_check):
+        _, hm, hk = fetch(s)
         if hk is not None:
-            bad_mask += int((ok != hk).sum())
-        bad_depth += int((depth_f32_to_u16(om) != hm).sum()) if args.u16 else int((om.view(np.uint32) != hm.view(np.uint32)).sum())
+            bad_mask += int((pf.mask != hk).sum())
+        bad_depth += int((depth_f32_to_u16(pf.masked) != hm).sum()) if args.u16 else int((pf.masked.view(np.uint32) != hm.view(np.uint32)).sum())
+    t_par = time.perf_counter() - t_par
     frames_total, bad_total, checked_total = frames_rank, bad_mask + bad_depth, len(check)
     per_rank = [{"rank": rank, "streams": n, "frames": frames_rank, "frames_checked": len(check), "mismatching_values": bad_mask + bad_depth}]
     if dist is not None:
@@ -303,29 +307,119 @@ def main():
 
     if rank == 0:
         value = frames_total / elapsed
-        per = dict(breakdown)
         px = W * H
         two = args.two_kernel
+        mask_b = 0 if args.no_mask else 1
+
+        def fresh_share():
+            return CF.build(args.workload, job_world, rank, streams=args.streams, triangles=args.triangles, variants=args.variants,
+                            width=args.width, height=args.height, urdfs=args.urdfs, near_arm=args.near_arm)
+
+        # ---- one-lane leg: every kernel alone on the GPU, the whole batch per launch -- what the roofline describes -----
+        iso_leg = None
+        breakdown = None
+        iso = None
+        if world == 1 and args.isolated_seconds > 0 and not (lanes == 1 and P == 1 and groups_per_batch == 1):
+            p1 = R.default_params()
+            p1.filter_replace_value, p1.depth_distance_threshold, p1.flags = p.filter_replace_value, p.depth_distance_threshold, p.flags
+            p1.raster_lanes, p1.max_inflight_streams, p1.bin_capacity = 1, min(n, 1024), args.bin_capacity
+            ctx.sync()
+            ctx1 = R.Context(W, H, n, local_rank, p1)
+            share1 = fresh_share()
+            share1.load(ctx1, on_device_fk=not args.host_poses)
+            sets1 = [(torch.empty_like(d_masked_set[0]), None if args.no_mask else torch.empty_like(d_mask_set[0])) for _ in range(2)]
+
+            def submit1(k):
+                m, kk = sets1[k % 2]
+                (ctx1.filter_batch_device_u16 if args.u16 else ctx1.filter_batch_device)(n, dptr[k % V], m.data_ptr(), kk.data_ptr() if kk is not None else 0)
+
+            for k in range(max(args.warmup, 2)):
+                share1.stage(ctx1, k)
+                submit1(k)
+                ctx1.sync()
+            kb = max(args.warmup, 2)
+            share1.stage(ctx1, kb)
+            tq = time.perf_counter()
+            for k in range(kb, kb + 8):
+                submit1(k)
+                share1.stage(ctx1, k + 1)
+            ctx1.sync()
+            est1 = (time.perf_counter() - tq) / 8
+            steps1 = max(16, int(np.ceil(args.isolated_seconds / max(est1, 1e-9))))
+            kb += 8
+            ctx1.enable_timing(3)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(kb, kb + steps1):
+                submit1(k)
+                share1.stage(ctx1, k + 1)
+            ctx1.sync()
+            torch.cuda.synchronize()
+            el1 = time.perf_counter() - t1
+            s1 = ctx1.stats()
+            g1 = max(1, s1["groups_last_batch"])
+            iso_leg = {k: s1["sum_ms_" + k] / max(s1["timed_batches"], 1) / g1 for k in ("setup", "clip", "raster", "compare")}
+            iso_leg.update({"timed_launches": s1["timed_batches"] * g1, "launches_per_step": g1, "steps": steps1, "seconds": el1,
+                            "frames_per_s": n * steps1 / el1, "device_memory_bytes": s1["device_bytes"]})
+            bctx, bshare, bk = ctx1, share1, kb + steps1
+        else:
+            bctx, bshare, bk = ctx, share, k_last + 1
+            sets1 = [(d_masked_set[i], d_mask_set[i]) for i in range(2)]
+
+            def submit1(k):
+                m, kk = sets1[k % 2]
+                (bctx.filter_batch_device_u16 if args.u16 else bctx.filter_batch_device)(n, dptr[k % V], m.data_ptr(), kk.data_ptr() if kk is not None else 0)
+
+        # stage-by-stage breakdown and the raster stage's kernels one by one: a few extra steps, one batch in flight, host
+        # waits after every step (on the one-lane context when there is one: nothing else on the GPU)
+        extra = 3 * V
+        acc = {"ms_pose": 0.0, "ms_setup": 0.0, "ms_raster": 0.0, "ms_compare": 0.0, "ms_total": 0.0}
+        bctx.enable_timing(1)
+        for j in range(extra):
+            bshare.stage(bctx, bk + j)
+            submit1(bk + j)
+            bctx.sync()
+            sx = bctx.stats()
+            for key in acc:
+                acc[key] += sx[key]
+        breakdown = {key: v / extra for key, v in acc.items()}
+        bctx.enable_timing(2)
+        gb = max(1, bctx.stats()["groups_last_batch"])
+        iso = {"ms_setup": 0.0, "ms_clip": 0.0, "ms_raster": 0.0, "ms_compare": 0.0}
+        for j in range(extra):
+            bshare.stage(bctx, bk + extra + j)
+            submit1(bk + extra + j)
+            bctx.sync()
+            sx = bctx.stats()
+            for key in iso:
+                iso[key] += sx[key] / extra / gb
+        if bctx is not ctx:
+            bctx.close()
+            del sets1
+            torch.cuda.empty_cache()
+
         # algorithmic bytes per launch:
         #   fused tile kernel : 9 B/pixel = 4 sensor read + 4 masked write + 1 mask write (8 without mask; 5 / 4 for 16UC1)
         #   two-kernel mode   : tile kernel writes the 4 B/pixel z-surface; compare moves 13 B/pixel
         #   set-up + clip     : every vertex (12 B) and triangle (12 B indices + 4 B order) of the model once per launch --
         #                       the geometry is shared by all streams; the records it writes are implementation traffic
-        mask_b = 0 if args.no_mask else 1
+        # a launch of the one-lane leg covers all n streams, a launch of the headline run n / groups_per_batch of them
+        src_ms = iso_leg if iso_leg is not None else head
+        launch_streams = n / (iso_leg["launches_per_step"] if iso_leg is not None else groups_per_batch)
+        geo_bytes = sum(12 * g.variants[0].n_vertices() + 16 * g.variants[0].n_triangles() for g in share.groups)
         kernels = {}
         if two:
-            kernels["tile_kernel<two_kernel>"] = (raster_ms, iso["ms_raster"], 4 * px * n, "valu-issue / LDS atomics (rasteriser: neither HBM nor MFMA, SURVEY.md 8d); HBM figure for context")
-            kernels["compare_kernel"] = (compare_ms, iso["ms_compare"], ((6 if args.u16 else 12) + mask_b) * px * n, "hbm")
+            kernels["tile_kernel<two_kernel>"] = ("raster", 4 * px, "valu-issue / LDS atomics (rasteriser: neither HBM nor MFMA, SURVEY.md 8d); HBM figure for context")
+            kernels["compare_kernel"] = ("compare", ((6 if args.u16 else 12) + mask_b) * px, "hbm")
         else:
-            kernels["tile_kernel<fused>"] = (raster_ms, iso["ms_raster"], ((4 if args.u16 else 8) + mask_b) * px * n, "hbm")
-        geo_bytes = sum(12 * g.variants[0].n_vertices() + 16 * g.variants[0].n_triangles() for g in share.groups)
-        kernels["setup_kernel"] = (setup_ms, iso["ms_setup"], geo_bytes, "valu-issue (triangle set-up: neither HBM nor MFMA, SURVEY.md 8d); HBM figure for context")
-        kernels["clip_kernel"] = (clip_ms, iso["ms_clip"], 0, "latency / divergent scalar code at LDS-limited occupancy; no algorithmic HBM traffic of its own (the time covers clip_kernel and bigrec_kernel, which appends the many-tile records both set-up and clip kernel listed)")
+            kernels["tile_kernel<fused>"] = ("raster", ((4 if args.u16 else 8) + mask_b) * px, "hbm")
+        kernels["setup_kernel"] = ("setup", None, "valu-issue (triangle set-up: neither HBM nor MFMA, SURVEY.md 8d); HBM figure for context")
+        kernels["clip_kernel"] = ("clip", 0, "latency / divergent scalar code at LDS-limited occupancy; no algorithmic HBM traffic of its own (the time covers clip_kernel and bigrec_kernel, which appends the many-tile records both set-up and clip kernel listed)")
         peak = 8000.0
         # Off-line counter data of this same command (rocprofv3 --pmc passes cannot run inside the timed region):
-        # used only when the committed measurement is of this exact workload, and labelled as such.
+        # used only when the committed measurement is of this exact workload AND launch shape, and labelled as such.
         default_cmd = (args.workload == "c3" and n == 256 and (W, H) == (640, 480) and not args.no_mask and not args.u16 and args.triangles == 250000 and not args.near_arm and not args.host_poses)
-        # (config 4's per-GPU share -- the other workload whose counters are committed, profiles/r03_pmc_workload_c4_shard_of_8.txt)
+        # (config 4's per-GPU share -- the other workload whose counters are committed)
         c4_share_cmd = (args.workload == "c4" and args.shard_of == 8 and n == 64 and (W, H) == (1280, 720) and not args.no_mask and not args.u16
                         and args.triangles == 250000 and not args.near_arm and not args.host_poses and not args.two_kernel)
         pmc = None
@@ -338,22 +432,40 @@ def main():
             valu_peak = json.load(open(os.path.join(ROOT, "profiles", "valu_peak.json")))
         except Exception:
             valu_peak = None
+        pmc_ok = pmc is not None and int(round(launch_streams)) == int((pmc or {}).get("streams_per_launch", 256))
+
+        def alg_bytes_of(name, streams):
+            _, per_stream, _ = kernels[name]
+            return geo_bytes if per_stream is None else int(per_stream * streams)
 
         def kernel_entry(name):
-            dur_ms, iso_ms, alg_bytes, bound = kernels[name]
+            key, _, bound = kernels[name]
+            dur_ms = src_ms[key]
+            alg_bytes = alg_bytes_of(name, launch_streams)
             achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
             e = {"kernel": name, "bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                 "traffic": None, "avg_launch_ms": dur_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                 "isolated": {"avg_launch_ms": iso_ms, "frac": (alg_bytes / (iso_ms * 1e-3) / 1e9 / peak) if iso_ms > 0 else None,
-                              "note": "same kernel(s) with nothing else on the GPU (extra steps after the timed region)"}}
+                 "traffic": None, "avg_launch_ms": dur_ms, "algorithmic_bytes_per_launch": alg_bytes, "streams_per_launch": launch_streams,
+                 "measured_on": ("one-lane context in this run (rtuf_params.raster_lanes = 1, one launch group per batch): HIP events around the kernel on its stream over that leg's %d timed steps, batches pipelined, no other raster kernel on the GPU" % iso_leg["steps"]) if iso_leg is not None
+                                else "the headline run's own context (HIP events around the kernel on its stream inside the timed region)"}
+            if iso is not None:
+                iso_ms = iso["ms_" + key]
+                ib = alg_bytes_of(name, n / gb)
+                e["isolated"] = {"avg_launch_ms": iso_ms, "frac": (ib / (iso_ms * 1e-3) / 1e9 / peak) if iso_ms > 0 else None,
+                                 "note": "same kernel with the host waiting after every batch (nothing else on the GPU at all; %d extra steps)" % extra}
+            if iso_leg is not None or overlapping:
+                hb = alg_bytes_of(name, n / groups_per_batch)
+                hm = head[key]
+                e["in_headline_run"] = {"avg_launch_ms": hm, "streams_per_launch": n / groups_per_batch, "algorithmic_bytes_per_launch": hb,
+                                        "frac": (hb / (hm * 1e-3) / 1e9 / peak) if hm > 0 else None,
+                                        "note": "per-launch time inside the headline's timed region: %d raster lane(s), %d launch groups per batch -- kernels of different groups overlap, so a launch shares the GPU with another kernel and its duration is not that of one kernel alone" % (lanes, groups_per_batch)}
             if name == "compare_kernel" and 4 * px * n < 2 * (256 << 20):
                 e["note"] = "HBM + MALL figure: the %d MB z-surface this kernel reads was written by the kernel before it and partly sits in the 256 MiB Infinity Cache; with --streams 1024 (z-surface 1.26 GB) the same kernel measures pure HBM" % (4 * px * n // 1000000)
-            rec = (pmc or {}).get("kernels", {}).get(name) if (pmc and default_cmd and P == 1) else None
-            if rec is None and pmc and c4_share_cmd and P == 1:
+            rec = (pmc or {}).get("kernels", {}).get(name) if (pmc_ok and default_cmd) else None
+            if rec is None and pmc and c4_share_cmd and int(round(launch_streams)) == 64:
                 rec = (pmc.get("c4_share") or {}).get("kernels", {}).get(name)
             if rec:
                 e["traffic"] = rec.get("hbm_bytes_per_launch")
-                e["traffic_source"] = "OFFLINE: " + (pmc.get("c4_share", {}).get("source") if (c4_share_cmd and not default_cmd) else pmc.get("source", "profiles/pmc_counters.json")) + " (rocprofv3 --pmc passes of this same command; not measured in this run)"
+                e["traffic_source"] = "OFFLINE: " + (pmc.get("c4_share", {}).get("source") if (c4_share_cmd and not default_cmd) else pmc.get("source", "profiles/pmc_counters.json")) + " (rocprofv3 --pmc passes of the one-lane launch shape of this same workload; not measured in this run)"
                 cnt = rec.get("wave64_valu_instructions_per_launch")
                 if cnt and dur_ms > 0:
                     g = cnt / (dur_ms * 1e-3) / 1e9
@@ -389,106 +501,135 @@ def main():
         if dom["bound"] != "hbm":
             dom = dict(dom, bound_note=dom["bound"], bound="hbm")   # (the contract's vocabulary; the note says what really limits it)
         roof = dict(dom)
-        roof.update({"launches_per_step": groups_per_batch, "timed_launches": timed,
+        roof.update({"launches_per_step": iso_leg["launches_per_step"] if iso_leg is not None else groups_per_batch,
+                     "timed_launches": iso_leg["timed_launches"] if iso_leg is not None else timed * groups_per_batch,
                      "all_kernels": [e for e in entries if e["kernel"] != dom["kernel"]]})
+        if iso_leg is not None:
+            roof["one_lane_leg"] = {"frames_per_s": iso_leg["frames_per_s"], "steps": iso_leg["steps"], "seconds": iso_leg["seconds"], "device_memory_bytes": iso_leg["device_memory_bytes"],
+                                    "note": "the same workload through a context of ONE raster lane (kernels one after the other, bins for the whole batch): what the headline figure would be without the lanes' overlap"}
         out = {
             "metric": "filtered depth frames/sec (640x480, PR2 URDF)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "timed_steps": timed_steps, "min_seconds": args.min_seconds,
+            "timed_steps": timed_steps, "min_seconds": args.min_seconds, "timed_seconds": elapsed,
             "ms_per_step": elapsed / max(timed_steps, 1) * 1e3, "higher_is_better": True, "scaling": share.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "depth_format": "16UC1" if args.u16 else "32FC1",
             "config": {"workload": share.describe(),
                        "streams_per_gpu": n if share.scaling == "weak" else [x["streams"] for x in per_rank], "streams_total": sum(x["streams"] for x in per_rank),
                        "poses": "host matrices" if args.host_poses else "joint positions, forward kinematics on the GPU", "mode": "two-kernel" if two else "fused", "mask_output": (not args.no_mask),
                        "parallelism": ("stream-sharded x%d" % world) + (" (shares of a %d-GPU job)" % job_world if args.shard_of else ""), "pipelines_per_gpu": P,
+                       "raster_lanes": lanes, "launch_groups_per_batch": groups_per_batch, "streams_per_launch_group": st["launch_group"],
                        "host_threads_pinned_to_gpu_numa_node": pinned_cpus},
             "per_stream_fps": value / max(sum(x["streams"] for x in per_rank), 1),
             "collectives": ({"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "world": world,
                              "used_for": "barriers around the timed region, MAX all-reduce of the repetition count and the elapsed time, all-gather of per-rank frame and parity counts; no data-path collective"}
                             if dist is not None else None),
-            "kernel_ms_per_step": dict(per, note="stage breakdown from %d extra steps after the timed region: one batch in flight, every stage bracketed by HIP events (ms_setup there = cull + set-up + clip + waiting for the pose stage); roofline.avg_launch_ms is measured inside the timed region" % extra),
-            "rasteriser": {"triangles_per_s": float(share.triangles_per_stream().sum()) / (setup_ms * 1e-3) if setup_ms > 0 else None,
-                           "binned_triangles_per_s": st["triangles_binned"] / (raster_ms * 1e-3) if raster_ms > 0 else None,
+            "kernel_ms_per_step": dict(breakdown, note="stage breakdown from %d extra steps after the timed region on the %s: one batch in flight, every stage bracketed by HIP events (ms_setup there = cull + set-up + clip + many-tile kernels)" % (extra, "one-lane context" if iso_leg is not None else "headline context")),
+            "rasteriser": {"triangles_per_s": float(share.triangles_per_stream().sum()) / (src_ms["setup"] * 1e-3) * (launch_streams / n) if src_ms["setup"] > 0 else None,
+                           "binned_triangles_per_s": st["triangles_binned"] / (src_ms["raster"] * 1e-3) * (launch_streams / n) if src_ms["raster"] > 0 else None,
                            "triangles_submitted": int(share.triangles_per_stream().sum()), "triangles_binned": st["triangles_binned"],
                            "triangles_clipped": st["triangles_clipped"], "bin_entries": st["bin_entries"],
                            "fragments_binned": st["fragments_binned"], "max_bin_fill": st["max_bin_fill"], "max_fragment_bin_fill": st["max_fbin_fill"], "bin_capacity": st["bin_capacity"], "regrowths": st["regrowths"],
                            "setup": {"work_items": st["work_items"], "zero_survivor_items": st["zero_survivor_items"],
                                      "note": "work item = one set-up workgroup: a chunk of <= 256 triangles x up to 3 streams whose frustum its box touches; zero-survivor = none of its triangles reached a bin or the clip list's survivors (sub-pixel or outside)"},
                            "tile": {"cover_tiles": st["cover_tiles"], "occluded_entries": st["occluded_entries"], "exact_z_tiles": st["exact_tiles"],
-                                    "tiles_per_launch": n * ((W + 63) // 64) * ((H + 31) // 32), "overdraw": overdraw}},
+                                    "tiles_per_launch": int(round(n / groups_per_batch)) * ((W + 63) // 64) * ((H + 31) // 32), "overdraw": overdraw}},
             "device_memory_bytes": st["device_bytes"],
             "roofline": roof,
             "parity": {"frames_checked": checked_total, "mismatching_values": bad_total, "mask_mismatch_pixels": bad_mask, "depth_mismatch_pixels": bad_depth,
-                       "per_rank": per_rank, "note": "every rank checks --check-frames frames of its last step against the oracle; mask/depth split is rank 0's"},
+                       "per_rank": per_rank, "oracle_threads": threads, "seconds": t_par,
+                       "note": "every rank checks --check-frames streams (default: all) of its LAST TIMED step against the oracle, which runs on the host cores; mask/depth split is rank 0's"},
         }
         if fk_err is not None:
             out["fk"] = {"on_device": True, "max_abs_diff_vs_host_fk": fk_err}
-        # ---- the same steps with the library's internal pipelines overlapping (rtuf_params.pipelines) ----------
-        if world == 1 and P == 1 and args.overlap_pipelines > 1 and not args.debug_flags:
-            PO = args.overlap_pipelines
-            p2 = R.default_params()
-            p2.filter_replace_value, p2.depth_distance_threshold, p2.flags, p2.pipelines = p.filter_replace_value, p.depth_distance_threshold, p.flags, PO
-            ctx.sync()
-            ctx2 = R.Context(W, H, n, local_rank, p2)
-            share2 = CF.build(args.workload, job_world, rank, streams=args.streams, triangles=args.triangles, variants=args.variants,
-                              width=args.width, height=args.height, urdfs=args.urdfs, near_arm=args.near_arm)
-            share2.load(ctx2, on_device_fk=not args.host_poses)
-            sets2 = [(torch.empty_like(d_masked_set[0]), None if args.no_mask else torch.empty_like(d_mask_set[0])) for _ in range(2 * PO)]
+        # ---- the whole path with the planes in host memory (the reference's own timer wraps upload + render + read-back,
+        # src/urdf_filter.cpp:211-244, :332-353, :729-735).  Never `value`. ----------------------------------------------
+        if world == 1 and args.host_copy_seconds > 0 and P == 1 and not two and not args.no_mask:
+            link_gbs = 63.0          # PCIe 5.0 x16, per direction
+            hc = {"link": "PCIe 5.0 x16: %.0f GB/s per direction" % link_gbs, "modes": {}}
+            words = ctx.mask_bits_words()
 
-            def submit2(k):
-                m, kk = sets2[k % len(sets2)]
-                (ctx2.filter_batch_device_u16 if args.u16 else ctx2.filter_batch_device)(n, dptr[k % V], m.data_ptr(), kk.data_ptr() if kk is not None else 0)
+            def host_leg(fmt, bits):
+                dt = np.uint16 if fmt == "16UC1" else np.float32
+                h_in = [ctx.host_alloc((n, H, W), dt) for _ in range(2)]
+                h_out = [] if bits else [ctx.host_alloc((n, H, W), dt) for _ in range(2)]
+                h_mask = [] if bits else [ctx.host_alloc((n, H, W), np.uint8) for _ in range(2)]
+                h_bits = [ctx.host_alloc((n, words), np.uint32) for _ in range(2)] if bits else []
+                for v in range(2):
+                    d = d_depth[v % V].cpu().numpy()
+                    if args.u16:
+                        d = depth_u16_to_f32(d.view(np.uint16))
+                    h_in[v][...] = depth_f32_to_u16(np.nan_to_num(d, nan=0.0, posinf=0.0)) if fmt == "16UC1" else d
 
-            for k in range(max(args.warmup, 2) * PO):
-                share2.stage(ctx2, k)
-                submit2(k)
-                ctx2.sync()
-            kb = args.warmup * PO + ((-args.warmup * PO) % V)
-            share2.stage(ctx2, kb)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            for k in range(kb, kb + timed_steps):
-                submit2(k)
-                share2.stage(ctx2, k + 1)
-            ctx2.sync()
-            torch.cuda.synchronize()
-            el2 = time.perf_counter() - t2
-            # parity of its last batch (same checker)
-            k2_last = kb + timed_steps - 1
-            m2, kk2 = sets2[k2_last % len(sets2)]
-            l2, c2 = (None, None) if args.host_poses else ctx2.read_poses(n, share2.n_links_total)
-            bad2 = 0
-            for s_ in check[:2]:
-                hd2 = d_depth[k2_last % V][s_].cpu().numpy()
-                hm2 = m2[s_].cpu().numpy()
-                if args.u16:
-                    hm2 = hm2.view(np.uint16)
-                    hd2 = depth_u16_to_f32(hd2.view(np.uint16))
-                proj, draws, off, cam = share2.oracle_frame(k2_last, s_, l2, c2)
-                om, ok = O.filter_frame(hd2, proj, draws, off, cam, max_diff=wl0.max_diff, replace_value=wl0.replace_value)
-                if kk2 is not None:
-                    bad2 += int((ok != kk2[s_].cpu().numpy()).sum())
-                bad2 += int((depth_f32_to_u16(om) != hm2).sum()) if args.u16 else int((om.view(np.uint32) != hm2.view(np.uint32)).sum())
-            out["overlapped"] = {"pipelines": PO, "value": n * timed_steps / el2, "unit": "frames/s", "ms_per_step": el2 / timed_steps * 1e3,
-                                 "timed_steps": timed_steps, "frames_checked": len(check[:2]), "mismatching_values": bad2,
-                                 "note": "same workload and step count on a context with rtuf_params.pipelines = %d: batches alternate between %d internal pipelines, so kernels of different batches share the GPU (higher throughput; per-launch kernel times, and with them a per-kernel roofline, no longer describe one kernel -- hence not the headline)" % (PO, PO)}
-            ctx2.close()
+                def go(k):
+                    if bits:
+                        ctx.filter_batch_bits_async(h_in[k % 2], h_bits[k % 2])
+                    else:
+                        ctx.filter_batch_async(h_in[k % 2], h_out[k % 2], h_mask[k % 2])
+
+                kq = k_last + 1 + ((-(k_last + 1)) % V)            # variant 0 first: h_in[k % 2] then matches share.stage(k) for V = 2
+                for k in range(kq, kq + 2):
+                    share.stage(ctx, k)
+                    go(k)
+                    ctx.sync()
+                share.stage(ctx, kq + 2)
+                tq = time.perf_counter()
+                go(kq + 2)
+                ctx.sync()
+                est = time.perf_counter() - tq
+                steps_h = max(4, int(np.ceil(args.host_copy_seconds / max(est, 1e-9))))
+                steps_h += steps_h % 2
+                ks = kq + 4
+                share.stage(ctx, ks)
+                th = time.perf_counter()
+                for k in range(ks, ks + steps_h):
+                    go(k)                                       # two batches in flight: the third call retires the first
+                    share.stage(ctx, k + 1)
+                ctx.sync()
+                el = time.perf_counter() - th
+                # parity of the last batch, first and last stream (same checker; V == 2 keeps planes and poses in step)
+                bad = None
+                if V == 2:
+                    kl = ks + steps_h - 1
+                    lk, ck = (None, None) if args.host_poses else ctx.read_poses(n, share.n_links_total)
+                    bad = 0
+                    for s_ in (0, n - 1):
+                        d32 = depth_u16_to_f32(h_in[kl % 2][s_]) if fmt == "16UC1" else h_in[kl % 2][s_]
+                        proj, draws, off, cam = share.oracle_frame(kl, s_, lk, ck)
+                        om, ok = O.filter_frame(d32, proj, draws, off, cam, max_diff=wl0.max_diff, replace_value=wl0.replace_value)
+                        if bits:
+                            m2, k2 = R.expand_mask_bits(h_in[kl % 2][s_], h_bits[kl % 2][s_], wl0.replace_value)
+                        else:
+                            m2, k2 = h_out[kl % 2][s_], h_mask[kl % 2][s_]
+                        want = depth_f32_to_u16(om) if fmt == "16UC1" else om
+                        bad += int((ok != k2).sum()) + int((want.view(np.uint16 if fmt == "16UC1" else np.uint32) != m2.view(np.uint16 if fmt == "16UC1" else np.uint32)).sum())
+                b_in = h_in[0].nbytes
+                b_out = h_bits[0].nbytes if bits else h_out[0].nbytes + h_mask[0].nbytes
+                up, down = b_in * steps_h / el / 1e9, b_out * steps_h / el / 1e9
+                for a_ in h_in + h_out + h_mask + h_bits:
+                    ctx.host_free(a_)
+                return {"frames_per_s": n * steps_h / el, "ms_per_step": el / steps_h * 1e3, "steps": steps_h, "seconds": el,
+                        "host_to_device_GB_per_s": up, "device_to_host_GB_per_s": down,
+                        "fraction_of_link": {"host_to_device": up / link_gbs, "device_to_host": down / link_gbs},
+                        "frames_checked": 2 if bad is not None else 0, "mismatching_values": bad}
+
+            try:
+                hc["modes"]["32FC1 planes in and out, two batches in flight"] = host_leg("32FC1", False)
+                hc["modes"]["16UC1 planes in, mask bits out (1 bit per pixel), two batches in flight"] = host_leg("16UC1", True)
+            except Exception as e:      # noqa: BLE001 - pinned memory may be short on a shared box; the headline must survive
+                hc["error"] = repr(e)
+            hc["note"] = ("same workload and context as `value`, but the sensor planes start in pinned HOST memory and the results end there "
+                          "(rtuf_filter_batch_async / rtuf_filter_batch_bits_u16_async: upload on one copy stream, kernels, read-back on another); "
+                          "PCIe-bound. Never `value`: the contract's value has its inputs resident in HBM")
+            out["with_host_copies"] = hc
         # ---- CPU baseline: the oracle port on this box's host cores, on a bounded sample of the same batch ----
         if world == 1 and args.cpu_seconds > 0 and n > 0:
-            cores = len(os.sched_getaffinity(0))
-            quota = None
-            try:        # a container's CPU quota (cgroup v2): the cores the threads below can really use at once
-                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-                quota = None if q == "max" else float(q) / float(per)
-            except Exception:
-                quota = None
+            cores = host_threads
             # inputs: the first streams of the last batch (exactly what the GPU just filtered), prepared once
             n_in = min(n, 64)
-            inputs = []
+            prepared = []
             for s in range(n_in):
                 hd, _, _ = fetch(s)
-                inputs.append((hd,) + tuple(share.oracle_frame(k_last, s, link_dev, cam_dev)))
-            prepared = [O.PreparedFrame(*inputs[i % n_in], max_diff=wl0.max_diff, replace_value=wl0.replace_value) for i in range(n_in)]
+                prepared.append(O.PreparedFrame(hd, *share.oracle_frame(k_last, s, link_dev, cam_dev), max_diff=wl0.max_diff, replace_value=wl0.replace_value))
             c0 = time.perf_counter()
             n1 = 0
             while time.perf_counter() - c0 < args.cpu_seconds:
@@ -499,7 +640,6 @@ def main():
             # Python in the loop; per-thread scratch memory)
             # as many threads as cores this process may really use at once: min(visible hardware threads, cgroup CPU quota) --
             # 256 threads under a 16-core quota only measure the scheduler
-            threads = max(1, min(cores, int(quota))) if quota else cores
             nN, tN = O.filter_throughput(prepared, args.cpu_seconds, threads)
             cb = {"value": n1 / t1, "unit": "frames/s", "cores": 1, "kind": "port",
                   "sample": "%d frames of the last batch (first %d streams, cycled) through oracle/rtuf_oracle.c, single thread, %.1f s" % (n1, n_in, t1),

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTUF_ABI_VERSION 4
+#define RTUF_ABI_VERSION 5
 
 typedef struct rtuf_context rtuf_context;
 
@@ -71,8 +71,10 @@ typedef struct {
   float filter_replace_value;       /* rosparam filter_replace_value     -> shader uniform replace_value (:631) */
   uint32_t flags;                   /* RTUF_FLAG_* */
   uint32_t bin_capacity;            /* triangles per (stream, screen tile) bin; 0 = automatic */
-  uint32_t max_inflight_streams;    /* streams rasterised per internal launch group; 0 = automatic: up to 1024,
-                                       fewer if the bins would exceed a third of the free device memory */
+  uint32_t max_inflight_streams;    /* streams rasterised per internal launch group (= streams a raster lane's bins are sized for);
+                                       0 = automatic: a quarter of max_streams with two raster lanes (256 streams: four
+                                       groups of 64, two per lane), the whole batch up to 1024 with one; fewer if the bins
+                                       would exceed a third of the free device memory or memory_limit_mb */
   uint32_t pipelines;               /* 0 / 1: one raster pipeline.  2..4: that many complete pipelines (HIP streams, bins,
                                        staging, geometry copy) inside the context; batches alternate between them, so the
                                        small and low-occupancy kernels of one batch (pose stage, cull, clip, kernel tails)
@@ -80,7 +82,18 @@ typedef struct {
                                        256-stream VGA workload).  Setters apply to all pipelines; up to 2 x pipelines batches
                                        may be in flight; rtuf_filter() and the debug read-backs use the first / the last-used
                                        pipeline.  Fixed at rtuf_create. */
-  uint32_t reserved[4];
+  /* ABI 5 */
+  uint32_t raster_lanes;            /* 0 = automatic (2).  A raster lane is a HIP stream plus a set of tile bins sized for ONE launch
+                                       group.  With 2, a batch of >= 32 streams is split into an even number of launch groups that
+                                       alternate between the lanes: group B's set-up kernel (VALU-bound, no LDS traffic to speak
+                                       of) runs under group A's tile kernel (LDS atomics + HBM streaming), and every kernel's ramp,
+                                       tail and launch gap is filled by the other lane.  Smaller batches take one lane each, in
+                                       turn.  1 = one lane, every kernel alone on the GPU (what per-kernel timings and rooflines
+                                       should be measured with).  Fixed at rtuf_create. */
+  uint32_t memory_limit_mb;         /* upper bound of the rasteriser's working set (tile bins of all lanes), MiB; 0 = a third of
+                                       the free device memory at rtuf_finalize_models.  When the bins a scene needs would exceed it
+                                       the launch groups shrink (more, smaller launches) instead of the call failing. */
+  uint32_t reserved[2];
 } rtuf_params;
 
 void rtuf_default_params(rtuf_params *p);
@@ -261,10 +274,17 @@ const float *rtuf_get_masked_depth(const rtuf_context *ctx);      /* getMaskedDe
 const uint8_t *rtuf_get_mask(const rtuf_context *ctx);            /* mask_ */
 
 int rtuf_sync(rtuf_context *ctx);
-/* The HIP stream the raster stage of this context is enqueued on (for callers that time with HIP events or order their
- * own work behind a batch).  A single-pipeline concept: a context created with rtuf_params.pipelines > 1 spreads its
- * batches over several internal streams and returns NULL here. */
+/* The HIP stream the raster stage of this context is enqueued on -- defined only for a context of ONE raster lane and ONE
+ * pipeline (rtuf_params.raster_lanes = 1, pipelines <= 1).  Every other context spreads a batch over several internal
+ * streams and returns NULL here: do NOT pass that NULL to hipStreamWaitEvent / hipEventRecord (NULL is the legacy default
+ * stream there: nothing fails and the ordering is simply wrong).  Callers that order their own device work behind the
+ * batches use rtuf_order_stream_after_batches() instead, which is right for every configuration. */
 void *rtuf_stream(rtuf_context *ctx);
+/* Makes `hip_stream` (a hipStream_t of the context's device; NULL = the legacy default stream) wait, on the device, for
+ * every batch enqueued on this context so far: all raster lanes, all pipelines, and for host-plane batches their
+ * downloads.  Does not block the host and does not retire anything (the batches' buffers stay owned by the library until
+ * rtuf_wait_oldest / rtuf_sync).  ABI 5. */
+int rtuf_order_stream_after_batches(rtuf_context *ctx, void *hip_stream);
 
 /* Counters of the last batch and kernel timings measured with HIP events on the context's
  * stream (replaces the wall-clock statistics of src/urdf_filter.cpp:239-266). */
@@ -295,6 +315,13 @@ typedef struct {
   uint32_t reserved0;
   uint64_t raster_atomics;          /* instrumented builds (-DRTUF_COUNT) only: depth tests the tile kernel issued      */
   uint64_t drawn_pixels;            /* instrumented builds only: pixels whose final depth key is not the background's   */
+  /* ABI 5 */
+  uint32_t raster_lanes;            /* raster lanes of the context (of each pipeline)                                   */
+  uint32_t launch_group;            /* streams a lane's bins are sized for right now (shrinks when memory is short)      */
+  uint32_t groups_last_batch;       /* launch groups the last batch was split into                                       */
+  uint32_t graphs_enabled;          /* 1 while small batches replay captured hipGraphs (pipeline children only); the library
+                                       switches them off for good when captures keep evicting live entries               */
+  uint64_t graph_hits, graph_misses;/* replays / captures so far                                                          */
 } rtuf_stats;
 int rtuf_get_stats(rtuf_context *ctx, rtuf_stats *out);
 /* Per-kernel HIP-event timing (off by default: every event costs a few microseconds of stream

@@ -116,6 +116,30 @@ class PreparedFrame:
         return self.masked, self.mask
 
 
+def run_prepared(prepared, n_threads):
+    """Runs every prepared frame once, on up to n_threads host threads (the C call releases the GIL); the results are in
+    each frame's .masked / .mask.  The all-stream parity checks of bench.py and the full-size GPU tests."""
+    if n_threads <= 1 or len(prepared) <= 1:
+        for f in prepared:
+            f.run()
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(int(n_threads), len(prepared))) as ex:
+        list(ex.map(lambda f: f.run(), prepared))
+
+
+def usable_threads():
+    """Host threads this process can really run at once: min(visible hardware threads, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
 def filter_throughput(prepared, seconds, n_threads):
     """Filters the prepared frames cyclically for `seconds` on n_threads POSIX threads inside the C library (no Python
     in the loop); returns (frames filtered, elapsed seconds).  bench.py's cpu_baseline.all_cores leg."""

@@ -16,7 +16,7 @@ RTUF_OK = 0
 RTUF_ERR_NO_DEVICE = -2
 OP_NONE, OP_SCALE, OP_TRANSLATE = 0, 1, 2
 FLAG_TWO_KERNEL = 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 #: every symbol include/rtuf.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -28,7 +28,7 @@ SYMBOLS = [
     "rtuf_stream", "rtuf_get_stats", "rtuf_enable_timing", "rtuf_debug_read_zsurface",
     "rtuf_filter_batch_async", "rtuf_filter_batch_u16_async", "rtuf_wait_oldest", "rtuf_host_alloc", "rtuf_host_free",
     "rtuf_mask_bits_words", "rtuf_filter_batch_bits_async", "rtuf_filter_batch_bits_u16_async", "rtuf_filter_batch_device_bits",
-    "rtuf_filter_batch_device_bits_u16", "rtuf_expand_mask_bits",
+    "rtuf_filter_batch_device_bits_u16", "rtuf_expand_mask_bits", "rtuf_order_stream_after_batches",
 ]
 
 
@@ -36,7 +36,8 @@ class Params(ctypes.Structure):
     _fields_ = [("near_plane", ctypes.c_float), ("far_plane", ctypes.c_float),
                 ("depth_distance_threshold", ctypes.c_float), ("filter_replace_value", ctypes.c_float),
                 ("flags", ctypes.c_uint32), ("bin_capacity", ctypes.c_uint32),
-                ("max_inflight_streams", ctypes.c_uint32), ("pipelines", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 4)]
+                ("max_inflight_streams", ctypes.c_uint32), ("pipelines", ctypes.c_uint32),
+                ("raster_lanes", ctypes.c_uint32), ("memory_limit_mb", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 2)]
 
 
 class Stats(ctypes.Structure):
@@ -53,7 +54,9 @@ class Stats(ctypes.Structure):
                 ("cover_tiles", ctypes.c_uint32), ("exact_tiles", ctypes.c_uint32),
                 ("work_items", ctypes.c_uint32), ("zero_survivor_items", ctypes.c_uint32),
                 ("cover_pass", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
-                ("raster_atomics", ctypes.c_uint64), ("drawn_pixels", ctypes.c_uint64)]
+                ("raster_atomics", ctypes.c_uint64), ("drawn_pixels", ctypes.c_uint64),
+                ("raster_lanes", ctypes.c_uint32), ("launch_group", ctypes.c_uint32), ("groups_last_batch", ctypes.c_uint32),
+                ("graphs_enabled", ctypes.c_uint32), ("graph_hits", ctypes.c_uint64), ("graph_misses", ctypes.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
@@ -158,6 +161,7 @@ def load_library(path=None):
     lib.rtuf_filter_batch_device_bits.argtypes = [vp, ci, vp, vp]
     lib.rtuf_filter_batch_device_bits_u16.argtypes = [vp, ci, vp, vp]
     lib.rtuf_expand_mask_bits.argtypes = [vp, ci, vp, ci, ci, ctypes.c_float, vp, vp]
+    lib.rtuf_order_stream_after_batches.argtypes = [vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -397,7 +401,14 @@ class Context:
         self._check(self._lib.rtuf_sync(self._h))
 
     def stream_handle(self):
+        """hipStream_t of a context with ONE raster lane and one pipeline; None for every other context (never hand that
+        None to HIP as a stream: use order_stream_after_batches)."""
         return self._lib.rtuf_stream(self._h)
+
+    def order_stream_after_batches(self, hip_stream=None):
+        """Makes `hip_stream` (an int / c_void_p hipStream_t; None = the legacy default stream) wait on the device for every
+        batch enqueued so far, whatever the number of lanes and pipelines."""
+        self._check(self._lib.rtuf_order_stream_after_batches(self._h, ctypes.c_void_p(hip_stream) if hip_stream else None))
 
     def enable_timing(self, on=True):
         # True/1: every stage; 2: only around the tile (and compare) kernel; False/0: off

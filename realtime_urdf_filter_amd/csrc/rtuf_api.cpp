@@ -32,6 +32,9 @@ struct HostDraw {
 };
 struct HostLink { std::vector<HostDraw> draws; };
 static constexpr int kMaxInflight = 2;      // device batches that may be in flight at once
+static constexpr int kMaxLanes = 2;         // raster lanes of a context (rtuf_params.raster_lanes)
+static constexpr int kSplitMin = 32;        // batches of at least this many streams are split over the lanes; smaller ones
+                                            // take one lane each, in turn (their cost is launches, not kernel time)
 
 struct Kinematics {               // on-device forward kinematics of one model
   int n_frames = 0, camera_frame = -1, max_depth = 0;
@@ -68,7 +71,6 @@ inline bool flags_valid(uint32_t flags)
 
 struct rtuf_context {
   int device = 0;
-  hipStream_t stream = nullptr;
   int width = 0, height = 0, tiles_x = 0, tiles_y = 0, max_streams = 0;
   rtuf_params params{};
   std::string error;
@@ -101,15 +103,34 @@ struct rtuf_context {
   uint64_t* h_model_mask = nullptr;    // pinned [max_streams]
   uint64_t* d_model_mask = nullptr;
 
-  // rasteriser working set
-  int group = 0;                       // in-flight streams per launch group
+  // Rasteriser working set.  A RASTER LANE is a HIP stream plus the arrays one launch group is rasterised through (tile
+  // bins, clip list, many-tile list, work list); the launch groups of a batch alternate between the lanes, so group B's
+  // set-up kernel runs under group A's tile kernel and every kernel's ramp, tail and launch gap is filled by the other
+  // lane -- what two contexts of half the streams gave a caller by hand (509 k instead of 455 k frames/s on the 256-stream
+  // VGA workload), now inside one context and with bins for two quarter-batches instead of two halves.  Kernels of one lane
+  // are ordered by its stream, which is all the hand-over its arrays need; lanes share nothing that is written per group.
+  struct Lane {
+    hipStream_t stream = nullptr;
+    PackedTri* d_bins = nullptr; BinHeader* d_bin_hdr = nullptr;
+    Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
+    ClipItem* d_clip_list = nullptr;
+    float4* d_clip_spill = nullptr;
+    BigRec* d_big_list = nullptr;                                // many-tile records (per counter shard), see bigrec_kernel
+    WorkItem* d_items[kMaxInflight] = {};                        // the launch group's set-up work list (cull_kernel -> setup_kernel), one per
+                                                                 // batch slot: with one lane a batch's first cull runs in its pose stage,
+                                                                 // under the set-up kernel of the batch before it
+    float* d_zsurface = nullptr;
+  };
+  Lane lane[kMaxLanes];
+  int n_lanes = 1;
+  int next_lane = 0;                   // lane of the next batch that is not split
+  int last_lane = 0;                   // lane of the newest batch's last group (debug read-back of the z-surface)
+  int group = 0;                       // streams per launch group at most (= streams a lane's bins are sized for)
+  int max_groups = 1;                  // launch groups a batch of max_streams streams is split into (sizes the counter blocks)
   uint32_t capacity = 0, fcapacity = 0, clip_capacity = 0;
-  PackedTri* d_bins = nullptr; BinHeader* d_bin_hdr = nullptr;
-  Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
-  ClipItem* d_clip_list = nullptr; uint32_t items_hint = 0;
-  float4* d_clip_spill = nullptr;
-  BigRec* d_big_list = nullptr; uint32_t big_capacity = 0;      // many-tile records (per counter shard), see bigrec_kernel
-  float* d_zsurface = nullptr;
+  uint32_t big_capacity = 0;           // many-tile list, per counter shard
+  uint32_t items_hint = 0; int items_hint_streams = 0;      // longest work list of the last batch's groups, and their size
+  size_t memory_budget = 0;            // upper bound of the lanes' tile bins (rtuf_params.memory_limit_mb or a third of the free memory)
   // every device allocation of the context goes through dev_alloc / dev_free: rtuf_stats.device_bytes is their sum
   std::unordered_map<void*, size_t> dev_blocks;
   size_t device_bytes = 0;
@@ -129,8 +150,10 @@ struct rtuf_context {
     bool active = false;
     int n = 0; const float* depth = nullptr; float* masked = nullptr; uint8_t* mask = nullptr; bool u16 = false;
     uint32_t* bits = nullptr;                // mask-only output (1 bit per pixel) instead of masked / mask
-    Counters* h_counters = nullptr;          // pinned; filled by the copy that ends the batch
-    hipEvent_t done = nullptr;               // recorded after that copy
+    Counters* h_counters = nullptr;          // pinned [max_groups]: one block per launch group, filled by the copies that end the batch
+    hipEvent_t done[kMaxLanes] = {};         // recorded on each lane after its copy
+    uint32_t lanes_used = 0;                 // bit l: the batch has launch groups on lane l
+    int n_groups = 0;                        // launch groups of the batch
     std::vector<hipEvent_t> events;          // stage timing
     std::vector<int> q_idx;                  // per model: joint-position staging buffer
     int cam_idx = 0, link_idx = 0;           // camera / link-matrix staging sets
@@ -138,7 +161,7 @@ struct rtuf_context {
     // writes only buffers of its own slot, so it overlaps the raster kernels of the batch before it.
     Camera* d_cams = nullptr; double* d_link_tf = nullptr;
     float* d_mvp = nullptr; BgInfo* d_bg = nullptr;
-    WorkItem* d_items = nullptr; Counters* d_counters = nullptr;
+    Counters* d_counters = nullptr;          // [max_groups]
     bool dirty_cams = true, dirty_link_tf = true;
     int uploaded_streams = 0;
     hipEvent_t posed = nullptr;              // recorded on the side stream after the pose stage
@@ -147,7 +170,7 @@ struct rtuf_context {
     static constexpr int kGraphs = 6;
     struct { uint64_t hash = 0; hipGraphExec_t exec = nullptr; } graphs[kGraphs];
     int graph_next = 0;
-    uint32_t setup_grid = 0xffffffffu;       // work items the set-up launch covered (single-group batches)
+    std::vector<uint32_t> setup_grid;        // per launch group: work items its set-up launch covered (0xffffffff = the worst case)
     bool cover_pass = true;                  // this batch runs the cover pass (decided when it is first enqueued, kept for re-runs)
     int timing = 0;                          // event timing of this batch: 0 none, 1 every stage, 2 tile/compare kernel only
     // Host-plane batches (rtuf_filter_batch*): device staging of this slot, the caller's planes, and the
@@ -157,6 +180,7 @@ struct rtuf_context {
     uint32_t* st_bits = nullptr; size_t st_bits_streams = 0;
     std::vector<void*> h_masked, h_mask, h_bits;
     hipEvent_t uploaded = nullptr, downloaded = nullptr;
+    bool wait_upload = false;                // the lanes wait for `uploaded` before the first kernel that reads the planes
   };
   Batch batch[kMaxInflight];
   hipStream_t side = nullptr;                // pose stages (see Batch)
@@ -168,7 +192,8 @@ struct rtuf_context {
   // batch's raster kernels, which a graph on the main stream would serialise (batch = 1: 75 us plain, 94 us as a graph).
   // Cleared when the runtime refuses stream capture / instantiation.
   bool graphs_ok = false;
-  uint32_t graph_hits = 0, graph_misses = 0; // replays / captures: a caller that never repeats an argument set (fresh output buffers
+  uint32_t graph_evictions = 0;              // captures of the current 64-batch window that replaced a live cache entry
+  uint64_t graph_hits = 0, graph_misses = 0; // replays / captures: a caller that never repeats an argument set (fresh output buffers
                                              // every frame) would pay a capture + instantiate per batch -- then graphs are switched off
   // The cover pass (bigrec_kernel<0> + the cover-aware tile kernel) pays where triangles cover whole tiles -- walls, anything
   // close to the lens -- and costs 3 % where none do (a finely tessellated robot at arm's length).  It is an optimisation
@@ -233,11 +258,25 @@ static void dev_free(rtuf_context* c, T*& p)
   p = nullptr;
 }
 
-// A working buffer of the rasteriser is too small for the batch in flight: the new one is allocated BEFORE the old one is
-// freed whenever both fit (a failed allocation then leaves the context as it was, and the call fails with RTUF_ERR_OOM);
-// only when they do not fit together the old one goes first, and a failure after that marks the context unusable.
+// Launch groups a batch of n streams is split into: as many as the lanes' bins need (c->group streams each at most), and,
+// with two lanes, an even number (>= 2) for batches worth splitting, so that both lanes get the same amount of work.
+static int groups_for(const rtuf_context* c, int n)
+{
+  int k = (n + c->group - 1) / std::max(c->group, 1);
+  if (c->n_lanes > 1 && n >= kSplitMin) k = std::max(2, k + (k & 1));
+  return std::max(k, 1);
+}
+
+static void sync_lanes(rtuf_context* c)
+{
+  for (int l = 0; l < c->n_lanes; l++) if (c->lane[l].stream) (void)hipStreamSynchronize(c->lane[l].stream);
+}
+
+// A working buffer of the rasteriser is too small for the batch in flight (its contents are not needed: the batch is run
+// again).  The new one is allocated BEFORE the old one is freed whenever both fit; when they do not, the old one goes first.
+// On failure the buffer is gone (nullptr) and the caller decides: smaller launch groups, or give up.
 template <typename T>
-static int regrow(rtuf_context* c, T*& buf, size_t new_bytes, const char* what)
+static hipError_t realloc_dev(rtuf_context* c, T*& buf, size_t new_bytes)
 {
   T* fresh = nullptr;
   hipError_t e = dev_alloc(c, &fresh, new_bytes);
@@ -245,37 +284,90 @@ static int regrow(rtuf_context* c, T*& buf, size_t new_bytes, const char* what)
     (void)hipGetLastError();
     dev_free(c, buf);
     e = dev_alloc(c, &fresh, new_bytes);
-    if (e != hipSuccess) {
-      c->broken = true;
-      return c->fail(RTUF_ERR_OOM, "growing the %s to %zu bytes failed: %s", what, new_bytes, hipGetErrorString(e));
-    }
+    if (e != hipSuccess) { (void)hipGetLastError(); return e; }
   } else {
     dev_free(c, buf);
   }
   buf = fresh;
+  return hipSuccess;
+}
+template <typename T>
+static int regrow(rtuf_context* c, T*& buf, size_t new_bytes, const char* what)
+{
+  const hipError_t e = realloc_dev(c, buf, new_bytes);
+  if (e != hipSuccess) {
+    c->broken = true;
+    return c->fail(RTUF_ERR_OOM, "growing the %s to %zu bytes failed: %s", what, new_bytes, hipGetErrorString(e));
+  }
   c->stats.regrowths++;
+  return RTUF_OK;
+}
+
+static size_t lane_bins_bytes(const rtuf_context* c, int G, uint32_t cap, uint32_t fcap)
+{
+  return (size_t)G * (size_t)c->tiles_x * c->tiles_y * ((size_t)cap * sizeof(PackedTri) + (size_t)fcap * sizeof(Frag));
+}
+
+// The per-batch counter blocks (one per launch group) follow the number of groups a full batch is split into.
+static int alloc_counter_blocks(rtuf_context* c)
+{
+  c->max_groups = groups_for(c, c->max_streams);
+  for (auto& b : c->batch) {
+    dev_free(c, b.d_counters);
+    if (b.h_counters) { (void)hipHostFree(b.h_counters); b.h_counters = nullptr; }
+    HIP_TRY(c, hipHostMalloc(&b.h_counters, sizeof(Counters) * (size_t)c->max_groups));
+    HIP_TRY(c, dev_alloc(c, &b.d_counters, sizeof(Counters) * (size_t)c->max_groups));
+    HIP_TRY(c, hipMemset(b.d_counters, 0, sizeof(Counters) * (size_t)c->max_groups));
+  }
   return RTUF_OK;
 }
 
 // Bins sized from what the batch asked for: a quarter above the fullest record / fragment bin, in steps of 256 / 1024 entries
 // (never smaller than they are).  One allocation holds what used to be sized for the worst tile any scene could have.
+// When the larger bins do not fit -- the memory limit of the context, or what the device has left (a shared GPU, several
+// pipelines, 720p with many streams) -- the LAUNCH GROUP shrinks instead: the same bytes then hold deeper bins for fewer
+// streams, a batch is rasterised in more, smaller launches, and nothing fails.  Only when not even one stream's bins can
+// be had the context is lost.
 static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
 {
-  const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
   auto round_up = [](uint64_t v, uint64_t q) { return (uint32_t)std::min<uint64_t>(((v + q - 1) / q) * q, 0x7fffffffu); };
   const uint32_t cap = std::max(c->capacity, needed > c->capacity ? round_up((uint64_t)needed + needed / 4, 256) : c->capacity);
   const uint32_t fcap = std::max(c->fcapacity, fneeded > c->fcapacity ? round_up((uint64_t)fneeded + fneeded / 4, 1024) : c->fcapacity);
-  if ((size_t)c->group * tiles * ((size_t)cap * sizeof(PackedTri) + (size_t)fcap * sizeof(Frag)) > ((size_t)200 << 30))
-    return c->fail(RTUF_ERR_CAPACITY, "bin capacity %u/%u too large", cap, fcap);
-  if (cap != c->capacity) {
-    const int rc = regrow(c, c->d_bins, (size_t)c->group * tiles * cap * sizeof(PackedTri), "record bins");
-    if (rc != RTUF_OK) return rc;
-    c->capacity = cap;
+  if (cap == c->capacity && fcap == c->fcapacity) return RTUF_OK;
+  // what may be spent: the context's limit, and no more than the device can give once the present bins are returned
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+  const size_t held = (size_t)c->n_lanes * lane_bins_bytes(c, c->group, c->capacity, c->fcapacity);
+  size_t budget = (size_t)((double)(free_b + held) * 0.9);
+  if (c->params.memory_limit_mb) budget = std::min(budget, (size_t)c->params.memory_limit_mb << 20);
+  int G = c->group;
+  while (G > 1 && (size_t)c->n_lanes * lane_bins_bytes(c, G, cap, fcap) > budget) G = (G + 1) / 2;
+  for (;;) {
+    hipError_t e = hipSuccess;
+    for (int l = 0; l < c->n_lanes && e == hipSuccess; l++) {
+      rtuf_context::Lane& ln = c->lane[l];
+      // (a smaller group with deeper bins may fit the allocation that is there)
+      const size_t want = (size_t)G * c->tiles_x * c->tiles_y * (size_t)cap * sizeof(PackedTri);
+      const size_t fwant = (size_t)G * c->tiles_x * c->tiles_y * (size_t)fcap * sizeof(Frag);
+      auto have = [&](void* q) { auto it = c->dev_blocks.find(q); return (q && it != c->dev_blocks.end()) ? it->second : (size_t)0; };
+      if (have(ln.d_bins) < want) e = realloc_dev(c, ln.d_bins, want);
+      if (e == hipSuccess && have(ln.d_fbins) < fwant) e = realloc_dev(c, ln.d_fbins, fwant);
+    }
+    if (e == hipSuccess) break;
+    if (G == 1) {
+      c->broken = true;
+      return c->fail(RTUF_ERR_OOM, "growing the tile bins to %u + %u entries failed even for launch groups of one stream: %s", cap, fcap, hipGetErrorString(e));
+    }
+    G = (G + 1) / 2;            // the device has less than it said: halve the launch group and try again
   }
-  if (fcap != c->fcapacity) {
-    const int rc = regrow(c, c->d_fbins, (size_t)c->group * tiles * fcap * sizeof(Frag), "fragment bins");
-    if (rc != RTUF_OK) return rc;
-    c->fcapacity = fcap;
+  c->stats.regrowths++;
+  c->capacity = cap;
+  c->fcapacity = fcap;
+  if (G != c->group) {
+    c->group = G;
+    c->items_hint = 0;
+    const int rc = alloc_counter_blocks(c);
+    if (rc != RTUF_OK) { c->broken = true; return rc; }
   }
   return RTUF_OK;
 }
@@ -362,6 +454,10 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
     snprintf(g_create_error, sizeof g_create_error, "unknown rtuf_params.flags bits 0x%x", params->flags & ~kKnownFlags);
     return RTUF_ERR_INVALID;
   }
+  if (params && params->raster_lanes > (uint32_t)kMaxLanes) {
+    snprintf(g_create_error, sizeof g_create_error, "raster_lanes = %u: at most %d", params->raster_lanes, kMaxLanes);
+    return RTUF_ERR_INVALID;
+  }
   {
     // the kernels exist for gfx950 (MI350X / MI355X) only: on any other device the first launch would fail with an opaque
     // "invalid device function"
@@ -385,7 +481,8 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
   // (a front context of several pipelines owns no streams of its own: HIP multiplexes streams onto a few hardware queues,
   // and two pipelines whose main streams share a queue do not overlap at all)
   const bool front = c->params.pipelines > 1;
-  if (e == hipSuccess && !front) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  c->n_lanes = c->params.raster_lanes ? (int)c->params.raster_lanes : kMaxLanes;
+  for (int l = 0; l < c->n_lanes && e == hipSuccess && !front; l++) e = hipStreamCreateWithFlags(&c->lane[l].stream, hipStreamNonBlocking);
   if (e == hipSuccess && !front) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
   if (e != hipSuccess) {
     snprintf(g_create_error, sizeof g_create_error, "hip init failed: %s", hipGetErrorString(e));
@@ -394,8 +491,10 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
   }
   if (c->params.pipelines > 1) {
     if (c->params.pipelines > 4) { snprintf(g_create_error, sizeof g_create_error, "pipelines = %u: at most 4", c->params.pipelines); rtuf_destroy(c); return RTUF_ERR_INVALID; }
+    // (the pipelines are the overlap here: every child is a context of one raster lane, whose small batches can replay graphs)
     rtuf_params kp = c->params;
     kp.pipelines = 0;
+    kp.raster_lanes = 1;
     for (uint32_t i = 0; i < c->params.pipelines; i++) {
       rtuf_context* k = nullptr;
       const int rc = rtuf_create(&k, device_id, width, height, max_streams, &kp);
@@ -413,8 +512,12 @@ static void free_frame_buffers(rtuf_context* c)
   hipSetDevice(c->device);
   auto hfree = [](auto*& p) { if (p) { hipHostFree(p); p = nullptr; } };
   dev_free(c, c->d_model_mask);
-  for (auto& b : c->batch) { dev_free(c, b.d_cams); dev_free(c, b.d_link_tf); dev_free(c, b.d_mvp); dev_free(c, b.d_bg); dev_free(c, b.d_items); dev_free(c, b.d_counters); }
-  dev_free(c, c->d_bins); dev_free(c, c->d_bin_hdr); dev_free(c, c->d_fbins); dev_free(c, c->d_fbin_count); dev_free(c, c->d_clip_list); dev_free(c, c->d_clip_spill); dev_free(c, c->d_big_list); dev_free(c, c->d_zsurface);
+  for (auto& b : c->batch) { dev_free(c, b.d_cams); dev_free(c, b.d_link_tf); dev_free(c, b.d_mvp); dev_free(c, b.d_bg); dev_free(c, b.d_counters); }
+  for (auto& ln : c->lane) {
+    dev_free(c, ln.d_bins); dev_free(c, ln.d_bin_hdr); dev_free(c, ln.d_fbins); dev_free(c, ln.d_fbin_count); dev_free(c, ln.d_clip_list);
+    dev_free(c, ln.d_clip_spill); dev_free(c, ln.d_big_list); dev_free(c, ln.d_zsurface);
+    for (auto*& it : ln.d_items) dev_free(c, it);
+  }
   for (auto& b : c->batch) { dev_free(c, b.st_depth); dev_free(c, b.st_masked); dev_free(c, b.st_mask); b.st_streams = 0; dev_free(c, b.st_bits); b.st_bits_streams = 0; }
   for (auto*& p : c->ring_cams) hfree(p);
   for (auto*& p : c->ring_link_tf) hfree(p);
@@ -430,7 +533,7 @@ void rtuf_destroy(rtuf_context* c)
   c->kids.clear();
   hipSetDevice(c->device);
   if (c->side) hipStreamSynchronize(c->side);
-  if (c->stream) hipStreamSynchronize(c->stream);
+  sync_lanes(c);
   if (c->h2d) hipStreamSynchronize(c->h2d);
   if (c->d2h) hipStreamSynchronize(c->d2h);
   for (HostModel& m : c->models) {
@@ -445,7 +548,7 @@ void rtuf_destroy(rtuf_context* c)
   dev_free(c, c->d_cverts); dev_free(c, c->d_ctris); dev_free(c, c->d_corder); dev_free(c, c->d_chunks); dev_free(c, c->d_draws);
   for (auto& b : c->batch) {
     for (hipEvent_t ev : b.events) hipEventDestroy(ev);
-    if (b.done) hipEventDestroy(b.done);
+    for (hipEvent_t ev : b.done) if (ev) hipEventDestroy(ev);
     if (b.posed) hipEventDestroy(b.posed);
     for (auto& g : b.graphs) if (g.exec) hipGraphExecDestroy(g.exec);
     if (b.uploaded) hipEventDestroy(b.uploaded);
@@ -456,7 +559,7 @@ void rtuf_destroy(rtuf_context* c)
   if (c->h2d) hipStreamDestroy(c->h2d);
   if (c->d2h) hipStreamDestroy(c->d2h);
   if (c->side) hipStreamDestroy(c->side);
-  if (c->stream) hipStreamDestroy(c->stream);
+  for (auto& ln : c->lane) if (ln.stream) hipStreamDestroy(ln.stream);
   delete c;
 }
 
@@ -478,17 +581,14 @@ int rtuf_set_params(rtuf_context* c, const rtuf_params* p)
   if (c->finalized && p->far_plane != c->params.far_plane)
     return c->fail(RTUF_ERR_STATE, "far_plane is fixed once the models are finalized (was %g)", (double)c->params.far_plane);
   const uint32_t keep_cap = c->params.bin_capacity, keep_inf = c->params.max_inflight_streams, keep_pipes = c->params.pipelines;
-  const bool two_before = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
+  const uint32_t keep_lanes = c->params.raster_lanes, keep_limit = c->params.memory_limit_mb;
   c->params = *p;
   c->params.bin_capacity = keep_cap;
   c->params.max_inflight_streams = keep_inf;
   c->params.pipelines = keep_pipes;
-  const bool two_now = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
-  if (c->finalized && two_now && !two_before && !c->d_zsurface) {
-    hipSetDevice(c->device);
-    HIP_TRY(c, dev_alloc(c, &c->d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));
-  }
-  return RTUF_OK;
+  c->params.raster_lanes = keep_lanes;
+  c->params.memory_limit_mb = keep_limit;
+  return RTUF_OK;      // (two-kernel mode's z-surfaces are allocated by the first batch that needs them)
 }
 
 // ---- geometry -------------------------------------------------------------------------
@@ -557,18 +657,15 @@ static int alloc_frame_buffers(rtuf_context* c)
   c->cam_ring = rtuf_context::StageRing(); c->link_ring = rtuf_context::StageRing();
   c->h_cams = c->ring_cams[0]; c->h_link_tf = c->ring_link_tf[0];
   HIP_TRY(c, hipHostMalloc(&c->h_model_mask, sizeof(uint64_t) * N));
-  for (auto& b : c->batch) {
-    HIP_TRY(c, hipHostMalloc(&b.h_counters, sizeof(Counters)));
-    if (!b.done) HIP_TRY(c, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
-  }
+  for (auto& b : c->batch)
+    for (int l = 0; l < c->n_lanes; l++)
+      if (!b.done[l]) HIP_TRY(c, hipEventCreateWithFlags(&b.done[l], hipEventDisableTiming));
   HIP_TRY(c, dev_alloc(c, &c->d_model_mask, sizeof(uint64_t) * N));
   for (auto& b : c->batch) {
     HIP_TRY(c, dev_alloc(c, &b.d_cams, sizeof(Camera) * N));
     HIP_TRY(c, dev_alloc(c, &b.d_link_tf, sizeof(double) * 16 * L * N));
     HIP_TRY(c, dev_alloc(c, &b.d_mvp, sizeof(float) * 16 * (size_t)(c->n_draws + 1) * N));
     HIP_TRY(c, dev_alloc(c, &b.d_bg, sizeof(BgInfo) * N));
-    HIP_TRY(c, dev_alloc(c, &b.d_counters, sizeof(Counters)));
-    HIP_TRY(c, hipMemset(b.d_counters, 0, sizeof(Counters)));
     b.dirty_cams = b.dirty_link_tf = true; b.uploaded_streams = 0;
     if (!b.posed) HIP_TRY(c, hipEventCreateWithFlags(&b.posed, hipEventDisableTiming));
   }
@@ -587,39 +684,44 @@ static int alloc_frame_buffers(rtuf_context* c)
     c->h_model_mask[s] = ~0ull;
   }
   // rasteriser working set
-  // one launch group for up to 1024 streams: kernels of 4x the work lose 4x less to their ramp and tail
-  // (1024 streams in one group: 522 k frames/s, in four groups of 256: 460 k)
-  int G = c->params.max_inflight_streams ? (int)c->params.max_inflight_streams : 1024;
+  // Launch group = the streams one lane's bins are sized for.  One lane: the whole batch up to 1024 streams (kernels of 4x
+  // the work lose 4x less to their ramp and tail: 1024 streams in one group 522 k frames/s, in four groups of 256 one
+  // after the other 460 k).  Two lanes: a quarter of the streams -- a full batch then is four groups, two per lane, the
+  // lanes' kernels fill each other's ramps and tails, and the bins are half of what one group for all streams would take.
+  int G = c->params.max_inflight_streams ? (int)c->params.max_inflight_streams
+                                         : (c->n_lanes > 1 && N >= kSplitMin ? std::max((N + 3) / 4, 16) : 1024);
   G = std::min(G, N);
   // Bins: fixed capacity per (stream, tile), direct addressing (one atomicAdd gives the slot: anything cleverer -- paged
   // bins were built and measured, DESIGN.md section 4b -- costs the two big kernels 8 to 24 %).  What is NOT fixed any more is
-  // the size: 1024 records + 4096 fragments per bin to start with (64 KiB: 2.5 GB for 256 VGA streams), grown on the first
-  // batch to a quarter above the fullest bin that batch produced (the 250 k-triangle robot: 3840 + 13568, 8.7 GB; round 2
-  // reserved 8192 + 32768 = 19.6 GB whatever the scene).  rtuf_params.bin_capacity fixes the starting point.
+  // the size: 1024 records + 4096 fragments per bin to start with (64 KiB per bin), grown on the first
+  // batch to a quarter above the fullest bin that batch produced (the 250 k-triangle robot: 3840 + 13568; round 2
+  // reserved 8192 + 32768 whatever the scene).  rtuf_params.bin_capacity fixes the starting point.
   uint32_t cap = c->params.bin_capacity ? c->params.bin_capacity : 1024u;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
-  const size_t budget = std::max(free_b / 3, (size_t)1 << 30);
-  while (G > 1 && (size_t)G * tiles * cap * (sizeof(PackedTri) + 4 * sizeof(Frag)) > budget) G = (G + 1) / 2;
-  c->group = G;
+  c->memory_budget = std::max(free_b / 3, (size_t)1 << 30);
+  if (c->params.memory_limit_mb) c->memory_budget = (size_t)c->params.memory_limit_mb << 20;
   c->capacity = cap;
   c->fcapacity = std::max<uint32_t>(4 * cap, 1024);   // 8-byte fragments of all boxes up to 4x4 pixel centres
+  while (G > 1 && (size_t)c->n_lanes * lane_bins_bytes(c, G, c->capacity, c->fcapacity) > c->memory_budget) G = (G + 1) / 2;
+  c->group = G;
   c->clip_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 8192 / kCounterShards, 1024), (size_t)1 << 22);   // per shard
-  HIP_TRY(c, dev_alloc(c, &c->d_bins, (size_t)G * tiles * cap * sizeof(PackedTri)));
-  HIP_TRY(c, dev_alloc(c, &c->d_bin_hdr, (size_t)G * tiles * sizeof(BinHeader)));
-  HIP_TRY(c, dev_alloc(c, &c->d_fbins, (size_t)G * tiles * c->fcapacity * sizeof(Frag)));
-  HIP_TRY(c, dev_alloc(c, &c->d_fbin_count, (size_t)G * tiles * sizeof(uint32_t)));
-  HIP_TRY(c, hipMemsetAsync(c->d_fbin_count, 0, (size_t)G * tiles * sizeof(uint32_t), c->stream));
-  launch_init_headers(c->d_bin_hdr, (size_t)G * tiles, c->stream);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, dev_alloc(c, &c->d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
-  HIP_TRY(c, dev_alloc(c, &c->d_clip_spill, clip_spill_bytes(c->clip_capacity)));
   c->big_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 64, 1024), (size_t)1 << 20);                 // per shard
-  HIP_TRY(c, dev_alloc(c, &c->d_big_list, (size_t)c->big_capacity * kCounterShards * sizeof(BigRec)));
-  for (auto& b : c->batch) HIP_TRY(c, dev_alloc(c, &b.d_items, (size_t)c->n_chunks * (size_t)max_items_per_chunk(G) * sizeof(WorkItem)));
-  if (c->params.flags & RTUF_FLAG_TWO_KERNEL)
-    HIP_TRY(c, dev_alloc(c, &c->d_zsurface, (size_t)G * c->width * c->height * sizeof(float)));
-  return RTUF_OK;
+  for (int l = 0; l < c->n_lanes; l++) {
+    rtuf_context::Lane& ln = c->lane[l];
+    HIP_TRY(c, dev_alloc(c, &ln.d_bins, (size_t)G * tiles * cap * sizeof(PackedTri)));
+    HIP_TRY(c, dev_alloc(c, &ln.d_bin_hdr, (size_t)G * tiles * sizeof(BinHeader)));
+    HIP_TRY(c, dev_alloc(c, &ln.d_fbins, (size_t)G * tiles * c->fcapacity * sizeof(Frag)));
+    HIP_TRY(c, dev_alloc(c, &ln.d_fbin_count, (size_t)G * tiles * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(ln.d_fbin_count, 0, (size_t)G * tiles * sizeof(uint32_t), ln.stream));
+    launch_init_headers(ln.d_bin_hdr, (size_t)G * tiles, ln.stream);
+    HIP_TRY(c, hipStreamSynchronize(ln.stream));
+    HIP_TRY(c, dev_alloc(c, &ln.d_clip_list, (size_t)c->clip_capacity * kCounterShards * sizeof(ClipItem)));
+    HIP_TRY(c, dev_alloc(c, &ln.d_clip_spill, clip_spill_bytes(c->clip_capacity)));
+    HIP_TRY(c, dev_alloc(c, &ln.d_big_list, (size_t)c->big_capacity * kCounterShards * sizeof(BigRec)));
+    for (auto*& it : ln.d_items) HIP_TRY(c, dev_alloc(c, &it, (size_t)c->n_chunks * (size_t)max_items_per_chunk(G) * sizeof(WorkItem)));
+  }
+  return alloc_counter_blocks(c);
 }
 
 int rtuf_finalize_models(rtuf_context* c)
@@ -1093,7 +1195,8 @@ int rtuf_debug_read_poses(rtuf_context* c, int n, double* link_tf_out, double* c
   if (!c) return RTUF_ERR_INVALID;
   if (!c->finalized || n <= 0 || n > c->max_streams) return c->fail(RTUF_ERR_INVALID, "bad arguments");
   hipSetDevice(c->device);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->side));
+  sync_lanes(c);
   const size_t L = (size_t)std::max(c->n_links, 1);
   if (link_tf_out) HIP_TRY(c, hipMemcpy(link_tf_out, c->batch[c->last_slot].d_link_tf, sizeof(double) * 16 * L * n, hipMemcpyDeviceToHost));
   if (cam_tf_out) {
@@ -1119,7 +1222,7 @@ static hipEvent_t get_event(rtuf_context::Batch& b, size_t i)
 struct BatchPlan {
   std::vector<FkArgs> fks;
   PoseArgs pa{};
-  struct Group { SetupArgs sa{}; TileArgs ta{}; CompareArgs ca{}; bool compare = false; };
+  struct Group { SetupArgs sa{}; TileArgs ta{}; CompareArgs ca{}; bool compare = false; int lane = 0; };
   std::vector<Group> groups;
   bool cover_pass = true;
   uint64_t hash() const
@@ -1128,47 +1231,64 @@ struct BatchPlan {
     auto mix = [&h](const void* p, size_t n) { const unsigned char* q = static_cast<const unsigned char*>(p); for (size_t i = 0; i < n; i++) { h ^= q[i]; h *= 1099511628211ull; } };
     for (const FkArgs& f : fks) mix(&f, sizeof f);
     mix(&pa, sizeof pa);
-    for (const Group& g : groups) { mix(&g.sa, sizeof g.sa); mix(&g.ta, sizeof g.ta); if (g.compare) mix(&g.ca, sizeof g.ca); }
+    for (const Group& g : groups) { mix(&g.sa, sizeof g.sa); mix(&g.ta, sizeof g.ta); if (g.compare) mix(&g.ca, sizeof g.ca); mix(&g.lane, sizeof g.lane); }
     return h ^ (uint64_t)fks.size() << 56 ^ (uint64_t)groups.size() << 48 ^ (uint64_t)cover_pass << 47;
   }
 };
 
 static constexpr int kGraphMaxStreams = 32;     // batches up to this size replay a captured hipGraph (timing off)
 
-// Enqueues the kernels of a plan: pose stage (forward kinematics, matrix stacks, cull of the first group) on `sp`,
-// raster stage on `st`, which waits for the pose stage through the batch's `posed` event.
-static int issue_plan(rtuf_context* c, rtuf_context::Batch& b, const BatchPlan& plan, hipStream_t sp, hipStream_t st, uint32_t items_hint, size_t& ev)
+// Timing events of a batch: start and end of the pose stage, the end of every lane's part, and five per launch group --
+// E0 before its first kernel (mode 1: the cull; mode 2: the set-up kernel), E1 after the set-up kernel (mode 2), E2 after
+// clip + many-tile kernels, E3 after the tile kernel, E4 after the compare kernel (two-kernel mode).
+enum { kEvStart = 0, kEvPoseEnd = 1, kEvLaneEnd = 2, kEvGroup0 = 2 + kMaxLanes, kEvPerGroup = 5 };
+
+// Enqueues the kernels of a plan: pose stage (forward kinematics, matrix stacks) on `sp`, then every launch group on the
+// stream of its lane, which waits for the pose stage through the batch's `posed` event.  With one lane the first group's
+// cull still belongs to the pose stage (it then runs under the previous batch's raster kernels).
+static int issue_plan(rtuf_context* c, rtuf_context::Batch& b, const BatchPlan& plan, hipStream_t sp, bool worst_case_grid)
 {
   const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
+  auto mark = [&](size_t i, hipStream_t s) { hipEventRecord(get_event(b, i), s); };
+  if (b.timing == 1) mark(kEvStart, sp);
   for (const FkArgs& fa : plan.fks) launch_fk(fa, sp);
   launch_pose(plan.pa, sp);
-  if (b.timing == 1) hipEventRecord(get_event(b, ev++), sp);
-  const bool single_group = plan.groups.size() == 1;
+  if (b.timing == 1) mark(kEvPoseEnd, sp);
+  const bool cull_in_pose = c->n_lanes == 1;
+  if (cull_in_pose) launch_cull(plan.groups[0].sa, sp);
+  HIP_TRY(c, hipEventRecord(b.posed, sp));
+  for (int l = 0; l < c->n_lanes; l++)
+    if (b.lanes_used >> l & 1u) HIP_TRY(c, hipStreamWaitEvent(c->lane[l].stream, b.posed, 0));
   for (size_t g = 0; g < plan.groups.size(); g++) {
     const BatchPlan::Group& gr = plan.groups[g];
-    if (g > 0) launch_reset_clip(b.d_counters, st);          // the clip list is per group
-    // the first group's cull belongs to the pose stage; the raster kernels wait for that stage here
-    launch_cull(gr.sa, g == 0 ? sp : st);
-    if (g == 0) {
-      HIP_TRY(c, hipEventRecord(b.posed, sp));
-      HIP_TRY(c, hipStreamWaitEvent(st, b.posed, 0));
-    }
-    // a batch of one group reads its work-list length back with the counters: instead of sweeping the
-    // part of the list beyond the (estimated) grid with a second launch, it is run again if the estimate
-    // was too small (retire_oldest); batches of several groups reuse the counter, so they sweep
-    if (b.timing >= 2) hipEventRecord(get_event(b, ev++), st);     // (after the wait for the pose stage: set-up time only)
-    const uint32_t grid = launch_setup(gr.sa, items_hint, !single_group, st);
-    b.setup_grid = single_group ? grid : 0xffffffffu;
-    if (b.timing >= 2) hipEventRecord(get_event(b, ev++), st);
+    hipStream_t st = c->lane[gr.lane].stream;
+    const size_t e0 = kEvGroup0 + kEvPerGroup * g;
+    if (b.timing == 1) mark(e0, st);
+    if (!(cull_in_pose && g == 0)) launch_cull(gr.sa, st);
+    if (b.timing >= 2) mark(e0, st);                 // (after the wait for the pose stage: set-up time only)
+    // The set-up grid is sized from the previous batch's work lists (scaled to this group's streams); the group's list
+    // length comes back with its counters, and a batch whose list outgrew the grid is run again (retire_oldest).
+    uint32_t hint = 0;
+    if (!worst_case_grid && c->items_hint && c->items_hint_streams > 0)
+      hint = (uint32_t)(((uint64_t)c->items_hint * (uint64_t)gr.sa.group_size + (uint64_t)c->items_hint_streams - 1) / (uint64_t)c->items_hint_streams);
+    const uint32_t grid = launch_setup(gr.sa, hint, false, st);
+    b.setup_grid[g] = worst_case_grid ? 0xffffffffu : grid;
+    if (b.timing >= 2) mark(e0 + 1, st);
     launch_clip(gr.sa, st);
     launch_bigrec(gr.sa, plan.cover_pass, st);      // appends the many-tile records the two kernels above listed (after the cover pass, if it is on)
-    if (b.timing) hipEventRecord(get_event(b, ev++), st);
+    if (b.timing) mark(e0 + 2, st);
     launch_tile(gr.ta, two, plan.cover_pass, st);
-    if (b.timing) hipEventRecord(get_event(b, ev++), st);
-    if (gr.compare) launch_compare(gr.ca, st);
-    if (b.timing == 1 || (b.timing == 2 && gr.compare)) hipEventRecord(get_event(b, ev++), st);
+    if (b.timing) mark(e0 + 3, st);
+    if (gr.compare) { launch_compare(gr.ca, st); if (b.timing) mark(e0 + 4, st); }
   }
-  launch_publish_counters(b.d_counters, b.h_counters, st);
+  // every lane publishes the counter blocks of its own groups
+  const int ng = (int)plan.groups.size();
+  for (int l = 0; l < c->n_lanes; l++) {
+    if (!(b.lanes_used >> l & 1u)) continue;
+    if (ng == 1) launch_publish_counters(b.d_counters, b.h_counters, 0, 1, 1, c->lane[l].stream);
+    else launch_publish_counters(b.d_counters, b.h_counters, l, c->n_lanes, (ng - l + c->n_lanes - 1) / c->n_lanes, c->lane[l].stream);
+    if (b.timing == 1) mark(kEvLaneEnd + l, c->lane[l].stream);
+  }
   return RTUF_OK;
 }
 
@@ -1178,21 +1298,32 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
   const float* d_depth = b.depth; float* d_masked = b.masked; uint8_t* d_mask = b.mask;
   const bool io_u16 = b.u16;
   const size_t esz = io_u16 ? sizeof(uint16_t) : sizeof(float);
-  hipStream_t st = c->stream;
   const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
+  // Launch groups: as many as the lanes' bins ask for, alternating between the lanes; a batch that is not split takes one
+  // lane, the next such batch the other.
+  const int n_groups = groups_for(c, n);
+  const int per_group = (n + n_groups - 1) / n_groups;
+  if (!rerun) {
+    b.lanes_used = 0;
+    if (n_groups == 1) { b.lanes_used = 1u << c->next_lane; c->next_lane = (c->next_lane + 1) % c->n_lanes; }
+    else for (int l = 0; l < std::min(c->n_lanes, n_groups); l++) b.lanes_used |= 1u << l;
+  } else if (n_groups > 1) {
+    // (a re-run after the launch group shrank may need both lanes where the first run needed one)
+    for (int l = 0; l < std::min(c->n_lanes, n_groups); l++) b.lanes_used |= 1u << l;
+  }
+  const int lane0 = __builtin_ctz(b.lanes_used);
+  hipStream_t st = c->lane[lane0].stream;        // (graph replay: single-lane contexts only)
   const size_t L = (size_t)std::max(c->n_links, 1);
   const size_t plane = (size_t)c->width * c->height;
-  size_t ev = 0;
   if (!rerun) {
     // mode 3 = mode 2 on every eighth batch only (each event costs ~5 us of stream time)
     b.timing = c->timing == 3 ? ((c->timing_seq++ & 7u) == 0 ? 2 : 0) : c->timing;
   }
-  const bool use_graph = c->graphs_ok && !b.timing && n <= kGraphMaxStreams && n <= c->group;
+  const bool use_graph = c->graphs_ok && c->n_lanes == 1 && !b.timing && n <= kGraphMaxStreams && n_groups == 1;
   // the pose stage of this batch runs on the side stream, concurrent with the raster kernels of the batch before it
   // (graph replay: everything hangs off the main stream, the side stream is forked inside the graph)
   hipStream_t sp = use_graph ? st : c->side;
   c->last_slot = (int)(&b - &c->batch[0]);
-  if (b.timing == 1) hipEventRecord(get_event(b, ev++), sp);
   // only what the host changed since the last batch crosses the bus (with on-device forward
   // kinematics that is just the joint positions below)
   const bool more = n > b.uploaded_streams;
@@ -1254,28 +1385,31 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
   // to_linear_depth's constants exactly as the shader evaluates them (include/shaders/urdf_filter.frag:14-17), in float
   const float zn = c->params.near_plane, zf = c->params.far_plane;
   const float sc_num = (zn * zf) / (zn - zf), sc_off = zf / (zf - zn);
-  pa.bg = b.d_bg; pa.counters = b.d_counters;
+  pa.bg = b.d_bg; pa.counters = b.d_counters; pa.n_counters = n_groups;
   pa.sc_num = sc_num; pa.sc_off = sc_off; pa.max_diff = c->params.depth_distance_threshold;
   pa.n_streams = n; pa.n_draws = c->n_draws; pa.n_links = (int)L; pa.z_far = c->params.far_plane;
   pa.width = c->width; pa.height = c->height;
-  for (int base = 0; base < n; base += c->group) {
-    const int gs = std::min(c->group, n - base);
+  for (int g = 0, base = 0; base < n; g++, base += per_group) {
+    const int gs = std::min(per_group, n - base);
     plan.groups.emplace_back();
     BatchPlan::Group& gr = plan.groups.back();
     memset(&gr.sa, 0, sizeof gr.sa); memset(&gr.ta, 0, sizeof gr.ta); memset(&gr.ca, 0, sizeof gr.ca);
+    gr.lane = n_groups == 1 ? lane0 : g % c->n_lanes;
+    const rtuf_context::Lane& ln = c->lane[gr.lane];
+    Counters* const d_counters = b.d_counters + g;
     SetupArgs& sa = gr.sa;
     sa.cverts = c->d_cverts; sa.ctris = c->d_ctris; sa.corder = c->d_corder; sa.chunks = c->d_chunks; sa.mvp = b.d_mvp;
     sa.model_mask = c->d_model_mask; sa.bg = b.d_bg;
-    sa.bins = c->d_bins; sa.bin_hdr = c->d_bin_hdr; sa.fbins = c->d_fbins; sa.fbin_count = c->d_fbin_count; sa.fcapacity = c->fcapacity; sa.capacity = c->capacity;
-    sa.clip_list = c->d_clip_list; sa.clip_spill = c->d_clip_spill; sa.big_list = c->d_big_list; sa.big_capacity = c->big_capacity; sa.counters = b.d_counters; sa.group_base = base; sa.group_size = gs;
+    sa.bins = ln.d_bins; sa.bin_hdr = ln.d_bin_hdr; sa.fbins = ln.d_fbins; sa.fbin_count = ln.d_fbin_count; sa.fcapacity = c->fcapacity; sa.capacity = c->capacity;
+    sa.clip_list = ln.d_clip_list; sa.clip_spill = ln.d_clip_spill; sa.big_list = ln.d_big_list; sa.big_capacity = c->big_capacity; sa.counters = d_counters; sa.group_base = base; sa.group_size = gs;
     sa.n_draws = c->n_draws; sa.width = c->width; sa.height = c->height; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
     sa.clip_capacity = c->clip_capacity; sa.bg_chunk = c->bg_chunk;
-    sa.items = b.d_items; sa.n_chunks = c->n_chunks; sa.flags = c->params.flags;
+    sa.items = ln.d_items[c->last_slot]; sa.n_chunks = c->n_chunks; sa.flags = c->params.flags;
     TileArgs& ta = gr.ta;
-    ta.bins = c->d_bins; ta.bin_hdr = c->d_bin_hdr; ta.fbins = c->d_fbins; ta.fbin_count = c->d_fbin_count; ta.fcapacity = c->fcapacity; ta.capacity = c->capacity;
+    ta.bins = ln.d_bins; ta.bin_hdr = ln.d_bin_hdr; ta.fbins = ln.d_fbins; ta.fbin_count = ln.d_fbin_count; ta.fcapacity = c->fcapacity; ta.capacity = c->capacity;
     ta.depth = d_depth; ta.masked = d_masked; ta.mask = d_mask;
-    ta.zsurface = c->d_zsurface; ta.bg = b.d_bg; ta.counters = b.d_counters;
-    ta.big_list = c->d_big_list;
+    ta.zsurface = ln.d_zsurface; ta.bg = b.d_bg; ta.counters = d_counters;
+    ta.big_list = ln.d_big_list;
     ta.group_base = base; ta.group_size = gs; ta.width = c->width; ta.height = c->height;
     ta.tiles_x = c->tiles_x; ta.tiles_y = c->tiles_y; ta.flags = c->params.flags;
     ta.z_near = c->params.near_plane; ta.z_far = c->params.far_plane;
@@ -1286,7 +1420,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     gr.compare = two && !b.bits;
     if (gr.compare) {
       CompareArgs& ca = gr.ca;
-      ca.depth = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_depth) + (size_t)base * plane * esz); ca.zsurface = c->d_zsurface;
+      ca.depth = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_depth) + (size_t)base * plane * esz); ca.zsurface = ln.d_zsurface;
       ca.masked = reinterpret_cast<float*>(reinterpret_cast<char*>(d_masked) + (size_t)base * plane * esz);
       ca.io_u16 = io_u16 ? 1 : 0; ca.mask = d_mask ? d_mask + (size_t)base * plane : nullptr;
       ca.n_pixels = (size_t)gs * plane;
@@ -1294,6 +1428,13 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
       ca.sc_num = sc_num; ca.sc_off = sc_off;
     }
   }
+  b.n_groups = (int)plan.groups.size();
+  b.setup_grid.assign(plan.groups.size(), 0xffffffffu);
+  c->last_lane = plan.groups.back().lane;
+  // host-plane batches: the lanes' first kernels wait for the upload of the planes
+  if (b.wait_upload)
+    for (int l = 0; l < c->n_lanes; l++)
+      if (b.lanes_used >> l & 1u) HIP_TRY(c, hipStreamWaitEvent(c->lane[l].stream, b.uploaded, 0));
   bool launched = false;
   if (use_graph) {
     // Small batch: its ~8 launches, two event operations and the cross-stream wait cost the host more than the GPU
@@ -1302,8 +1443,18 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     const uint64_t h = plan.hash();
     hipGraphExec_t exec = nullptr;
     for (auto& g : b.graphs) if (g.exec && g.hash == h) exec = g.exec;
+    // A capture that has to evict a LIVE entry of the slot's cache is what thrashing looks like (a caller that never repeats
+    // an argument set: fresh output buffers every frame); filling free entries -- the ring of staging buffers, the cover
+    // pass going on and off, a regrowth -- is not.  Judged over windows of 64 batches, so a burst long ago does not count.
     if (exec) c->graph_hits++;
-    else if (++c->graph_misses >= 32 && c->graph_misses > 2 * c->graph_hits) c->graphs_ok = false;     // thrashing: plain launches are cheaper
+    else {
+      c->graph_misses++;
+      if (b.graphs[b.graph_next].exec) c->graph_evictions++;
+    }
+    if (((c->graph_hits + c->graph_misses) & 63u) == 0u) {
+      if (c->graph_evictions > 32) c->graphs_ok = false;       // more than half of the window's batches captured over a live entry
+      c->graph_evictions = 0;
+    }
     if (!exec && c->graphs_ok) {
       hipGraph_t graph = nullptr;
       // (the side stream joins the capture below: it must not still carry plain launches of an earlier batch)
@@ -1313,7 +1464,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
         if (!c->fork_ev) hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
         hipEventRecord(c->fork_ev, st);
         hipStreamWaitEvent(c->side, c->fork_ev, 0);
-        const int rc = issue_plan(c, b, plan, c->side, st, 0u, ev);
+        const int rc = issue_plan(c, b, plan, c->side, true);
         e = hipStreamEndCapture(st, &graph);
         if (rc != RTUF_OK) e = hipErrorUnknown;
       }
@@ -1334,16 +1485,17 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     }
     if (exec) {
       HIP_TRY(c, hipGraphLaunch(exec, st));
-      b.setup_grid = 0xffffffffu;          // worst-case grid: the work list always fits
+      b.setup_grid.assign(plan.groups.size(), 0xffffffffu);          // worst-case grid: the work list always fits
       launched = true;
     }
   }
   if (!launched) {
     if (!use_graph) c->side_used_plain = true;
-    const int rc = issue_plan(c, b, plan, use_graph ? st : sp, st, c->items_hint, ev);
+    const int rc = issue_plan(c, b, plan, use_graph ? st : sp, false);
     if (rc != RTUF_OK) return rc;
   }
-  HIP_TRY(c, hipEventRecord(b.done, st));
+  for (int l = 0; l < c->n_lanes; l++)
+    if (b.lanes_used >> l & 1u) HIP_TRY(c, hipEventRecord(b.done[l], c->lane[l].stream));
   HIP_TRY(c, hipGetLastError());
   return RTUF_OK;
 }
@@ -1354,7 +1506,8 @@ static int enqueue_download(rtuf_context* c, rtuf_context::Batch& b)
 {
   const size_t plane = (size_t)c->width * c->height;
   const size_t esz = b.u16 ? sizeof(uint16_t) : sizeof(float);
-  HIP_TRY(c, hipStreamWaitEvent(c->d2h, b.done, 0));
+  for (int l = 0; l < c->n_lanes; l++)
+    if (b.lanes_used >> l & 1u) HIP_TRY(c, hipStreamWaitEvent(c->d2h, b.done[l], 0));
   if (b.bits) {
     const size_t words = (size_t)c->height * (size_t)((c->width + 31) / 32);
     for (int s = 0; s < b.n;) {
@@ -1390,19 +1543,31 @@ static int retire_oldest(rtuf_context* c)
   for (int attempt = 0; attempt < 8; attempt++) {
     rtuf_context::Batch& b = c->batch[c->oldest];
     if (!c->pending || !b.active) { c->pending = 0; return RTUF_OK; }
-    HIP_TRY(c, hipEventSynchronize(b.done));
-    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0, occluded = 0, raster_atomics = 0, drawn_pixels = 0;
-             unsigned max_bin_fill = 0, max_fbin_fill = 0, clip_overflow = 0, uncovered = 0, max_big_fill = 0, cover_tiles = 0, exact_tiles = 0, zero_items = 0; } k;
-    c->items_hint = b.h_counters->work.n_items;      // sizes the next batches' set-up grid
-    for (int i = 0; i < kCounterShards; i++) {
-      const CounterShard& sh = b.h_counters->shard[i];
-      k.tris_binned += sh.tris_binned; k.bin_entries += sh.bin_entries; k.clip_count += sh.clip_count;
-      k.max_bin_fill = std::max(k.max_bin_fill, sh.max_bin_fill); k.clip_overflow |= sh.clip_overflow;
-      k.max_fbin_fill = std::max(k.max_fbin_fill, sh.max_fbin_fill); k.frags += sh.frags; k.uncovered |= sh.uncovered;
-      k.max_big_fill = std::max(k.max_big_fill, sh.max_big_fill);
-      k.occluded += sh.occluded; k.cover_tiles += sh.cover_tiles; k.exact_tiles += sh.exact_tiles; k.zero_items += sh.zero_items;
-      k.raster_atomics += sh.raster_atomics; k.drawn_pixels += sh.drawn_pixels;
+    for (int l = 0; l < c->n_lanes; l++)
+      if (b.lanes_used >> l & 1u) HIP_TRY(c, hipEventSynchronize(b.done[l]));
+    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0, occluded = 0, raster_atomics = 0, drawn_pixels = 0, work_items = 0;
+             unsigned max_bin_fill = 0, max_fbin_fill = 0, clip_overflow = 0, uncovered = 0, max_big_fill = 0, cover_tiles = 0, exact_tiles = 0, zero_items = 0,
+                      max_items = 0; } k;
+    bool list_over = false;                    // some group's set-up grid was sized too small for its work list
+    int group_streams = 0;
+    for (int g = 0; g < b.n_groups; g++) {
+      const Counters& cn = b.h_counters[g];
+      k.work_items += cn.work.n_items;
+      k.max_items = std::max(k.max_items, cn.work.n_items);
+      list_over = list_over || cn.work.n_items > b.setup_grid[g];
+      for (int i = 0; i < kCounterShards; i++) {
+        const CounterShard& sh = cn.shard[i];
+        k.tris_binned += sh.tris_binned; k.bin_entries += sh.bin_entries; k.clip_count += sh.clip_count;
+        k.max_bin_fill = std::max(k.max_bin_fill, sh.max_bin_fill); k.clip_overflow |= sh.clip_overflow;
+        k.max_fbin_fill = std::max(k.max_fbin_fill, sh.max_fbin_fill); k.frags += sh.frags; k.uncovered |= sh.uncovered;
+        k.max_big_fill = std::max(k.max_big_fill, sh.max_big_fill);
+        k.occluded += sh.occluded; k.cover_tiles += sh.cover_tiles; k.exact_tiles += sh.exact_tiles; k.zero_items += sh.zero_items;
+        k.raster_atomics += sh.raster_atomics; k.drawn_pixels += sh.drawn_pixels;
+      }
     }
+    group_streams = (b.n + b.n_groups - 1) / std::max(b.n_groups, 1);
+    c->items_hint = k.max_items;               // sizes the next batches' set-up grids (the longest list of this batch's groups ...
+    c->items_hint_streams = group_streams;     // ... of so many streams each)
     c->stats.triangles_submitted = (uint64_t)c->n_tris * (uint64_t)b.n;
     c->stats.triangles_binned = k.tris_binned;
     c->stats.bin_entries = k.bin_entries;
@@ -1412,44 +1577,38 @@ static int retire_oldest(rtuf_context* c)
     c->stats.fragments_binned = k.frags;
     c->stats.max_fbin_fill = k.max_fbin_fill;
     c->stats.occluded_entries = k.occluded; c->stats.cover_tiles = k.cover_tiles; c->stats.exact_tiles = k.exact_tiles;
-    c->stats.work_items = b.h_counters->work.n_items; c->stats.zero_survivor_items = k.zero_items;
+    c->stats.work_items = (uint32_t)std::min<unsigned long long>(k.work_items, 0xffffffffu); c->stats.zero_survivor_items = k.zero_items;
     c->stats.raster_atomics = k.raster_atomics; c->stats.drawn_pixels = k.drawn_pixels;
     c->stats.cover_pass = b.cover_pass ? 1u : 0u;
+    c->stats.groups_last_batch = (uint32_t)b.n_groups;
     const bool bin_over = k.max_bin_fill > c->capacity || k.max_fbin_fill > c->fcapacity;
     const bool clip_over = k.clip_overflow != 0;
     const bool big_over = k.max_big_fill > c->big_capacity;
-    const bool list_over = b.h_counters->work.n_items > b.setup_grid;     // the set-up grid was sized too small
     if (list_over) c->stats.regrowths++;
     if (!bin_over && !clip_over && !list_over && !big_over) {
       if (b.host_io) HIP_TRY(c, hipEventSynchronize(b.downloaded));
-      if (b.timing == 1 && b.events.size() >= 2) {
-        // events: [start, pose_end, (setup_end, tile_end, compare_end) per group ...]
-        float ms = 0;
-        c->stats.ms_pose = c->stats.ms_setup = c->stats.ms_clip = c->stats.ms_raster = c->stats.ms_compare = 0;
-        hipEventElapsedTime(&ms, b.events[0], b.events[1]); c->stats.ms_pose = ms;
-        size_t e = 1;
-        for (int base = 0; base < b.n; base += c->group) {
-          hipEventElapsedTime(&ms, b.events[e], b.events[e + 1]); c->stats.ms_setup += ms;
-          hipEventElapsedTime(&ms, b.events[e + 1], b.events[e + 2]); c->stats.ms_raster += ms;
-          hipEventElapsedTime(&ms, b.events[e + 2], b.events[e + 3]); c->stats.ms_compare += ms;
-          e += 3;
-        }
-        hipEventElapsedTime(&ms, b.events[0], b.events[e]); c->stats.ms_total = ms;
-      } else if (b.timing == 2 && b.events.size() >= 4) {
-        // events: (setup_begin, clip_begin, tile_begin, tile_end[, compare_end]) per group
+      if (b.timing && b.events.size() >= (size_t)(kEvGroup0 + kEvPerGroup * b.n_groups)) {
+        // per launch group E0 .. E4 (see issue_plan).  With two lanes the kernels of different groups overlap: the sums
+        // below add up per-launch durations, they are not wall time.
         const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0 && !b.bits;
-        float ms = 0;
+        auto el = [&](size_t i, size_t j) { float ms = 0; hipEventElapsedTime(&ms, b.events[i], b.events[j]); return ms; };
         c->stats.ms_pose = c->stats.ms_setup = c->stats.ms_clip = c->stats.ms_raster = c->stats.ms_compare = c->stats.ms_total = 0;
-        size_t e = 0;
-        for (int base = 0; base < b.n; base += c->group) {
-          hipEventElapsedTime(&ms, b.events[e], b.events[e + 1]); c->stats.ms_setup += ms;
-          hipEventElapsedTime(&ms, b.events[e + 1], b.events[e + 2]); c->stats.ms_clip += ms;
-          hipEventElapsedTime(&ms, b.events[e + 2], b.events[e + 3]); c->stats.ms_raster += ms;
-          if (two) { hipEventElapsedTime(&ms, b.events[e + 3], b.events[e + 4]); c->stats.ms_compare += ms; }
-          e += two ? 5 : 4;
+        for (int g = 0; g < b.n_groups; g++) {
+          const size_t e0 = kEvGroup0 + kEvPerGroup * (size_t)g;
+          if (b.timing == 1) {
+            c->stats.ms_setup += el(e0, e0 + 2);
+          } else {
+            c->stats.ms_setup += el(e0, e0 + 1);
+            c->stats.ms_clip += el(e0 + 1, e0 + 2);
+          }
+          c->stats.ms_raster += el(e0 + 2, e0 + 3);
+          if (two) c->stats.ms_compare += el(e0 + 3, e0 + 4);
         }
-      }
-      if (b.timing) {
+        if (b.timing == 1) {
+          c->stats.ms_pose = el(kEvStart, kEvPoseEnd);
+          for (int l = 0; l < c->n_lanes; l++)
+            if (b.lanes_used >> l & 1u) c->stats.ms_total = std::max(c->stats.ms_total, el(kEvStart, kEvLaneEnd + l));
+        }
         c->acc_ms[0] += c->stats.ms_pose; c->acc_ms[1] += c->stats.ms_setup; c->acc_ms[2] += c->stats.ms_raster;
         c->acc_ms[3] += c->stats.ms_compare; c->acc_ms[4] += c->stats.ms_total; c->acc_ms[5] += c->stats.ms_clip;
         c->acc_batches++;
@@ -1472,28 +1631,37 @@ static int retire_oldest(rtuf_context* c)
       return RTUF_OK;
     }
     // overflow: wait for the later batches too, enlarge, and run everything in flight again in order
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    sync_lanes(c);
     if (c->d2h) HIP_TRY(c, hipStreamSynchronize(c->d2h));
     auto give_up = [&](int rc) { for (auto& o : c->batch) o.active = false; c->pending = 0; return rc; };
     if (bin_over) { const int rc = grow_bins(c, k.max_bin_fill, k.max_fbin_fill); if (rc != RTUF_OK) return give_up(rc); }
     if (clip_over) {
       const uint32_t larger = c->clip_capacity * 4;
-      int rc = regrow(c, c->d_clip_list, (size_t)larger * kCounterShards * sizeof(ClipItem), "clip list");
-      if (rc == RTUF_OK && clip_spill_bytes(larger) != clip_spill_bytes(c->clip_capacity)) { rc = regrow(c, c->d_clip_spill, clip_spill_bytes(larger), "clip spill area"); c->stats.regrowths--; }
-      if (rc != RTUF_OK) return give_up(rc);
+      for (int l = 0; l < c->n_lanes; l++) {
+        int rc = regrow(c, c->lane[l].d_clip_list, (size_t)larger * kCounterShards * sizeof(ClipItem), "clip list");
+        if (rc == RTUF_OK && clip_spill_bytes(larger) != clip_spill_bytes(c->clip_capacity)) { rc = regrow(c, c->lane[l].d_clip_spill, clip_spill_bytes(larger), "clip spill area"); c->stats.regrowths--; }
+        if (rc != RTUF_OK) return give_up(rc);
+        if (l) c->stats.regrowths--;           // (one regrowth, however many lanes)
+      }
       c->clip_capacity = larger;
     }
     if (big_over) {
       // (half as much again as this run asked for: poses move, and a list that just fits overflows on the next batch)
       uint32_t larger = c->big_capacity;
       while (larger < k.max_big_fill + k.max_big_fill / 2) larger *= 2;
-      const int rc = regrow(c, c->d_big_list, (size_t)larger * kCounterShards * sizeof(BigRec), "many-tile list");
-      if (rc != RTUF_OK) return give_up(rc);
+      for (int l = 0; l < c->n_lanes; l++) {
+        const int rc = regrow(c, c->lane[l].d_big_list, (size_t)larger * kCounterShards * sizeof(BigRec), "many-tile list");
+        if (rc != RTUF_OK) return give_up(rc);
+        if (l) c->stats.regrowths--;
+      }
       c->big_capacity = larger;
     }
     const size_t tiles = (size_t)c->tiles_x * c->tiles_y;
-    launch_init_headers(c->d_bin_hdr, (size_t)c->group * tiles, c->stream);
-    HIP_TRY(c, hipMemsetAsync(c->d_fbin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->stream));
+    for (int l = 0; l < c->n_lanes; l++) {
+      // (the arrays were sized for the launch group the context started with: at least the present one)
+      launch_init_headers(c->lane[l].d_bin_hdr, (size_t)c->group * tiles, c->lane[l].stream);
+      HIP_TRY(c, hipMemsetAsync(c->lane[l].d_fbin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->lane[l].stream));
+    }
     for (int i = 0; i < c->pending; i++) {
       rtuf_context::Batch& r = c->batch[(c->oldest + i) % kMaxInflight];
       int rc = enqueue_batch(c, r, true);
@@ -1506,17 +1674,20 @@ static int retire_oldest(rtuf_context* c)
   return c->fail(RTUF_ERR_CAPACITY, "tile bins still overflow after regrowth");
 }
 
-static int submit_batch(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask, bool u16, uint32_t* d_bits = nullptr)
+static int submit_batch(rtuf_context* c, int n, const float* d_depth, float* d_masked, uint8_t* d_mask, bool u16, uint32_t* d_bits = nullptr,
+                        bool wait_upload = false)
 {
   if (c->broken) return c->fail(RTUF_ERR_STATE, "context unusable: a bin regrowth failed (%s)", c->error.c_str());
   hipSetDevice(c->device);
-  if ((c->params.flags & RTUF_FLAG_TWO_KERNEL) && !c->d_zsurface)
-    HIP_TRY(c, dev_alloc(c, &c->d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));
-  // two-kernel mode keeps one z-surface: its batches do not overlap
+  if (c->params.flags & RTUF_FLAG_TWO_KERNEL)
+    for (int l = 0; l < c->n_lanes; l++)
+      if (!c->lane[l].d_zsurface) HIP_TRY(c, dev_alloc(c, &c->lane[l].d_zsurface, (size_t)c->group * c->width * c->height * sizeof(float)));
+  // two-kernel mode keeps one z-surface per lane: its batches do not overlap
   const int limit = (c->params.flags & RTUF_FLAG_TWO_KERNEL) ? 1 : kMaxInflight;
   while (c->pending >= limit) { const int rc = retire_oldest(c); if (rc != RTUF_OK) return rc; }
   rtuf_context::Batch& b = c->batch[(c->oldest + c->pending) % kMaxInflight];
   b.n = n; b.depth = d_depth; b.masked = d_masked; b.mask = d_mask; b.u16 = u16; b.host_io = false; b.bits = d_bits;
+  b.wait_upload = wait_upload;
   const int rc = enqueue_batch(c, b, false);
   if (rc == RTUF_OK) { b.active = true; c->pending++; }
   return rc;
@@ -1621,11 +1792,26 @@ int rtuf_sync(rtuf_context* c)
   }
   hipSetDevice(c->device);
   while (c->pending) { const int rc = retire_oldest(c); if (rc != RTUF_OK) return rc; }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int l = 0; l < c->n_lanes; l++) HIP_TRY(c, hipStreamSynchronize(c->lane[l].stream));
   return RTUF_OK;
 }
 
-void* rtuf_stream(rtuf_context* c) { return (c && c->kids.empty()) ? (void*)c->stream : nullptr; }
+void* rtuf_stream(rtuf_context* c) { return (c && c->kids.empty() && c->n_lanes == 1) ? (void*)c->lane[0].stream : nullptr; }
+
+int rtuf_order_stream_after_batches(rtuf_context* c, void* hip_stream)
+{
+  KIDS_ALL(c, rtuf_order_stream_after_batches(k, hip_stream));
+  if (!c) return RTUF_ERR_INVALID;
+  hipSetDevice(c->device);
+  hipStream_t user = static_cast<hipStream_t>(hip_stream);
+  for (const auto& b : c->batch) {
+    if (!b.active) continue;
+    for (int l = 0; l < c->n_lanes; l++)
+      if (b.lanes_used >> l & 1u) HIP_TRY(c, hipStreamWaitEvent(user, b.done[l], 0));
+    if (b.host_io && b.downloaded) HIP_TRY(c, hipStreamWaitEvent(user, b.downloaded, 0));
+  }
+  return RTUF_OK;
+}
 
 // ---- host planes -----------------------------------------------------------------------------------
 // The reference's filter() takes a host buffer and leaves host results (src/urdf_filter.cpp:233-234,
@@ -1671,8 +1857,7 @@ static int submit_host_batch(rtuf_context* c, int n, const void* const* depth_in
     HIP_TRY(c, hipMemcpyAsync((char*)b.st_depth + (size_t)s * plane * esz, depth_in[s], (size_t)(e - s) * plane * esz, hipMemcpyHostToDevice, c->h2d));
     s = e;
   }
-  HIP_TRY(c, hipEventRecord(b.uploaded, c->h2d));
-  HIP_TRY(c, hipStreamWaitEvent(c->stream, b.uploaded, 0));
+  HIP_TRY(c, hipEventRecord(b.uploaded, c->h2d));          // (the lanes' first kernels wait for it: enqueue_batch)
   bool any_mask = false;
   b.h_bits.clear();
   if (bits_out) {
@@ -1682,7 +1867,7 @@ static int submit_host_batch(rtuf_context* c, int n, const void* const* depth_in
     b.h_mask.assign((size_t)n, nullptr);
     if (mask_out) for (int s = 0; s < n; s++) { b.h_mask[s] = mask_out[s]; any_mask |= mask_out[s] != nullptr; }
   }
-  int rc = submit_batch(c, n, b.st_depth, b.st_masked, any_mask ? b.st_mask : nullptr, u16, bits_out ? b.st_bits : nullptr);
+  int rc = submit_batch(c, n, b.st_depth, b.st_masked, any_mask ? b.st_mask : nullptr, u16, bits_out ? b.st_bits : nullptr, true);
   if (rc != RTUF_OK) return rc;
   b.host_io = true;
   return enqueue_download(c, b);
@@ -1809,11 +1994,14 @@ int rtuf_get_stats(rtuf_context* c, rtuf_stats* out)
 {
   if (!c || !out) return RTUF_ERR_INVALID;
   if (!c->kids.empty()) {
-    // counters and last-batch times of the pipeline that ran last; event sums and regrowths over all pipelines
+    // counters and last-batch times of the pipeline that ran last (cover_pass, cover_tiles, work_items ... are that
+    // pipeline's: each decides about its cover pass on its own); event sums, regrowths, memory and graph counts over all pipelines
     *out = c->kids[c->last_kid]->stats;
     out->bin_capacity = c->kids[c->last_kid]->capacity;
+    out->raster_lanes = (uint32_t)c->kids[c->last_kid]->n_lanes; out->launch_group = (uint32_t)c->kids[c->last_kid]->group;
     out->regrowths = 0; out->timed_batches = 0; out->device_bytes = 0;
-    for (const rtuf_context* k : c->kids) out->device_bytes += k->device_bytes;
+    out->graphs_enabled = 1u; out->graph_hits = out->graph_misses = 0;
+    for (const rtuf_context* k : c->kids) { out->device_bytes += k->device_bytes; out->graphs_enabled &= k->graphs_ok ? 1u : 0u; out->graph_hits += k->graph_hits; out->graph_misses += k->graph_misses; }
     out->sum_ms_pose = out->sum_ms_setup = out->sum_ms_raster = out->sum_ms_compare = out->sum_ms_total = out->sum_ms_clip = 0;
     for (const rtuf_context* k : c->kids) {
       out->regrowths += k->stats.regrowths; out->timed_batches += k->stats.timed_batches;
@@ -1825,6 +2013,8 @@ int rtuf_get_stats(rtuf_context* c, rtuf_stats* out)
   *out = c->stats;
   out->bin_capacity = c->capacity;
   out->device_bytes = c->device_bytes;
+  out->raster_lanes = (uint32_t)c->n_lanes; out->launch_group = (uint32_t)c->group;
+  out->graphs_enabled = c->graphs_ok ? 1u : 0u; out->graph_hits = c->graph_hits; out->graph_misses = c->graph_misses;
   return RTUF_OK;
 }
 
@@ -1843,11 +2033,12 @@ int rtuf_debug_read_zsurface(rtuf_context* c, int n, float* host_out)
 {
   KIDS_ONE(c, c->last_kid, rtuf_debug_read_zsurface(k, n, host_out));
   if (!c || !host_out) return RTUF_ERR_INVALID;
-  if (!(c->params.flags & RTUF_FLAG_TWO_KERNEL) || !c->d_zsurface) return c->fail(RTUF_ERR_STATE, "z-surface exists only in two-kernel mode");
-  if (n <= 0 || n > c->group) return c->fail(RTUF_ERR_INVALID, "z-surface holds the last in-flight group (%d streams)", c->group);
+  const float* zs = c->lane[c->last_lane].d_zsurface;
+  if (!(c->params.flags & RTUF_FLAG_TWO_KERNEL) || !zs) return c->fail(RTUF_ERR_STATE, "z-surface exists only in two-kernel mode");
+  if (n <= 0 || n > c->group) return c->fail(RTUF_ERR_INVALID, "z-surface holds the last launch group (at most %d streams)", c->group);
   hipSetDevice(c->device);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipMemcpy(host_out, c->d_zsurface, (size_t)n * c->width * c->height * sizeof(float), hipMemcpyDeviceToHost));
+  sync_lanes(c);
+  HIP_TRY(c, hipMemcpy(host_out, zs, (size_t)n * c->width * c->height * sizeof(float), hipMemcpyDeviceToHost));
   return RTUF_OK;
 }
 

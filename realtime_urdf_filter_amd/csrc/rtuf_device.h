@@ -11,9 +11,11 @@
 //   per frame, per stream s (slot within the batch)
 //     cams   Camera[N]   projection / camera_offset_inv / camera_tf as f64
 //     link_tf f64[N][L][16]                                         (two slots: one per batch in flight)
-//     mvp    f32[N][D][16]  written by pose_kernel;  bg BgInfo[N];  items WorkItem[] written by cull_kernel
+//     mvp    f32[N][D][16]  written by pose_kernel;  bg BgInfo[N];  items WorkItem[] written by cull_kernel (one list per raster lane)
 //     depth  f32[N][H][W] in, masked f32[N][H][W] + mask u8[N][H][W] out
-//   rasteriser working set, per in-flight stream g and screen tile
+//   rasteriser working set of ONE RASTER LANE (a context has one or two: a lane is a HIP stream plus the arrays below; the
+//   launch groups of a batch alternate between the lanes, so one group's set-up runs under the other's tile kernel),
+//   per stream g of the launch group and screen tile
 //     bin_hdr   BinHeader[G][tiles]   records binned from the front (small boxes) and from the back of the bin, and the tile's
 //                                     cover (nearest triangle that covers the WHOLE tile): 16 bytes, one scalar load in the tile kernel
 //     bins      PackedTri[G][tiles][capacity]  (32 B records: small boxes from the front, larger from the back)
@@ -231,7 +233,8 @@ struct PoseArgs {
   float* mvp;                // [n_streams][n_draws + 1][16]
   BgInfo* bg;                // [n_streams]
   float sc_num, sc_off, max_diff;   // to_linear_depth constants (host-computed, see shade_consts) and the threshold
-  Counters* counters;        // zeroed by the kernel's first workgroup
+  Counters* counters;        // [n_counters]: one block per launch group of the batch, zeroed by this kernel
+  int n_counters;
   int n_streams, n_draws, n_links;
   float z_far;
   int width, height;
@@ -324,9 +327,9 @@ uint32_t launch_setup(const SetupArgs& a, uint32_t items_hint, bool sweep, hipSt
 void launch_clip(const SetupArgs& a, hipStream_t st);
 size_t clip_spill_bytes(uint32_t clip_capacity);
 void launch_bigrec(const SetupArgs& a, bool cover_pass, hipStream_t st);      // cover_pass: bigrec_kernel<0> runs first (and launch_tile gets the same flag)
-void launch_reset_clip(Counters* c, hipStream_t st);
 void launch_init_headers(BinHeader* hdr, size_t n_bins, hipStream_t st);
-void launch_publish_counters(const Counters* src, Counters* host_dst, hipStream_t st);
+// copies the counter blocks first, first + stride, ... (count of them) of a batch to the same places of the pinned host array
+void launch_publish_counters(const Counters* src, Counters* host_dst, int first, int stride, int count, hipStream_t st);
 void launch_tile(const TileArgs& a, bool two_kernel, bool cover_pass, hipStream_t st);   // a.io_u16 selects the 16UC1 variant
 void launch_compare(const CompareArgs& a, hipStream_t st);
 

@@ -119,8 +119,9 @@ __global__ void pose_kernel(PoseArgs a)
   const int per = a.n_draws + 1;
   // first kernel of a batch that every configuration runs: it also zeroes the batch's counters
   // (statistics, clip lists, work-list length), which saves a separate fill launch per batch
-  if (blockIdx.x == 0) {
-    uint32_t* w = reinterpret_cast<uint32_t*>(a.counters);
+  // (one block of counters per launch group of the batch)
+  for (int cb = blockIdx.x; cb < a.n_counters; cb += gridDim.x) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(a.counters + cb);
     for (int i = threadIdx.x; i < (int)(sizeof(Counters) / 4); i += blockDim.x) w[i] = 0u;
   }
   if (gid >= a.n_streams * per) return;
@@ -2238,22 +2239,15 @@ __global__ __launch_bounds__(kBlock) void compare_kernel(CompareArgs a)
   }
 }
 
-// clip-list counters are per in-flight group: reset between groups of one batch (clip_count of
-// earlier groups stays in the statistics through clip_total)
-// The batch's counters go to pinned host memory with plain stores from a one-workgroup kernel: a
-// hipMemcpyAsync of 8 KB costs a blit launch plus ~10 us of copy-engine set-up on the stream.
-__global__ void publish_counters_kernel(const Counters* __restrict__ src, Counters* __restrict__ host_dst)
+// A batch's counters (one block per launch group) go to pinned host memory with plain stores from a tiny kernel, one
+// workgroup per block: a hipMemcpyAsync of 8 KB costs a blit launch plus ~10 us of copy-engine set-up on the stream.
+// Every raster lane publishes the blocks of its own groups (first, first + stride, ...) at the end of its part of the batch.
+__global__ void publish_counters_kernel(const Counters* __restrict__ src, Counters* __restrict__ host_dst, int first, int stride)
 {
-  const uint4* s = reinterpret_cast<const uint4*>(src);
-  uint4* d = reinterpret_cast<uint4*>(host_dst);
+  const int b = first + (int)blockIdx.x * stride;
+  const uint4* s = reinterpret_cast<const uint4*>(src + b);
+  uint4* d = reinterpret_cast<uint4*>(host_dst + b);
   for (int i = threadIdx.x; i < (int)(sizeof(Counters) / 16); i += blockDim.x) d[i] = s[i];
-}
-
-__global__ void reset_clip_kernel(Counters* c)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < kCounterShards) { c->shard[i].clip_count = 0; c->shard[i].big_count = 0; }
-  if (i == kCounterShards) c->work.n_items = 0;
 }
 
 // bin headers of a fresh (or regrown) working set: nothing binned, no cover
@@ -2264,17 +2258,13 @@ __global__ void init_headers_kernel(BinHeader* hdr, size_t n_bins)
 }
 
 // host-callable launchers ---------------------------------------------------------------
-void launch_publish_counters(const Counters* src, Counters* host_dst, hipStream_t st)
+void launch_publish_counters(const Counters* src, Counters* host_dst, int first, int stride, int count, hipStream_t st)
 {
-  hipLaunchKernelGGL(publish_counters_kernel, dim3(1), dim3(256), 0, st, src, host_dst);
+  if (count > 0) hipLaunchKernelGGL(publish_counters_kernel, dim3((unsigned)count), dim3(256), 0, st, src, host_dst, first, stride);
 }
 void launch_init_headers(BinHeader* hdr, size_t n_bins, hipStream_t st)
 {
   hipLaunchKernelGGL(init_headers_kernel, dim3((unsigned)((n_bins + 255) / 256)), dim3(256), 0, st, hdr, n_bins);
-}
-void launch_reset_clip(Counters* c, hipStream_t st)
-{
-  hipLaunchKernelGGL(reset_clip_kernel, dim3(2), dim3(kCounterShards), 0, st, c);
 }
 void launch_fk(const FkArgs& a, hipStream_t st)
 {

@@ -10,7 +10,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--steps", "3", "--warmup", "1", "--streams", "8", "--triangles", "8000", "--cpu-seconds", "0.5", "--check-frames", "2"]
+SMALL = ["--steps", "3", "--warmup", "1", "--streams", "8", "--triangles", "8000", "--cpu-seconds", "0.5", "--check-frames", "2",
+         "--min-seconds", "0.5", "--isolated-seconds", "0.3", "--host-copy-seconds", "0.3"]
 REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline", "cpu_baseline"]
 
@@ -28,7 +29,7 @@ def test_bench_line_contract():
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
-    assert d["timed_steps"] % 3 == 0 and d["timed_steps"] * d["ms_per_step"] * 1e-3 >= 0.3       # --min-seconds default 0.5 (estimate-sized)
+    assert d["timed_steps"] % 3 == 0 and d["timed_steps"] * d["ms_per_step"] * 1e-3 >= 0.3       # --min-seconds 0.5 (estimate-sized)
     assert d["value"] > 0 and abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
@@ -36,10 +37,31 @@ def test_bench_line_contract():
     names = {rf["kernel"]} | {e["kernel"] for e in rf["all_kernels"]}
     assert names == {"tile_kernel<fused>", "setup_kernel", "clip_kernel"}
     assert all(rf["avg_launch_ms"] >= e["avg_launch_ms"] > 0 for e in rf["all_kernels"])
+    # the roofline comes from the one-lane leg of the same run (every kernel alone on the GPU); the headline's own per-launch
+    # figures sit beside it
+    assert "one-lane context" in rf["measured_on"] and rf["in_headline_run"]["avg_launch_ms"] > 0 and rf["one_lane_leg"]["frames_per_s"] > 0
+    assert d["config"]["raster_lanes"] == 2 and d["config"]["launch_groups_per_batch"] == 1      # 8 streams: not split, the lanes in turn
+    hc = d["with_host_copies"]["modes"]
+    assert len(hc) == 2 and all(m["frames_per_s"] > 0 and m["mismatching_values"] == 0 and 0 < m["fraction_of_link"]["host_to_device"] < 1.2 for m in hc.values())
     assert d["parity"]["mask_mismatch_pixels"] == 0 and d["parity"]["depth_mismatch_pixels"] == 0 and d["parity"]["frames_checked"] >= 2
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "workload" in d["config"]
     assert cb["all_cores"]["cores"] >= 1 and cb["all_cores"]["value"] > 0
+
+
+def test_bench_line_with_split_batches_and_every_stream_checked():
+    """64 streams: the headline context splits every batch into four launch groups on two raster lanes; by default every
+    stream of the last timed step is checked against the oracle."""
+    args = ["--steps", "3", "--warmup", "1", "--streams", "64", "--triangles", "8000", "--width", "320", "--height", "192", "--cpu-seconds", "0",
+            "--min-seconds", "0.3", "--isolated-seconds", "0.2", "--host-copy-seconds", "0"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert d["config"]["raster_lanes"] == 2 and d["config"]["launch_groups_per_batch"] == 4 and d["config"]["streams_per_launch_group"] == 16
+    assert d["parity"]["frames_checked"] == 64 and d["parity"]["mismatching_values"] == 0
+    rf = d["roofline"]
+    assert rf["streams_per_launch"] == 64 and rf["in_headline_run"]["streams_per_launch"] == 16 and rf["launches_per_step"] == 1
+    assert "with_host_copies" not in d and "cpu_baseline" not in d
 
 
 def test_bench_nccl_world1():
@@ -96,7 +118,7 @@ def test_bench_two_ranks_rehearsal_config4_and_config5():
 def test_bench_min_seconds_floor_and_per_gpu_share_flag():
     """--min-seconds repeats the --steps steps (whole multiples); --shard-of runs rank 0's share of a larger job."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--check-frames", "1",
-                        "--min-seconds", "0.2", "--workload", "c4", "--shard-of", "8", "--streams", "16", "--triangles", "8000", "--width", "320", "--height", "192"],
+                        "--min-seconds", "0.2", "--isolated-seconds", "0", "--host-copy-seconds", "0", "--workload", "c4", "--shard-of", "8", "--streams", "16", "--triangles", "8000", "--width", "320", "--height", "192"],
                        capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)

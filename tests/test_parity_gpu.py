@@ -1424,3 +1424,82 @@ def test_stl_facets_are_welded_at_load_and_the_image_does_not_change():
     assert bits_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     om, ok = O.filter_frame(depth[1], wl.projection[1], wl.oracle_draws(1), wl.offset_inv[1], wl.cam_tf[1], max_diff=wl.max_diff, replace_value=wl.replace_value)
     assert (ok != outs[1][1][1]).sum() == 0 and bits_equal(om, outs[1][0][1])
+
+
+# ---- raster lanes (ABI 5) -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("lanes,group,want_groups", [(2, 0, 4), (2, 24, 4), (2, 8, 8), (1, 0, 1), (1, 24, 3)])
+def test_raster_lanes_split_a_batch_into_launch_groups(lanes, group, want_groups):
+    """64 streams.  With two raster lanes (own HIP stream + own tile bins each) the batch is split into an even number of
+    launch groups that alternate between the lanes; with one lane into as many groups as the bins ask for, one after the
+    other.  Too-small bins force a regrowth (every lane's bins grow, both batches run again).  Every stream of every batch
+    equals the oracle, whatever the split; rtuf_stats reports it."""
+    import torch
+    n = 64
+    ctx, P, geo, depth, per = run_soups(128, 96, n, seed=77, raster_lanes=lanes, max_inflight_streams=group, bin_capacity=1)
+    masked, mask = ctx.filter_batch(depth)
+    check_vs_oracle(masked, mask, P, geo, depth, per)
+    st = ctx.stats()
+    assert st["raster_lanes"] == lanes and st["groups_last_batch"] == want_groups and st["regrowths"] >= 1, st
+    assert st["work_items"] > 0 and st["triangles_submitted"] == n * 350
+    assert (ctx.stream_handle() is None) == (lanes == 2)
+    # three device batches back to back (two in flight): the lanes run ahead of each other across batch boundaries
+    dev = torch.device("cuda:0")
+    d_in = [torch.from_numpy(np.roll(depth, k, axis=0).copy()).to(dev) for k in range(3)]
+    outs = [(torch.empty((n, 96, 128), dtype=torch.float32, device=dev), torch.empty((n, 96, 128), dtype=torch.uint8, device=dev)) for _ in range(3)]
+    torch.cuda.synchronize()
+    for k in range(3):
+        ctx.filter_batch_device(n, d_in[k].data_ptr(), outs[k][0].data_ptr(), outs[k][1].data_ptr())
+    # a caller's own stream ordered behind everything enqueued so far: its copies see finished planes
+    s_user = torch.cuda.Stream()
+    ctx.order_stream_after_batches(s_user.cuda_stream)
+    with torch.cuda.stream(s_user):
+        early = [(o[0].clone(), o[1].clone()) for o in outs]
+    s_user.synchronize()
+    ctx.sync()
+    for k in range(3):
+        dk = np.roll(depth, k, axis=0)
+        check_vs_oracle(outs[k][0].cpu().numpy(), outs[k][1].cpu().numpy(), P, geo, dk, per)
+        assert torch.equal(early[k][1], outs[k][1]) and torch.equal(early[k][0].view(torch.int32), outs[k][0].view(torch.int32))
+    assert ctx.stats()["regrowths"] == st["regrowths"]
+    ctx.close()
+
+
+def test_small_batches_take_the_lanes_in_turn():
+    """Batches below the split size are not split: each takes one lane, the next batch the other (so two small batches in
+    flight overlap on the GPU).  Six batches of 3 streams with different sensor planes, nothing waits in between."""
+    import torch
+    n, W, H = 3, 160, 120
+    ctx, P, geo, depth, per = run_soups(W, H, n, seed=31)
+    dev = torch.device("cuda:0")
+    d_in = [torch.from_numpy((depth + 0.01 * k).astype(np.float32)).to(dev) for k in range(6)]
+    outs = [(torch.empty((n, H, W), dtype=torch.float32, device=dev), torch.empty((n, H, W), dtype=torch.uint8, device=dev)) for _ in range(6)]
+    torch.cuda.synchronize()
+    for k in range(6):
+        ctx.filter_batch_device(n, d_in[k].data_ptr(), outs[k][0].data_ptr(), outs[k][1].data_ptr())
+    ctx.sync()
+    for k in range(6):
+        check_vs_oracle(outs[k][0].cpu().numpy(), outs[k][1].cpu().numpy(), P, geo, (depth + 0.01 * k).astype(np.float32), per)
+    st = ctx.stats()
+    assert st["raster_lanes"] == 2 and st["groups_last_batch"] == 1
+    ctx.close()
+
+
+def test_memory_limit_shrinks_the_launch_group_instead_of_failing():
+    """rtuf_params.memory_limit_mb bounds the tile bins of all lanes.  Bins of one record must grow on the first batch; the
+    grown bins no longer fit the limit for the launch group the context started with, so the group shrinks (the same bytes
+    hold deeper bins for fewer streams, the batch runs in more launches) -- the context stays usable and exact."""
+    n = 48
+    ctx, P, geo, depth, per = run_soups(128, 96, n, seed=78, bin_capacity=1, memory_limit_mb=1)
+    before = ctx.stats()
+    assert before["launch_group"] == 8, before          # 2 lanes x 8 streams x 6 tiles x (32 + 1024 x 8) B = 0.75 MiB (16 streams: 1.5)
+    masked, mask = ctx.filter_batch(depth)
+    check_vs_oracle(masked, mask, P, geo, depth, per)
+    st = ctx.stats()
+    assert st["regrowths"] >= 1 and st["launch_group"] < before["launch_group"] and st["groups_last_batch"] >= n // st["launch_group"], st
+    lanes_bins = 2 * st["launch_group"] * 6 * (st["bin_capacity"] * 32)
+    assert lanes_bins <= 1 << 20
+    masked2, mask2 = ctx.filter_batch(depth)          # steady state: no further regrowth, same answer
+    assert bits_equal(masked, masked2) and np.array_equal(mask, mask2) and ctx.stats()["regrowths"] == st["regrowths"]
+    ctx.close()
+    with pytest.raises(R.RtufError):
+        R.Context(128, 96, n, 0, params(raster_lanes=3))
