@@ -126,12 +126,13 @@ struct Share {
 
 int main(int argc, char** argv)
 {
-  if (argc < 2) { std::fprintf(stderr, "usage: %s scene.bin [--devices N] [--mode block|model] [--steps K] [--dump S PREFIX] [--masks direct|rccl|none]\n", argv[0]); return 2; }
+  if (argc < 2) { std::fprintf(stderr, "usage: %s scene.bin [--devices N | --all-devices] [--mode block|model] [--steps K] [--dump S PREFIX] [--masks direct|rccl|none]\n", argv[0]); return 2; }
   int want_devices = 0, steps = 3, dump_stream = -1;
   std::string mode = "block", dump_prefix, masks = "direct";
   for (int i = 2; i < argc; i++) {
     const std::string a = argv[i];
     if (a == "--devices" && i + 1 < argc) want_devices = std::atoi(argv[++i]);
+    else if (a == "--all-devices") want_devices = 0;                       // every visible device (also the default)
     else if (a == "--mode" && i + 1 < argc) mode = argv[++i];
     else if (a == "--steps" && i + 1 < argc) steps = std::atoi(argv[++i]);
     else if (a == "--masks" && i + 1 < argc) masks = argv[++i];
@@ -267,27 +268,18 @@ int main(int argc, char** argv)
     double frames = 0, slowest = 0, mismatches = 0;
     for (const auto& r : all) { frames += r.frames; slowest = r.seconds > slowest ? r.seconds : slowest; mismatches += r.mismatches; }
     long long gathered_ok = -1;
+    mg::GatherPath gather_path;
     if (masks != "none") {
-      int most = 0;
-      for (int n : per_device) most = n > most ? n : most;
       const bool direct = masks == "direct";
       std::vector<uint32_t*> d_all(N, nullptr);
       std::vector<const uint32_t*> d_in(N, nullptr);
       for (int d = 0; d < N; d++) {
         mg::check_hip(hipSetDevice(devices[d]), "hipSetDevice");
-        mg::check_hip(hipMalloc(&d_all[d], (size_t)(direct ? sc.n_streams : N * most) * words * sizeof(uint32_t)), "hipMalloc(all masks)");
-        if (!direct && per_device[d] < most) {         // RCCL wants equal contributions: pad this device's slice
-          uint32_t* padded = nullptr;
-          mg::check_hip(hipMalloc(&padded, (size_t)most * words * 4), "hipMalloc(padded)");
-          mg::check_hip(hipMemset(padded, 0, (size_t)most * words * 4), "hipMemset");
-          if (per_device[d]) mg::check_hip(hipMemcpy(padded, share[d].d_bits, (size_t)per_device[d] * words * 4, hipMemcpyDeviceToDevice), "pad copy");
-          d_in[d] = padded;
-        } else {
-          d_in[d] = share[d].d_bits;
-        }
+        mg::check_hip(hipMalloc(&d_all[d], (size_t)sc.n_streams * words * sizeof(uint32_t)), "hipMalloc(all masks)");
+        d_in[d] = share[d].d_bits;                     // slices as they are: the RCCL path pads and compacts internally
       }
-      group.all_gather_mask_bits(d_in, per_device, words, d_all, direct);
-      // every device now holds every stream's mask: compare each device's table with the sources
+      gather_path = group.all_gather_mask_bits(d_in, per_device, words, d_all, direct);
+      // every device now holds every stream's mask, densely, device 0's streams first: compare each table with the sources
       gathered_ok = 1;
       std::vector<uint32_t> ref((size_t)sc.n_streams * words), got;
       size_t first = 0;
@@ -298,16 +290,10 @@ int main(int argc, char** argv)
       }
       for (int d = 0; d < N; d++) {
         mg::check_hip(hipSetDevice(devices[d]), "hipSetDevice");
-        got.assign((size_t)(direct ? sc.n_streams : N * most) * words, 0u);
+        got.assign((size_t)sc.n_streams * words, 0u);
         mg::check_hip(hipMemcpy(got.data(), d_all[d], got.size() * 4, hipMemcpyDeviceToHost), "gathered download");
-        size_t f = 0;
-        for (int e = 0; e < N; e++) {
-          const uint32_t* slice = direct ? &got[f * words] : &got[(size_t)e * most * words];
-          if (per_device[e] && std::memcmp(slice, &ref[f * words], (size_t)per_device[e] * words * 4) != 0) gathered_ok = 0;
-          f += (size_t)per_device[e];
-        }
+        if (std::memcmp(got.data(), ref.data(), got.size() * 4) != 0) gathered_ok = 0;
         mg::check_hip(hipFree(d_all[d]), "hipFree");
-        if (d_in[d] != share[d].d_bits) mg::check_hip(hipFree(const_cast<uint32_t*>(d_in[d])), "hipFree");
       }
     }
 
@@ -346,10 +332,13 @@ int main(int argc, char** argv)
       if (share[d].d_depth) { (void)hipFree(share[d].d_depth); (void)hipFree(share[d].d_masked); (void)hipFree(share[d].d_mask); (void)hipFree(share[d].d_bits); }
     }
     std::printf("{\"devices\": %d, \"mode\": \"%s\", \"streams\": %d, \"steps\": %d, \"frames\": %.0f, \"seconds_slowest_device\": %.6f, \"frames_per_s\": %.1f, "
-                "\"bits_vs_bytes_mismatches\": %.0f, \"mask_all_gather\": \"%s\", \"gathered_masks_equal_sources\": %lld, \"per_device\": [",
-                N, mode.c_str(), sc.n_streams, steps, frames, slowest, slowest > 0 ? frames / slowest : 0.0, mismatches, masks.c_str(), gathered_ok);
+                "\"bits_vs_bytes_mismatches\": %.0f, \"mask_all_gather\": \"%s\", \"mask_all_gather_path\": \"%s\", \"peer_access_everywhere\": %d, "
+                "\"gathered_masks_equal_sources\": %lld, \"per_device\": [",
+                N, mode.c_str(), sc.n_streams, steps, frames, slowest, slowest > 0 ? frames / slowest : 0.0, mismatches, masks.c_str(),
+                masks == "none" ? "none" : (gather_path.direct ? "peer-to-peer copies" : (gather_path.fell_back ? "rccl (fell back: a device pair has no peer access)" : "rccl")),
+                group.peer_access_everywhere() ? 1 : 0, gathered_ok);
     for (int d = 0; d < N; d++)
-      std::printf("%s{\"device\": %d, \"streams\": %d, \"frames\": %.0f, \"seconds\": %.6f}", d ? ", " : "", devices[d], per_device[d], all[d].frames, all[d].seconds);
+      std::printf("%s{\"device\": %d, \"streams\": %d, \"frames\": %.0f, \"seconds\": %.6f, \"host_thread_pinned_to_cpus\": %d}", d ? ", " : "", devices[d], per_device[d], all[d].frames, all[d].seconds, group.pinned_cpus(d));
     std::printf("]}\n");
     return (mismatches == 0 && gathered_ok != 0) ? 0 : 1;
   } catch (const std::exception& e) {

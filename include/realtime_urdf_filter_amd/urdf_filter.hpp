@@ -12,6 +12,7 @@
 // (INTEGRATION.md).  Header-only; link with librtuf.so.
 #pragma once
 
+#include <cmath>
 #include <cstdio>
 #include <memory>
 #include <stdexcept>
@@ -267,6 +268,32 @@ class RealtimeURDFFilter {
   {
     prepare(width, height);
     if (renderers_.empty() || !stage_frame(glTf, timestamp)) return false;
+    if ((width_ & 3) != 0 && (is_16uc1 || !masked_out)) {
+      // The fused 16UC1 kernels and the bit-packed mask need a width that is a multiple of 4.  Any other camera goes through
+      // the full 32FC1 planes, with the reference's own two conversions (src/urdf_filter.cpp:287-288, :309-312: convertTo
+      // 0.001 / 1000.0, round half to even, saturated) done here on the host -- slower, and right for every width.
+      const size_t px = (size_t)width_ * height_;
+      scratch_in_.resize(is_16uc1 ? px : 0);
+      scratch_out_.resize(px);
+      const float* in = static_cast<const float*>(depth);
+      if (is_16uc1) {
+        const uint16_t* u = static_cast<const uint16_t*>(depth);
+        for (size_t i = 0; i < px; i++) scratch_in_[i] = (float)u[i] * 0.001f;
+        in = scratch_in_.data();
+      }
+      float* out = (masked_out && !is_16uc1) ? static_cast<float*>(masked_out) : scratch_out_.data();
+      check(rtuf_filter_batch(ctx_, 1, &in, &out, mask_out ? &mask_out : nullptr));
+      if (masked_out && is_16uc1) {
+        uint16_t* o = static_cast<uint16_t*>(masked_out);
+        for (size_t i = 0; i < px; i++) {
+          const float v = out[i] * 1000.0f;
+          long q = 0;
+          if (v >= -2147483648.0f && v < 2147483648.0f) q = std::lrintf(v);
+          o[i] = (uint16_t)(q < 0 ? 0 : (q > 65535 ? 65535 : q));
+        }
+      }
+      return true;
+    }
     if (!masked_out) {
       // mask only: one bit per pixel comes back over the bus (rtuf_filter_batch_bits*), expanded here
       bits_.resize(rtuf_mask_bits_words(width_, height_));
@@ -365,6 +392,7 @@ class RealtimeURDFFilter {
   std::vector<int> model_ids_;
   unsigned char* pending_buffer_ = nullptr;
   std::vector<uint32_t> bits_;
+  std::vector<float> scratch_in_, scratch_out_;      // filter_into for widths that are not a multiple of 4
 };
 
 }  // namespace realtime_urdf_filter

@@ -80,6 +80,7 @@ struct rtuf_context {
   bool finalized = false;
   bool broken = false;                 // a bin regrowth failed half-way: the bins are gone, every later filter call fails
   int n_links = 0, n_draws = 0, n_chunks = 0;
+  int key_shift = 3;                   // depth keys: draw order << key_shift (32 - the bits the context's draw orders need)
   int64_t n_tris = 0, n_cverts = 0;
   uint32_t bg_chunk = 0;
 
@@ -111,6 +112,7 @@ struct rtuf_context {
   // are ordered by its stream, which is all the hand-over its arrays need; lanes share nothing that is written per group.
   struct Lane {
     hipStream_t stream = nullptr;
+    hipEvent_t setup_done = nullptr;                             // recorded after every set-up kernel of the lane (see chain_lane)
     PackedTri* d_bins = nullptr; BinHeader* d_bin_hdr = nullptr;
     Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
     ClipItem* d_clip_list = nullptr;
@@ -123,6 +125,11 @@ struct rtuf_context {
   };
   Lane lane[kMaxLanes];
   int n_lanes = 1;
+  // The set-up kernels of consecutive launch groups form a chain across the lanes: group g's set-up starts when group
+  // g - 1's has finished (an event wait on the other lane's stream).  Without it both lanes start a batch at the same
+  // moment and run in lock step -- set-up beside set-up, tile kernel beside tile kernel, two kernels that want the same
+  // unit -- instead of one group's set-up (VALU) under the other's tile kernel (LDS atomics, HBM streaming).
+  int chain_lane = -1;                 // lane of the most recently enqueued set-up kernel
   int next_lane = 0;                   // lane of the next batch that is not split
   int last_lane = 0;                   // lane of the newest batch's last group (debug read-back of the z-surface)
   int group = 0;                       // streams per launch group at most (= streams a lane's bins are sized for)
@@ -482,7 +489,10 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
   // and two pipelines whose main streams share a queue do not overlap at all)
   const bool front = c->params.pipelines > 1;
   c->n_lanes = c->params.raster_lanes ? (int)c->params.raster_lanes : kMaxLanes;
-  for (int l = 0; l < c->n_lanes && e == hipSuccess && !front; l++) e = hipStreamCreateWithFlags(&c->lane[l].stream, hipStreamNonBlocking);
+  for (int l = 0; l < c->n_lanes && e == hipSuccess && !front; l++) {
+    e = hipStreamCreateWithFlags(&c->lane[l].stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->lane[l].setup_done, hipEventDisableTiming);
+  }
   if (e == hipSuccess && !front) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
   if (e != hipSuccess) {
     snprintf(g_create_error, sizeof g_create_error, "hip init failed: %s", hipGetErrorString(e));
@@ -559,7 +569,7 @@ void rtuf_destroy(rtuf_context* c)
   if (c->h2d) hipStreamDestroy(c->h2d);
   if (c->d2h) hipStreamDestroy(c->d2h);
   if (c->side) hipStreamDestroy(c->side);
-  for (auto& ln : c->lane) if (ln.stream) hipStreamDestroy(ln.stream);
+  for (auto& ln : c->lane) { if (ln.setup_done) hipEventDestroy(ln.setup_done); if (ln.stream) hipStreamDestroy(ln.stream); }
   delete c;
 }
 
@@ -855,6 +865,13 @@ int rtuf_finalize_models(rtuf_context* c)
   c->n_draws = (int)draws.size();
   c->n_tris = tri_seq;
   if (tri_seq >= (int64_t)kMaxOrder) return c->fail(RTUF_ERR_CAPACITY, "%lld triangles: draw-order keys are limited to %u", (long long)tri_seq, kMaxOrder);
+  {
+    // draw orders are 1 .. tri_seq (0 = background quad): the key's low word keeps the bits above them for the float z's
+    // low bits (at most 16: by then the exact-z pass is needed only within nanometres of the near plane)
+    int order_bits = 1;
+    while (((int64_t)1 << order_bits) <= tri_seq) order_bits++;
+    c->key_shift = std::min(32 - order_bits, 16);
+  }
   // background quad as the hidden last draw (used only when a stream's projection does not make
   // it a constant full-screen plane): GL_QUADS -> (0,1,3), (1,2,3); both get order 0
   {
@@ -1250,6 +1267,7 @@ static int issue_plan(rtuf_context* c, rtuf_context::Batch& b, const BatchPlan& 
 {
   const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
   auto mark = [&](size_t i, hipStream_t s) { hipEventRecord(get_event(b, i), s); };
+  if (b.timing) (void)get_event(b, kEvGroup0 + kEvPerGroup * plan.groups.size() - 1);      // (all of the batch's events exist)
   if (b.timing == 1) mark(kEvStart, sp);
   for (const FkArgs& fa : plan.fks) launch_fk(fa, sp);
   launch_pose(plan.pa, sp);
@@ -1271,8 +1289,10 @@ static int issue_plan(rtuf_context* c, rtuf_context::Batch& b, const BatchPlan& 
     uint32_t hint = 0;
     if (!worst_case_grid && c->items_hint && c->items_hint_streams > 0)
       hint = (uint32_t)(((uint64_t)c->items_hint * (uint64_t)gr.sa.group_size + (uint64_t)c->items_hint_streams - 1) / (uint64_t)c->items_hint_streams);
+    if (c->n_lanes > 1 && c->chain_lane >= 0 && c->chain_lane != gr.lane) HIP_TRY(c, hipStreamWaitEvent(st, c->lane[c->chain_lane].setup_done, 0));
     const uint32_t grid = launch_setup(gr.sa, hint, false, st);
     b.setup_grid[g] = worst_case_grid ? 0xffffffffu : grid;
+    if (c->n_lanes > 1) { HIP_TRY(c, hipEventRecord(c->lane[gr.lane].setup_done, st)); c->chain_lane = gr.lane; }
     if (b.timing >= 2) mark(e0 + 1, st);
     launch_clip(gr.sa, st);
     launch_bigrec(gr.sa, plan.cover_pass, st);      // appends the many-tile records the two kernels above listed (after the cover pass, if it is on)
@@ -1416,6 +1436,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     ta.max_diff = c->params.depth_distance_threshold; ta.replace_value = c->params.filter_replace_value;
     ta.sc_num = sc_num; ta.sc_off = sc_off;
     ta.io_u16 = io_u16 ? 1 : 0;
+    ta.key_shift = c->key_shift;
     ta.bits = b.bits;
     gr.compare = two && !b.bits;
     if (gr.compare) {

@@ -19,7 +19,8 @@
 //     bin_hdr   BinHeader[G][tiles]   records binned from the front (small boxes) and from the back of the bin, and the tile's
 //                                     cover (nearest triangle that covers the WHOLE tile): 16 bytes, one scalar load in the tile kernel
 //     bins      PackedTri[G][tiles][capacity]  (32 B records: small boxes from the front, larger from the back)
-//     fbin_count u32[G][tiles], fbins Frag[G][tiles][fcapacity]    (pixels of small triangles, 8 B)
+//     fbin_count u32[G][tiles], fbins Frag[G][tiles][fcapacity]    (pixels of small triangles, 8 B; top bit of the count: the
+//                                                                    record bin holds a near record, see KeyFmt)
 //     clip_list ClipItem[shards][clip_capacity]   triangles that cross a frustum plane (set-up kernel -> clip kernel)
 //     big_list  BigRec[shards][big_capacity]      records over more than 4 tiles (set-up / clip kernel -> bigrec_kernel)
 //     zsurface  f32[G][H][W]                       two-kernel mode only
@@ -291,6 +292,7 @@ struct TileArgs {
   float z_near, z_far, max_diff, replace_value;
   float sc_num, sc_off;          // z_near*z_far/(z_near-z_far) and z_far/(z_far-z_near) in float, as the shader computes them
   int io_u16;                    // 16UC1 in/out fused into the kernel (src/urdf_filter.cpp:287-288, :309-312)
+  int key_shift;                 // depth keys: draw order << key_shift in the low word, the float z's low bits below it (KeyFmt)
 };
 
 struct CompareArgs {

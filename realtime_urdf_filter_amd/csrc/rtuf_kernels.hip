@@ -647,6 +647,9 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int sha
     }
     uint32_t base = 0;
     if (act && lane == myleader) base = atomicAdd(&a.bin_hdr[bin >> 1].count[cls], (uint32_t)__popcll(mymask));
+    // a near record (it may produce window z <= 0.5) marks its bin: top bit of the fragment counter, read by the tile kernel
+    const unsigned long long nearm = __ballot(act && (pk.order & kNearBit) != 0u);
+    if (nearm && act && lane == myleader && (mymask & nearm)) atomicOr(&a.fbin_count[bin >> 1], 0x80000000u);
     base = __shfl(base, myleader);
     if (act) {
       const uint32_t pos = base + (uint32_t)__popcll(mymask & ((1ull << lane) - 1ull));
@@ -758,7 +761,7 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
       pending &= ~m;
     }
     uint32_t base = 0;
-    if (act && lane == myleader) base = atomicAdd(&a.fbin_count[bin], group_total);
+    if (act && lane == myleader) base = atomicAdd(&a.fbin_count[bin], group_total) & 0x7fffffffu;      // (top bit: the bin's near flag)
     base = __shfl(base, myleader);
     if (act) {
       uint32_t pos = base + base_in_group;
@@ -786,7 +789,7 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
       m &= m - 1;
       const int px = bx0 + (k & 3), py = by0 + (k >> 2);
       const int bin = __mul24(slot, tiles) + __mul24(py / kTileH, a.tiles_x) + (px / kTileW);
-      const uint32_t pos = atomicAdd(&a.fbin_count[bin], 1u);
+      const uint32_t pos = atomicAdd(&a.fbin_count[bin], 1u) & 0x7fffffffu;
       if (pos < a.fcapacity) {
         const float z = __fmaf_rn(dzdy, (float)py, __fmaf_rn(dzdx, (float)px, a0));
         const unsigned long long f = ((unsigned long long)z24_of(z) << 40) | ((unsigned long long)order << kFragPosBits) |
@@ -1401,6 +1404,7 @@ __global__ __launch_bounds__(256) void bigrec_kernel(SetupArgs a)
         if (!(zmax == zmax)) continue;
         const int bin = __mul24(qslot, tiles) + __mul24(ty, a.tiles_x) + tx;
         atomicMin(&a.bin_hdr[bin].cover, ((unsigned long long)z24_of(zmax) << 32) | my_id);
+        if (q.order & kNearBit) atomicOr(&a.fbin_count[bin], 0x80000000u);      // (a near cover: the tile's keys carry the float's low bits)
       }
       continue;
     }
@@ -1435,6 +1439,7 @@ __global__ __launch_bounds__(256) void bigrec_kernel(SetupArgs a)
             if (touches) {
               bin[jj] = b;
               pos[jj] = atomicAdd(&a.bin_hdr[b].count[1], 1u);          // many-tile records are large: back of the bin
+              if (q.order & kNearBit) atomicOr(&a.fbin_count[b], 0x80000000u);
               mine++;
             }
           }
@@ -1471,12 +1476,42 @@ __device__ __forceinline__ uint32_t* count_words() { __shared__ uint32_t s_cnt[2
 #define RTUF_COUNT_TEST() ((void)0)
 #endif
 
-template <int MODE>
-__device__ __forceinline__ void fragment(unsigned long long* keys, const TriRec& r, int px, int py, int lidx)
+// Depth keys: {z24, draw order << shift | low bits of the fragment's float z}.  The draw order takes as many of the low
+// word's bits as the context's triangle count needs (shift = 32 - those), the rest carries the LOW BITS OF THE FLOAT Z in
+// tiles that hold near geometry: the shader sees the unquantised gl_FragCoord.z, which below window z 0.5 is finer than
+// the 24-bit depth that decides the test -- but z24 pins z to an interval of 2^-24, and the float's low `shift` bits single
+// out one float in it as long as the interval holds fewer than 2^(shift-1) floats, i.e. for z24 >= 2^(26-shift)
+// (near_z_from_key; checked exhaustively on the CPU, tests/test_near_keys_cpu.py).  The low bits sit below the draw
+// order, and a triangle meets a pixel once, so they never decide a comparison: atomicMin still is "nearest 24-bit depth,
+// first drawn wins ties".  Round 3 re-walked every near record of such a tile to fetch the winners' float z (24,048 of
+// 38,400 tiles with the arm in front of the lens); now only winners closer than z24 < zexact still need that pass
+// (15 um in front of the near plane for the 250 k-triangle model).
+struct KeyFmt {
+  int shift;            // draw order << shift in the key's low word (TileArgs::key_shift)
+  uint32_t lowmask;     // (1 << shift) - 1 in tiles that hold near records (or a near cover), else 0
+  uint32_t zexact;      // winners with z24 < zexact need the exact-z pass: 2^(26-shift) in near tiles, else 2^23 + 1
+};
+
+// float z of a fragment from its 24-bit depth (zexact <= z24 <= 2^23) and the low `shift` bits of its float
+__device__ __forceinline__ float near_z_from_key(uint32_t z24, uint32_t low, int shift)
+{
+  const uint32_t cb = __float_as_uint(__fmul_rn((float)z24, 5.9604648328104515e-08f));      // about the middle of z24's interval
+  const uint32_t span = 1u << shift;
+  uint32_t cand = (cb & ~(span - 1u)) | low;
+  const int d = (int)(cand - cb);
+  const int half = (int)(span >> 1);
+  cand = d > half ? cand - span : (d < -half ? cand + span : cand);
+  return __uint_as_float(cand);
+}
+
+template <int MODE, bool LOW>
+__device__ __forceinline__ void fragment(unsigned long long* keys, const TriRec& r, int px, int py, int lidx, const KeyFmt& kf)
 {
   if (MODE == 0) RTUF_COUNT_TEST();
   const float z = __fmaf_rn(r.dzdy, (float)py, __fmaf_rn(r.dzdx, (float)px, r.a0));
-  const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | r.order;
+  // (r.order holds the draw order already shifted into place)
+  const uint32_t lo = LOW ? (r.order | (__float_as_uint(z) & kf.lowmask)) : r.order;
+  const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | lo;
   if (MODE == 0) {
     atomicMin(&keys[lidx], key);
   } else {
@@ -1539,16 +1574,16 @@ __device__ __forceinline__ TriRec broadcast_record(const TriRec& r, int src_lane
 // One lane's step of the cooperative paths: pixel (lx, ly) of the tile and the one below it (limited to the
 // box, qy1 inclusive).  Neighbouring lanes take neighbouring columns, so each of the two LDS atomics of a
 // step is conflict-free across the wave; the lower pixel's edge values are the upper one's plus B.
-template <int MODE>
-__device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriRec& q, int x_base, int y_base, int lx, int ly, int qy1)
+template <int MODE, bool LOW>
+__device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriRec& q, int x_base, int y_base, int lx, int ly, int qy1, const KeyFmt& kf)
 {
   const int px = x_base + lx, py = y_base + ly;
   const int e0 = __mul24(q.A[0], px) + __mul24(q.B[0], py) + q.C[0];
   const int e1 = __mul24(q.A[1], px) + __mul24(q.B[1], py) + q.C[1];
   const int e2 = __mul24(q.A[2], px) + __mul24(q.B[2], py) + q.C[2];
   const int lidx = ly * kTileW + lx;
-  if (min(e0, min(e1, e2)) > 0) fragment<MODE>(keys, q, px, py, lidx);
-  if (min(e0 + q.B[0], min(e1 + q.B[1], e2 + q.B[2])) > 0 && ly < qy1) fragment<MODE>(keys, q, px, py + 1, lidx + kTileW);
+  if (min(e0, min(e1, e2)) > 0) fragment<MODE, LOW>(keys, q, px, py, lidx, kf);
+  if (min(e0 + q.B[0], min(e1 + q.B[1], e2 + q.B[2])) > 0 && ly < qy1) fragment<MODE, LOW>(keys, q, px, py + 1, lidx + kTileW, kf);
 }
 
 // Rasterises the bin's records into the LDS key tile.  Every wave works on the records it loaded:
@@ -1559,13 +1594,13 @@ __device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriR
 // that lie behind it over their whole part of the tile are dropped when they are loaded.  MODE 1 looks only at records the
 // set-up marked as near (kNearBit) and, of those, only at the ones that can reach the lower half of the depth range here.
 
-template <int MODE>
+template <int MODE, bool LOW>
 __device__ __forceinline__ void raster_bin(unsigned long long* keys, const PackedTri* recs, uint32_t n,
                                            int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, uint32_t n_front, uint32_t capacity,
-                                           uint32_t* s_huge, TriRec* s_prec, uint4* s_pmeta, uint32_t zcover, const uint32_t* s_winners, int dbg_skip = 0)
+                                           uint32_t* s_huge, TriRec* s_prec, uint4* s_pmeta, uint32_t zcover, const uint32_t* s_winners, const KeyFmt& kf, int dbg_skip = 0)
 {
   const int lane = tid & 63;
-  const uint32_t zdrop = MODE == 1 ? min(zcover, 8388608u) : zcover;
+  const uint32_t zdrop = MODE == 1 ? min(zcover, kf.zexact - 1u) : zcover;      // MODE 1: only what can reach a depth that needs the pass
   for (uint32_t base = 0; base < n; base += kTileThreads) {
     const uint32_t i = base + tid;
     bool have = i < n;
@@ -1584,6 +1619,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     }
     if (have) {
       r = unpack_record(pk, width, height);
+      r.order <<= kf.shift;
       lx0 = max((int)(r.bbx & 0xffff) - x_base, 0);
       lx1 = min((int)(r.bbx >> 16) - x_base, kTileW - 1);
       ly0 = max((int)(r.bby & 0xffff) - y_base, 0);
@@ -1624,10 +1660,10 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
         if (todo > 0) {
           const bool right = px < px1, below = py < py_last;
           const int f0 = e0 + r.B[0], f1 = e1 + r.B[1], f2 = e2 + r.B[2];
-          if (min(e0, min(e1, e2)) > 0) fragment<MODE>(keys, r, px, py, lidx);
-          if (min(e0 + r.A[0], min(e1 + r.A[1], e2 + r.A[2])) > 0 && right) fragment<MODE>(keys, r, px + 1, py, lidx + 1);
-          if (min(f0, min(f1, f2)) > 0 && below) fragment<MODE>(keys, r, px, py + 1, lidx + kTileW);
-          if (min(f0 + r.A[0], min(f1 + r.A[1], f2 + r.A[2])) > 0 && right && below) fragment<MODE>(keys, r, px + 1, py + 1, lidx + kTileW + 1);
+          if (min(e0, min(e1, e2)) > 0) fragment<MODE, LOW>(keys, r, px, py, lidx, kf);
+          if (min(e0 + r.A[0], min(e1 + r.A[1], e2 + r.A[2])) > 0 && right) fragment<MODE, LOW>(keys, r, px + 1, py, lidx + 1, kf);
+          if (min(f0, min(f1, f2)) > 0 && below) fragment<MODE, LOW>(keys, r, px, py + 1, lidx + kTileW, kf);
+          if (min(f0 + r.A[0], min(f1 + r.A[1], f2 + r.A[2])) > 0 && right && below) fragment<MODE, LOW>(keys, r, px + 1, py + 1, lidx + kTileW + 1, kf);
           const bool wrap = px == px_lastq;
           e0 += wrap ? s0 : a0x2;
           e1 += wrap ? s1 : a1x2;
@@ -1675,7 +1711,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       const uint32_t inv = (uint32_t)ceilf(1048576.0f * __builtin_amdgcn_rcpf((float)qw));
       for (int idx = lane; idx < npair; idx += 64) {
         const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
-        raster_pair<MODE>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1);
+        raster_pair<MODE, LOW>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1, kf);
       }
     }
     unsigned long long big = __ballot(area > kSmallArea && area <= kQuarterArea);
@@ -1707,7 +1743,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       for (int idx = sub; __ballot(idx < npair); idx += 16) {
         if (idx < npair) {
           const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
-          raster_pair<MODE>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1);
+          raster_pair<MODE, LOW>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1, kf);
         }
       }
     }
@@ -1730,6 +1766,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
         uint4* dst = reinterpret_cast<uint4*>(&pk);
         dst[0] = src[0]; dst[1] = src[1];
         r = unpack_record(pk, width, height);
+        r.order <<= kf.shift;
       } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) reinterpret_cast<int*>(&r)[k] = 0;
@@ -1791,7 +1828,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
         const float zc = __fmaf_rn(q.dzdx, (float)px, q.a0);
         for (int ly = qy0 + (tid >> 6); ly <= qy1; ly += kTileThreads / 64) {
           const float z = __fmaf_rn(q.dzdy, (float)(y_base + ly), zc);
-          const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | q.order;
+          const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | (LOW ? (q.order | (__float_as_uint(z) & kf.lowmask)) : q.order);
           const int lidx = ly * kTileW + lane;
           if (MODE == 0) {
             RTUF_COUNT_TEST();
@@ -1805,13 +1842,13 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
           const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
           const int lx = qx0 + idx - __mul24(yy, qw), ly = qy0 + 2 * yy;
           const int lidx = ly * kTileW + lx;
-          fragment<MODE>(keys, q, x_base + lx, y_base + ly, lidx);
-          if (ly < qy1) fragment<MODE>(keys, q, x_base + lx, y_base + ly + 1, lidx + kTileW);
+          fragment<MODE, LOW>(keys, q, x_base + lx, y_base + ly, lidx, kf);
+          if (ly < qy1) fragment<MODE, LOW>(keys, q, x_base + lx, y_base + ly + 1, lidx + kTileW, kf);
         }
       } else {
         for (int idx = tid; idx < npair; idx += kTileThreads) {
           const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
-          raster_pair<MODE>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1);
+          raster_pair<MODE, LOW>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1, kf);
         }
       }
     }
@@ -1821,13 +1858,13 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
 
 // Fragments of the small triangles: 8 bytes each, perfectly coalesced, one LDS atomic each.  They never
 // need the exact-float-z pass (the set-up kernel keeps anything with window z near 0.5 or below as a record).
-__device__ __forceinline__ void raster_frags(unsigned long long* keys, const unsigned long long* frags, uint32_t nf, int tid, uint32_t zcover)
+__device__ __forceinline__ void raster_frags(unsigned long long* keys, const unsigned long long* frags, uint32_t nf, int tid, uint32_t zcover, int shift)
 {
   if (zcover == 0xffffffffu) {                 // (uniform) no cover: nothing to test per fragment
     for (uint32_t i = tid; i < nf; i += kTileThreads) {
       const unsigned long long f = frags[i];
       const int lidx = (int)((uint32_t)f & ((1u << kFragPosBits) - 1u));
-      const unsigned long long key = ((f >> 40) << 32) | ((f >> kFragPosBits) & (unsigned long long)kMaxOrder);
+      const unsigned long long key = ((f >> 40) << 32) | (((uint32_t)(f >> kFragPosBits) & kMaxOrder) << shift);
       RTUF_COUNT_TEST();
       atomicMin(&keys[lidx], key);
     }
@@ -1836,7 +1873,7 @@ __device__ __forceinline__ void raster_frags(unsigned long long* keys, const uns
   for (uint32_t i = tid; i < nf; i += kTileThreads) {
     const unsigned long long f = frags[i];
     const int lidx = (int)((uint32_t)f & ((1u << kFragPosBits) - 1u));
-    const unsigned long long key = ((f >> 40) << 32) | ((f >> kFragPosBits) & (unsigned long long)kMaxOrder);
+    const unsigned long long key = ((f >> 40) << 32) | (((uint32_t)(f >> kFragPosBits) & kMaxOrder) << shift);
     if ((uint32_t)(f >> 40) <= zcover) { RTUF_COUNT_TEST(); atomicMin(&keys[lidx], key); }        // (behind the tile's cover: cannot win)
   }
 }
@@ -1920,7 +1957,15 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
     count_front = h.x; count_back = h.y;
     cover = COVER ? ((unsigned long long)h.w << 32) | h.z : kNoCover;
   }
-  const uint32_t fcount = a.fbin_count[bin];
+  // fragment count, and in the top bit: the bin holds a near record (or its cover is one): the depth keys of this tile
+  // carry the low bits of the float z (KeyFmt)
+  const uint32_t fraw = a.fbin_count[bin];
+  const uint32_t fcount = fraw & 0x7fffffffu;
+  const bool near_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(fraw >> 31)) != 0u;
+  KeyFmt kf;
+  kf.shift = a.key_shift;
+  kf.lowmask = near_tile ? (1u << a.key_shift) - 1u : 0u;
+  kf.zexact = near_tile ? 1u << (26 - a.key_shift) : 8388609u;
   const uint32_t count = count_front + count_back;
   // (the stream's background entry after the bin's header in program order: the compiler then issues the three scalar loads
   // together -- with the background first it waited for it before it even computed the header's address)
@@ -1988,7 +2033,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       const CoverPlane c = cover_plane();
       for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
         const float z = __fmaf_rn(c.dzdy, (float)(y_base + i / kTileW), __fmaf_rn(c.dzdx, (float)(x_base + i % kTileW), c.a0));
-        const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | c.order;
+        const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | (c.order << kf.shift) | (__float_as_uint(z) & kf.lowmask);
         keys[i] = min(key, bgkey);
       }
     } else {
@@ -2007,22 +2052,30 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       if (fcount) atomicMax(&sh.max_fbin_fill, fcount);
       if (has_cover) atomicAdd(&sh.cover_tiles, 1u);
     }
+    // (two instances of the rasterisation: tiles without near geometry -- every tile of a robot at arm's length -- do not
+    // pay the instruction that puts the float's low bits into the key)
 #ifdef RTUF_ABLATE
-    if (!(a.flags & 0x800u)) raster_bin<0>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, (int)((a.flags >> 12) & 3u));
-    if (!(a.flags & 0x400u)) raster_frags(keys, frags, nf, tid, zcover);
+    if (!(a.flags & 0x800u)) {
+      if (near_tile) raster_bin<0, true>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, (int)((a.flags >> 12) & 3u));
+      else raster_bin<0, false>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, (int)((a.flags >> 12) & 3u));
+    }
+    if (!(a.flags & 0x400u)) raster_frags(keys, frags, nf, tid, zcover, kf.shift);
 #else
-    raster_bin<0>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners);
-    raster_frags(keys, frags, nf, tid, zcover);
+    if (near_tile) raster_bin<0, true>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf);
+    else raster_bin<0, false>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf);
+    raster_frags(keys, frags, nf, tid, zcover, kf.shift);
 #endif
     __syncthreads();
     if (tid == 0) s_huge[0] = 0;             // the exact-z pass below builds its list again
 
-    // Does any pixel need the exact float z of its winner?  Only when the winning depth is in the
-    // lower half of the depth range (z24 <= 2^23): above it, float z == (z24 + 1) * 2^-24 exactly.
+    // Does any pixel need a second look for the exact float z of its winner?  In the upper half of the depth range
+    // (z24 > 2^23) float z == (z24 + 1) * 2^-24 exactly; below, a tile with near geometry has the float's low bits in its
+    // keys, which settle everything but the last micrometres in front of the near plane (z24 < zexact); a tile without
+    // them has no record that could get there at all (the set-up marks those near) -- the test stays, it costs nothing.
     bool need = false;
     for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
       const unsigned long long k = keys[i];
-      if (k != bgkey && (uint32_t)(k >> 32) <= 8388608u) need = true;
+      if (k != bgkey && (uint32_t)(k >> 32) < kf.zexact) need = true;
     }
     if (__syncthreads_or(need)) {
       // which draw-order keys won such a pixel: only their records are walked again
@@ -2031,18 +2084,18 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       __syncthreads();
       for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
         const unsigned long long k = keys[i];
-        if (k != bgkey && (uint32_t)(k >> 32) <= 8388608u) {
-          const uint32_t h = winner_slot((uint32_t)k & kOrderMask);
+        if (k != bgkey && (uint32_t)(k >> 32) < kf.zexact) {
+          const uint32_t h = winner_slot((uint32_t)k >> kf.shift);
           atomicOr(&s_winners[h >> 5], 1u << (h & 31u));
         }
       }
       __syncthreads();
-      raster_bin<1>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners);
+      raster_bin<1, true>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf);
       if (has_cover) {                       // ... and the cover triangle, which is in no bin
         const CoverPlane c = cover_plane();
         for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
           const float z = __fmaf_rn(c.dzdy, (float)(y_base + i / kTileW), __fmaf_rn(c.dzdx, (float)(x_base + i % kTileW), c.a0));
-          const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | c.order;
+          const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | (c.order << kf.shift) | (__float_as_uint(z) & kf.lowmask);
           if (keys[i] == key) keys[i] = kResolvedBit | (unsigned long long)__float_as_uint(z);
         }
       }
@@ -2128,7 +2181,9 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
 #ifdef RTUF_COUNT
             if (r_px + j < a.width) atomicAdd(&count_words()[1], 1u);
 #endif
-            z[j] = (k & kResolvedBit) ? __uint_as_float((uint32_t)k) : __fmul_rn((float)((uint32_t)(k >> 32) + 1u), 5.9604644775390625e-08f);
+            const uint32_t khi = (uint32_t)(k >> 32);
+            z[j] = (k & kResolvedBit) ? __uint_as_float((uint32_t)k)
+                 : (khi > 8388608u ? __fmul_rn((float)(khi + 1u), 5.9604644775390625e-08f) : near_z_from_key(khi, (uint32_t)k & kf.lowmask, kf.shift));
             if (!TWO_KERNEL) thr[j] = shade_threshold(z[j], sc);
           }
         }

@@ -57,27 +57,31 @@ class TfProvider : public rtuf_host::TransformProvider {
 
 // What the private node handle must provide (names and meaning as in the reference's launch files; `device` is new).
 // One table instead of a sequence of getParam calls: the adapter's constructor walks it.
-struct RosParamSpec {
-  const char* name;
-  enum Kind { kString, kDouble, kBool, kInt } kind;
-  bool required;
-  size_t offset;                       // of the field in RosFilterConfig
-};
 struct RosFilterConfig {
   std::string fixed_frame, camera_frame;
   double depth_distance_threshold = 0.05, filter_replace_value = 0.0;
   bool show_gui = false;               // accepted, ignored: there is no window system behind this back end
   int device = 0;                      // which GPU
 };
+// (pointers to members, one per parameter type: RosFilterConfig holds std::strings, so it is not standard-layout and
+// offsetof on it would only be conditionally supported)
+struct RosParamSpec {
+  const char* name;
+  bool required;
+  std::string RosFilterConfig::*as_string;
+  double RosFilterConfig::*as_double;
+  bool RosFilterConfig::*as_bool;
+  int RosFilterConfig::*as_int;
+};
 inline const std::vector<RosParamSpec>& ros_param_table()
 {
   static const std::vector<RosParamSpec> table = {
-      {"fixed_frame", RosParamSpec::kString, true, offsetof(RosFilterConfig, fixed_frame)},
-      {"camera_frame", RosParamSpec::kString, true, offsetof(RosFilterConfig, camera_frame)},
-      {"depth_distance_threshold", RosParamSpec::kDouble, true, offsetof(RosFilterConfig, depth_distance_threshold)},
-      {"filter_replace_value", RosParamSpec::kDouble, false, offsetof(RosFilterConfig, filter_replace_value)},
-      {"show_gui", RosParamSpec::kBool, false, offsetof(RosFilterConfig, show_gui)},
-      {"device", RosParamSpec::kInt, false, offsetof(RosFilterConfig, device)},
+      {"fixed_frame", true, &RosFilterConfig::fixed_frame, nullptr, nullptr, nullptr},
+      {"camera_frame", true, &RosFilterConfig::camera_frame, nullptr, nullptr, nullptr},
+      {"depth_distance_threshold", true, nullptr, &RosFilterConfig::depth_distance_threshold, nullptr, nullptr},
+      {"filter_replace_value", false, nullptr, &RosFilterConfig::filter_replace_value, nullptr, nullptr},
+      {"show_gui", false, nullptr, nullptr, &RosFilterConfig::show_gui, nullptr},
+      {"device", false, nullptr, nullptr, nullptr, &RosFilterConfig::device},
   };
   return table;
 }
@@ -88,14 +92,11 @@ class RosFilter {
   {
     RosFilterConfig cfg;
     for (const RosParamSpec& spec : ros_param_table()) {
-      char* field = reinterpret_cast<char*>(&cfg) + spec.offset;
       bool found = false;
-      switch (spec.kind) {
-        case RosParamSpec::kString: found = nh_.getParam(spec.name, *reinterpret_cast<std::string*>(field)); break;
-        case RosParamSpec::kDouble: found = nh_.getParam(spec.name, *reinterpret_cast<double*>(field)); break;
-        case RosParamSpec::kBool: found = nh_.getParam(spec.name, *reinterpret_cast<bool*>(field)); break;
-        case RosParamSpec::kInt: found = nh_.getParam(spec.name, *reinterpret_cast<int*>(field)); break;
-      }
+      if (spec.as_string) found = nh_.getParam(spec.name, cfg.*spec.as_string);
+      else if (spec.as_double) found = nh_.getParam(spec.name, cfg.*spec.as_double);
+      else if (spec.as_bool) found = nh_.getParam(spec.name, cfg.*spec.as_bool);
+      else if (spec.as_int) found = nh_.getParam(spec.name, cfg.*spec.as_int);
       if (!found && spec.required) ROS_FATAL("private parameter ~%s is required", spec.name);
     }
     FilterParameters prm;
@@ -129,6 +130,16 @@ class RosFilter {
     if (!wants_depth && !wants_mask) return;
     const size_t bpp = u16 ? 2 : 4, row = (size_t)frame->width * bpp;
     if (frame->is_bigendian) { ROS_ERROR_THROTTLE(5.0, "input_depth: big-endian images are not supported"); return; }
+    // a message is untrusted input: its geometry must hold together before any row of it is read (cv_bridge did this for
+    // the reference) -- a short data vector would otherwise be read past its end by the compaction or the upload
+    if (frame->width == 0 || frame->height == 0 || (size_t)frame->step < row || frame->data.size() < (size_t)frame->step * frame->height) {
+      ROS_ERROR_THROTTLE(5.0, "input_depth: malformed image (%ux%u, step %u, %zu bytes)", frame->width, frame->height, frame->step, frame->data.size());
+      return;
+    }
+    if (camera_info->width != frame->width || camera_info->height != frame->height) {
+      ROS_ERROR_THROTTLE(5.0, "input_depth: camera_info is for %ux%u, the image is %ux%u", camera_info->width, camera_info->height, frame->width, frame->height);
+      return;
+    }
     // rows must be dense for the device upload; a padded image is compacted once
     const uint8_t* pixels = frame->data.data();
     if (frame->step != row) {

@@ -83,6 +83,10 @@ int main(int argc, char** argv)
   info->width = (uint32_t)W; info->height = (uint32_t)H;
   info->P[0] = std::atof(argv[5]); info->P[5] = std::atof(argv[6]); info->P[2] = std::atof(argv[7]); info->P[6] = std::atof(argv[8]); info->P[10] = 1;
 
+  // RTUF_MOCK_SHORT_IMAGE=<bytes>: a message whose data vector is that much shorter than step * height says it is;
+  // RTUF_MOCK_INFO_WIDTH=<w>: a camera_info that belongs to another image size.  The adapter must refuse both, not read on.
+  if (const char* cut = std::getenv("RTUF_MOCK_SHORT_IMAGE")) image->data.resize(image->data.size() - (size_t)std::atoi(cut));
+  if (const char* iw = std::getenv("RTUF_MOCK_INFO_WIDTH")) info->width = (uint32_t)std::atoi(iw);
   topics["input_depth"].callback(image, info);
 
   for (const std::string& l : ros::mock_log()) std::printf("log %s\n", l.c_str());

@@ -33,10 +33,10 @@ def test_adapter_sources_compile_against_the_mock(source):
     assert r.returncode == 0, r.stderr[-3000:]
 
 
-def run(tmp_path, depth, encoding, mode, pad=0, env=None):
+def run(tmp_path, depth, encoding, mode, pad=0, env=None, size=(640, 480), intrinsics=("525", "525", "319.5", "239.5")):
     (tmp_path / "m.urdf").write_text(WL.EXAMPLE_URDF)
     depth.tofile(tmp_path / "d.bin")
-    cmd = [harness(), str(tmp_path / "m.urdf"), str(tmp_path / "d.bin"), "640", "480", "525", "525", "319.5", "239.5", "5.0", encoding,
+    cmd = [harness(), str(tmp_path / "m.urdf"), str(tmp_path / "d.bin"), str(size[0]), str(size[1])] + list(intrinsics) + ["5.0", encoding,
            str(tmp_path / "o.depth"), str(tmp_path / "o.mask"), mode] + ([str(pad)] if pad else [])
     return subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **(env or {})))
 
@@ -87,3 +87,40 @@ def test_callback_32fc1_modes_and_padded_rows(tmp_path, mode, pad):
         assert np.array_equal(mask, fx.mask)
     else:
         assert np.array_equal(masked.view(np.uint32), fx.expected_masked().view(np.uint32))
+
+
+@pytest.mark.parametrize("env,what", [({"RTUF_MOCK_SHORT_IMAGE": "1000"}, "malformed image"), ({"RTUF_MOCK_INFO_WIDTH": "320"}, "camera_info is for 320x480")])
+def test_malformed_messages_are_refused_before_anything_is_read(tmp_path, env, what):
+    """A sensor_msgs/Image whose data vector is shorter than step * height, or whose camera_info belongs to another image
+    size, is reported and dropped (cv_bridge did that for the reference): no row of it is read, nothing is published, and the
+    GPU is never touched (this test runs without one)."""
+    fx = golden_io.Fixture("example_urdf_640x480")
+    r = run(tmp_path, fx.depth.astype(np.float32), "32FC1", "both", env=env)
+    assert "log ERROR: input_depth: " + what in r.stdout and "published depth 0 mask 0" in r.stdout, (r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("encoding,mode", [("16UC1", "both"), ("16UC1", "mask_only"), ("32FC1", "mask_only"), ("32FC1", "both")])
+def test_callback_width_that_is_not_a_multiple_of_four(tmp_path, encoding, mode):
+    """A 322-pixel-wide camera: the fused 16UC1 kernels and the bit-packed mask need width % 4 == 0, so the facade takes such
+    frames through the full 32FC1 planes and converts on the host with the reference's arithmetic -- every frame is
+    published, bit-identical to the oracle (these frames used to throw and never publish)."""
+    import oracle.bindings as O
+    import scenes as S
+    W, H = 322, 242
+    fx = golden_io.Fixture("example_urdf_640x480")
+    depth = S.sensor_depth(W, H, 3.0)
+    f, cx, cy = 525.0 * W / 640, (W - 1) / 2, (H - 1) / 2
+    P = S.projection(f, f, cx, cy, W, H)
+    data = depth_f32_to_u16(np.nan_to_num(depth, nan=0.0, posinf=0.0)) if encoding == "16UC1" else depth.astype(np.float32)
+    r = run(tmp_path, data, encoding, mode, size=(W, H), intrinsics=(repr(f), repr(f), repr(cx), repr(cy)))
+    assert r.returncode == 0 and "log " not in r.stdout, (r.stdout, r.stderr)
+    d32 = depth_u16_to_f32(data) if encoding == "16UC1" else data
+    om, ok = O.filter_frame(d32, P, fx.draws, fx.offset_inv, fx.cam_tf, max_diff=0.05, replace_value=5.0)
+    mask = np.fromfile(tmp_path / "o.mask", np.uint8).reshape(H, W)
+    assert np.array_equal(mask, ok) and mask.any()
+    if mode == "both":
+        if encoding == "16UC1":
+            assert np.array_equal(np.fromfile(tmp_path / "o.depth", np.uint16).reshape(H, W), depth_f32_to_u16(om))
+        else:
+            assert np.array_equal(np.fromfile(tmp_path / "o.depth", np.uint32).reshape(H, W), om.view(np.uint32))
