@@ -70,11 +70,14 @@ typedef struct {
   float depth_distance_threshold;   /* rosparam depth_distance_threshold -> shader uniform max_diff (:630) */
   float filter_replace_value;       /* rosparam filter_replace_value     -> shader uniform replace_value (:631) */
   uint32_t flags;                   /* RTUF_FLAG_* */
-  uint32_t bin_capacity;            /* triangles per (stream, screen tile) bin; 0 = automatic */
+  uint32_t bin_capacity;            /* triangles per (stream, screen tile) bin to start with (half per facing); 0 = automatic;
+                                       grown from what the first batches ask for */
   uint32_t max_inflight_streams;    /* streams rasterised per internal launch group (= streams a raster lane's bins are sized for);
-                                       0 = automatic: a quarter of max_streams with two raster lanes (256 streams: four
-                                       groups of 64, two per lane), the whole batch up to 1024 with one; fewer if the bins
-                                       would exceed a third of the free device memory or memory_limit_mb */
+                                       0 = automatic: half of max_streams with two raster lanes (256 streams: two groups of
+                                       128, one per lane), the whole batch up to 1024 with one; fewer if the bins would
+                                       exceed a third of the free device memory or memory_limit_mb.  Smaller groups trade
+                                       frames/s for memory: 256 VGA streams of a 250 k-triangle robot run at 478 k frames/s
+                                       in 8.8 GB with groups of 128, at 457 k in 4.5 GB with groups of 64 */
   uint32_t pipelines;               /* 0 / 1: one raster pipeline.  2..4: that many complete pipelines (HIP streams, bins,
                                        staging, geometry copy) inside the context; batches alternate between them, so the
                                        small and low-occupancy kernels of one batch (pose stage, cull, clip, kernel tails)
@@ -85,9 +88,8 @@ typedef struct {
   /* ABI 5 */
   uint32_t raster_lanes;            /* 0 = automatic (2).  A raster lane is a HIP stream plus a set of tile bins sized for ONE launch
                                        group.  With 2, a batch of >= 32 streams is split into an even number of launch groups that
-                                       alternate between the lanes: group B's set-up kernel (VALU-bound, no LDS traffic to speak
-                                       of) runs under group A's tile kernel (LDS atomics + HBM streaming), and every kernel's ramp,
-                                       tail and launch gap is filled by the other lane.  Smaller batches take one lane each, in
+                                       alternate between the lanes, which run free of each other: every kernel's ramp, tail and
+                                       launch gap is filled by the other lane's kernels.  Smaller batches take one lane each, in
                                        turn.  1 = one lane, every kernel alone on the GPU (what per-kernel timings and rooflines
                                        should be measured with).  Fixed at rtuf_create. */
   uint32_t memory_limit_mb;         /* upper bound of the rasteriser's working set (tile bins of all lanes), MiB; 0 = a third of
@@ -293,8 +295,8 @@ typedef struct {
   uint64_t triangles_binned;        /* (sub-)triangles that reached at least one tile  */
   uint64_t bin_entries;             /* records written to tile bins                    */
   uint64_t triangles_clipped;       /* triangles that went through the clipper         */
-  uint32_t max_bin_fill;            /* largest bin of the last batch                   */
-  uint32_t bin_capacity;
+  uint32_t max_bin_fill;            /* fullest half-bin of the last batch (a (stream, tile) bin is two: one per facing) */
+  uint32_t bin_capacity;            /* records per half-bin                             */
   uint32_t regrowths;               /* times the bins were enlarged and a batch re-run */
   uint32_t max_fbin_fill;           /* largest fragment bin of the last batch          */
   uint64_t fragments_binned;        /* covered pixels of small (<= 4x4 px box) triangles binned as fragments */
@@ -322,6 +324,9 @@ typedef struct {
   uint32_t graphs_enabled;          /* 1 while small batches replay captured hipGraphs (pipeline children only); the library
                                        switches them off for good when captures keep evicting live entries               */
   uint64_t graph_hits, graph_misses;/* replays / captures so far                                                          */
+  uint64_t hiz_culled_entries;      /* bin records the tile kernel dropped before their walk: second facing, behind the depth
+                                       bound of every 8x8 block their box touches (the back of every closed link, whatever a
+                                       near link hides)                                                                    */
 } rtuf_stats;
 int rtuf_get_stats(rtuf_context *ctx, rtuf_stats *out);
 /* Per-kernel HIP-event timing (off by default: every event costs a few microseconds of stream

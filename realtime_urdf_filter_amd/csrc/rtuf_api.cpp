@@ -112,7 +112,6 @@ struct rtuf_context {
   // are ordered by its stream, which is all the hand-over its arrays need; lanes share nothing that is written per group.
   struct Lane {
     hipStream_t stream = nullptr;
-    hipEvent_t setup_done = nullptr;                             // recorded after every set-up kernel of the lane (see chain_lane)
     PackedTri* d_bins = nullptr; BinHeader* d_bin_hdr = nullptr;
     Frag* d_fbins = nullptr; uint32_t* d_fbin_count = nullptr;
     ClipItem* d_clip_list = nullptr;
@@ -125,11 +124,11 @@ struct rtuf_context {
   };
   Lane lane[kMaxLanes];
   int n_lanes = 1;
-  // The set-up kernels of consecutive launch groups form a chain across the lanes: group g's set-up starts when group
-  // g - 1's has finished (an event wait on the other lane's stream).  Without it both lanes start a batch at the same
-  // moment and run in lock step -- set-up beside set-up, tile kernel beside tile kernel, two kernels that want the same
-  // unit -- instead of one group's set-up (VALU) under the other's tile kernel (LDS atomics, HBM streaming).
-  int chain_lane = -1;                 // lane of the most recently enqueued set-up kernel
+  // (The lanes run free of each other.  Chaining the set-up kernels across the lanes, so that one group's set-up always
+  // runs under the other group's tile kernel, was measured and is WORSE -- 426 k instead of 457 k frames/s at four groups,
+  // 466 k instead of 478 k at two: both kernels are bound by VALU issue, and side by side the set-up kernel loses the
+  // occupancy its latency hiding needs.  What the lanes buy is each kernel's ramp, tail and launch gap filled by the other
+  // lane)
   int next_lane = 0;                   // lane of the next batch that is not split
   int last_lane = 0;                   // lane of the newest batch's last group (debug read-back of the z-surface)
   int group = 0;                       // streams per launch group at most (= streams a lane's bins are sized for)
@@ -310,9 +309,10 @@ static int regrow(rtuf_context* c, T*& buf, size_t new_bytes, const char* what)
   return RTUF_OK;
 }
 
+// (cap = records per HALF-bin: a (stream, tile) bin is two of them, one per facing)
 static size_t lane_bins_bytes(const rtuf_context* c, int G, uint32_t cap, uint32_t fcap)
 {
-  return (size_t)G * (size_t)c->tiles_x * c->tiles_y * ((size_t)cap * sizeof(PackedTri) + (size_t)fcap * sizeof(Frag));
+  return (size_t)G * (size_t)c->tiles_x * c->tiles_y * ((size_t)2 * cap * sizeof(PackedTri) + (size_t)fcap * sizeof(Frag));
 }
 
 // The per-batch counter blocks (one per launch group) follow the number of groups a full batch is split into.
@@ -354,7 +354,7 @@ static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
     for (int l = 0; l < c->n_lanes && e == hipSuccess; l++) {
       rtuf_context::Lane& ln = c->lane[l];
       // (a smaller group with deeper bins may fit the allocation that is there)
-      const size_t want = (size_t)G * c->tiles_x * c->tiles_y * (size_t)cap * sizeof(PackedTri);
+      const size_t want = (size_t)G * c->tiles_x * c->tiles_y * (size_t)2 * cap * sizeof(PackedTri);
       const size_t fwant = (size_t)G * c->tiles_x * c->tiles_y * (size_t)fcap * sizeof(Frag);
       auto have = [&](void* q) { auto it = c->dev_blocks.find(q); return (q && it != c->dev_blocks.end()) ? it->second : (size_t)0; };
       if (have(ln.d_bins) < want) e = realloc_dev(c, ln.d_bins, want);
@@ -489,10 +489,7 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
   // and two pipelines whose main streams share a queue do not overlap at all)
   const bool front = c->params.pipelines > 1;
   c->n_lanes = c->params.raster_lanes ? (int)c->params.raster_lanes : kMaxLanes;
-  for (int l = 0; l < c->n_lanes && e == hipSuccess && !front; l++) {
-    e = hipStreamCreateWithFlags(&c->lane[l].stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->lane[l].setup_done, hipEventDisableTiming);
-  }
+  for (int l = 0; l < c->n_lanes && e == hipSuccess && !front; l++) e = hipStreamCreateWithFlags(&c->lane[l].stream, hipStreamNonBlocking);
   if (e == hipSuccess && !front) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
   if (e != hipSuccess) {
     snprintf(g_create_error, sizeof g_create_error, "hip init failed: %s", hipGetErrorString(e));
@@ -569,7 +566,7 @@ void rtuf_destroy(rtuf_context* c)
   if (c->h2d) hipStreamDestroy(c->h2d);
   if (c->d2h) hipStreamDestroy(c->d2h);
   if (c->side) hipStreamDestroy(c->side);
-  for (auto& ln : c->lane) { if (ln.setup_done) hipEventDestroy(ln.setup_done); if (ln.stream) hipStreamDestroy(ln.stream); }
+  for (auto& ln : c->lane) if (ln.stream) hipStreamDestroy(ln.stream);
   delete c;
 }
 
@@ -696,30 +693,34 @@ static int alloc_frame_buffers(rtuf_context* c)
   // rasteriser working set
   // Launch group = the streams one lane's bins are sized for.  One lane: the whole batch up to 1024 streams (kernels of 4x
   // the work lose 4x less to their ramp and tail: 1024 streams in one group 522 k frames/s, in four groups of 256 one
-  // after the other 460 k).  Two lanes: a quarter of the streams -- a full batch then is four groups, two per lane, the
-  // lanes' kernels fill each other's ramps and tails, and the bins are half of what one group for all streams would take.
+  // after the other 460 k).  Two lanes: half of the streams -- a full batch is two groups, one per lane, the lanes'
+  // kernels fill each other's ramps, tails and launch gaps, and the bins are what one group for all streams would take.
+  // (Measured on the 256-stream VGA workload: two groups of 128 478 k frames/s in 8.8 GB, four of 64 457 k in 4.5 GB,
+  // eight of 32 365 k in 2.2 GB, one lane 446 k in 8.7 GB; rtuf_params.memory_limit_mb / max_inflight_streams pick the
+  // smaller working sets.)
   int G = c->params.max_inflight_streams ? (int)c->params.max_inflight_streams
-                                         : (c->n_lanes > 1 && N >= kSplitMin ? std::max((N + 3) / 4, 16) : 1024);
+                                         : (c->n_lanes > 1 && N >= kSplitMin ? std::min((N + 1) / 2, 1024) : 1024);
   G = std::min(G, N);
   // Bins: fixed capacity per (stream, tile), direct addressing (one atomicAdd gives the slot: anything cleverer -- paged
   // bins were built and measured, DESIGN.md section 4b -- costs the two big kernels 8 to 24 %).  What is NOT fixed any more is
   // the size: 1024 records + 4096 fragments per bin to start with (64 KiB per bin), grown on the first
   // batch to a quarter above the fullest bin that batch produced (the 250 k-triangle robot: 3840 + 13568; round 2
   // reserved 8192 + 32768 whatever the scene).  rtuf_params.bin_capacity fixes the starting point.
-  uint32_t cap = c->params.bin_capacity ? c->params.bin_capacity : 1024u;
+  // (capacity = records per half-bin, one half per facing; rtuf_params.bin_capacity counts per (stream, tile) bin)
+  uint32_t cap = c->params.bin_capacity ? std::max(c->params.bin_capacity / 2u, 1u) : 512u;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
   c->memory_budget = std::max(free_b / 3, (size_t)1 << 30);
   if (c->params.memory_limit_mb) c->memory_budget = (size_t)c->params.memory_limit_mb << 20;
   c->capacity = cap;
-  c->fcapacity = std::max<uint32_t>(4 * cap, 1024);   // 8-byte fragments of all boxes up to 4x4 pixel centres
+  c->fcapacity = std::max<uint32_t>(8 * cap, 1024);   // 8-byte fragments of all boxes up to 4x4 pixel centres
   while (G > 1 && (size_t)c->n_lanes * lane_bins_bytes(c, G, c->capacity, c->fcapacity) > c->memory_budget) G = (G + 1) / 2;
   c->group = G;
   c->clip_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 8192 / kCounterShards, 1024), (size_t)1 << 22);   // per shard
   c->big_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 64, 1024), (size_t)1 << 20);                 // per shard
   for (int l = 0; l < c->n_lanes; l++) {
     rtuf_context::Lane& ln = c->lane[l];
-    HIP_TRY(c, dev_alloc(c, &ln.d_bins, (size_t)G * tiles * cap * sizeof(PackedTri)));
+    HIP_TRY(c, dev_alloc(c, &ln.d_bins, (size_t)G * tiles * 2 * cap * sizeof(PackedTri)));
     HIP_TRY(c, dev_alloc(c, &ln.d_bin_hdr, (size_t)G * tiles * sizeof(BinHeader)));
     HIP_TRY(c, dev_alloc(c, &ln.d_fbins, (size_t)G * tiles * c->fcapacity * sizeof(Frag)));
     HIP_TRY(c, dev_alloc(c, &ln.d_fbin_count, (size_t)G * tiles * sizeof(uint32_t)));
@@ -1289,10 +1290,8 @@ static int issue_plan(rtuf_context* c, rtuf_context::Batch& b, const BatchPlan& 
     uint32_t hint = 0;
     if (!worst_case_grid && c->items_hint && c->items_hint_streams > 0)
       hint = (uint32_t)(((uint64_t)c->items_hint * (uint64_t)gr.sa.group_size + (uint64_t)c->items_hint_streams - 1) / (uint64_t)c->items_hint_streams);
-    if (c->n_lanes > 1 && c->chain_lane >= 0 && c->chain_lane != gr.lane) HIP_TRY(c, hipStreamWaitEvent(st, c->lane[c->chain_lane].setup_done, 0));
     const uint32_t grid = launch_setup(gr.sa, hint, false, st);
     b.setup_grid[g] = worst_case_grid ? 0xffffffffu : grid;
-    if (c->n_lanes > 1) { HIP_TRY(c, hipEventRecord(c->lane[gr.lane].setup_done, st)); c->chain_lane = gr.lane; }
     if (b.timing >= 2) mark(e0 + 1, st);
     launch_clip(gr.sa, st);
     launch_bigrec(gr.sa, plan.cover_pass, st);      // appends the many-tile records the two kernels above listed (after the cover pass, if it is on)
@@ -1566,7 +1565,7 @@ static int retire_oldest(rtuf_context* c)
     if (!c->pending || !b.active) { c->pending = 0; return RTUF_OK; }
     for (int l = 0; l < c->n_lanes; l++)
       if (b.lanes_used >> l & 1u) HIP_TRY(c, hipEventSynchronize(b.done[l]));
-    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0, occluded = 0, raster_atomics = 0, drawn_pixels = 0, work_items = 0;
+    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0, occluded = 0, raster_atomics = 0, drawn_pixels = 0, work_items = 0, hiz_culled = 0;
              unsigned max_bin_fill = 0, max_fbin_fill = 0, clip_overflow = 0, uncovered = 0, max_big_fill = 0, cover_tiles = 0, exact_tiles = 0, zero_items = 0,
                       max_items = 0; } k;
     bool list_over = false;                    // some group's set-up grid was sized too small for its work list
@@ -1583,7 +1582,7 @@ static int retire_oldest(rtuf_context* c)
         k.max_fbin_fill = std::max(k.max_fbin_fill, sh.max_fbin_fill); k.frags += sh.frags; k.uncovered |= sh.uncovered;
         k.max_big_fill = std::max(k.max_big_fill, sh.max_big_fill);
         k.occluded += sh.occluded; k.cover_tiles += sh.cover_tiles; k.exact_tiles += sh.exact_tiles; k.zero_items += sh.zero_items;
-        k.raster_atomics += sh.raster_atomics; k.drawn_pixels += sh.drawn_pixels;
+        k.raster_atomics += sh.raster_atomics; k.drawn_pixels += sh.drawn_pixels; k.hiz_culled += sh.hiz_culled;
       }
     }
     group_streams = (b.n + b.n_groups - 1) / std::max(b.n_groups, 1);
@@ -1602,6 +1601,7 @@ static int retire_oldest(rtuf_context* c)
     c->stats.raster_atomics = k.raster_atomics; c->stats.drawn_pixels = k.drawn_pixels;
     c->stats.cover_pass = b.cover_pass ? 1u : 0u;
     c->stats.groups_last_batch = (uint32_t)b.n_groups;
+    c->stats.hiz_culled_entries = k.hiz_culled;
     const bool bin_over = k.max_bin_fill > c->capacity || k.max_fbin_fill > c->fcapacity;
     const bool clip_over = k.clip_overflow != 0;
     const bool big_over = k.max_big_fill > c->big_capacity;

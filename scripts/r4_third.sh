@@ -1,0 +1,20 @@
+#!/bin/bash
+out=gpurun_out/r4_third; mkdir -p $out
+line() { python - "$1" <<'PY' | tee -a gpurun_out/r4_third/summary.txt
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    r=d["roofline"]; ks={e["kernel"]:e for e in [r]+r["all_kernels"]}
+    print(round(d["value"]), "frames/s", round(d["device_memory_bytes"]/1e9,2), "GB", d["config"]["raster_lanes"], "lanes", d["config"]["launch_groups_per_batch"], "groups", "parity", d["parity"]["frames_checked"], d["parity"]["mismatching_values"],
+          {k.split("_")[0]:(round(v["avg_launch_ms"]*1e3,1), round((v.get("in_headline_run") or {}).get("avg_launch_ms",0)*1e3,1)) for k,v in ks.items()}, "one-lane", round((r.get("one_lane_leg") or {}).get("frames_per_s",0)), "exact tiles", d["rasteriser"]["tile"]["exact_z_tiles"])
+except Exception as e:
+    print("no line", e)
+PY
+}
+for v in "" "--launch-group 128" "--launch-group 96" "--near-arm" "--near-arm --launch-group 128" "--workload c4 --shard-of 8" "--workload c4 --shard-of 8 --launch-group 32" "--workload c5 --shard-of 8" "--workload c5 --shard-of 8 --launch-group 512" "--streams 1 --steps 500"; do
+  tag=$(echo "default$v" | tr -d ' -')
+  timeout 600 python bench.py --cpu-seconds 0 --host-copy-seconds 0 --min-seconds 2 --isolated-seconds 1 $v > $out/bench_$tag.json 2> $out/bench_$tag.err; echo "bench [$v] rc=$?" | tee -a $out/summary.txt
+  line $out/bench_$tag.json
+done
+timeout 1500 python -m pytest tests/test_ros_adapter.py tests/test_baseline_configs_gpu.py tests/test_bench_gpu.py -x -q -m gpu > $out/gpu_tests.txt 2>&1; echo "gpu subset rc=$?" | tee -a $out/summary.txt
+tail -5 $out/gpu_tests.txt

@@ -50,17 +50,17 @@ def test_bench_line_contract():
 
 
 def test_bench_line_with_split_batches_and_every_stream_checked():
-    """64 streams: the headline context splits every batch into four launch groups on two raster lanes; by default every
+    """64 streams: the headline context splits every batch into two launch groups, one per raster lane; by default every
     stream of the last timed step is checked against the oracle."""
     args = ["--steps", "3", "--warmup", "1", "--streams", "64", "--triangles", "8000", "--width", "320", "--height", "192", "--cpu-seconds", "0",
             "--min-seconds", "0.3", "--isolated-seconds", "0.2", "--host-copy-seconds", "0"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
-    assert d["config"]["raster_lanes"] == 2 and d["config"]["launch_groups_per_batch"] == 4 and d["config"]["streams_per_launch_group"] == 16
+    assert d["config"]["raster_lanes"] == 2 and d["config"]["launch_groups_per_batch"] == 2 and d["config"]["streams_per_launch_group"] == 32
     assert d["parity"]["frames_checked"] == 64 and d["parity"]["mismatching_values"] == 0
     rf = d["roofline"]
-    assert rf["streams_per_launch"] == 64 and rf["in_headline_run"]["streams_per_launch"] == 16 and rf["launches_per_step"] == 1
+    assert rf["streams_per_launch"] == 64 and rf["in_headline_run"]["streams_per_launch"] == 32 and rf["launches_per_step"] == 1
     assert "with_host_copies" not in d and "cpu_baseline" not in d
 
 
