@@ -531,7 +531,7 @@ def main():
                            "fragments_binned": st["fragments_binned"], "max_bin_fill": st["max_bin_fill"], "max_fragment_bin_fill": st["max_fbin_fill"], "bin_capacity": st["bin_capacity"], "regrowths": st["regrowths"],
                            "setup": {"work_items": st["work_items"], "zero_survivor_items": st["zero_survivor_items"],
                                      "note": "work item = one set-up workgroup: a chunk of <= 256 triangles x up to 3 streams whose frustum its box touches; zero-survivor = none of its triangles reached a bin or the clip list's survivors (sub-pixel or outside)"},
-                           "tile": {"cover_tiles": st["cover_tiles"], "occluded_entries": st["occluded_entries"], "exact_z_tiles": st["exact_tiles"], "hiz_culled_entries": st["hiz_culled_entries"],
+                           "tile": {"cover_tiles": st["cover_tiles"], "occluded_entries": st["occluded_entries"], "exact_z_tiles": st["exact_tiles"],
                                     "tiles_per_launch": int(round(n / groups_per_batch)) * ((W + 63) // 64) * ((H + 31) // 32), "overdraw": overdraw}},
             "device_memory_bytes": st["device_bytes"],
             "roofline": roof,

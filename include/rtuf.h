@@ -70,8 +70,8 @@ typedef struct {
   float depth_distance_threshold;   /* rosparam depth_distance_threshold -> shader uniform max_diff (:630) */
   float filter_replace_value;       /* rosparam filter_replace_value     -> shader uniform replace_value (:631) */
   uint32_t flags;                   /* RTUF_FLAG_* */
-  uint32_t bin_capacity;            /* triangles per (stream, screen tile) bin to start with (half per facing); 0 = automatic;
-                                       grown from what the first batches ask for */
+  uint32_t bin_capacity;            /* triangles per (stream, screen tile) bin to start with; 0 = automatic (1024); grown from what
+                                       the first batches ask for */
   uint32_t max_inflight_streams;    /* streams rasterised per internal launch group (= streams a raster lane's bins are sized for);
                                        0 = automatic: half of max_streams with two raster lanes (256 streams: two groups of
                                        128, one per lane), the whole batch up to 1024 with one; fewer if the bins would
@@ -295,8 +295,8 @@ typedef struct {
   uint64_t triangles_binned;        /* (sub-)triangles that reached at least one tile  */
   uint64_t bin_entries;             /* records written to tile bins                    */
   uint64_t triangles_clipped;       /* triangles that went through the clipper         */
-  uint32_t max_bin_fill;            /* fullest half-bin of the last batch (a (stream, tile) bin is two: one per facing) */
-  uint32_t bin_capacity;            /* records per half-bin                             */
+  uint32_t max_bin_fill;            /* largest bin of the last batch                   */
+  uint32_t bin_capacity;
   uint32_t regrowths;               /* times the bins were enlarged and a batch re-run */
   uint32_t max_fbin_fill;           /* largest fragment bin of the last batch          */
   uint64_t fragments_binned;        /* covered pixels of small (<= 4x4 px box) triangles binned as fragments */
@@ -324,9 +324,6 @@ typedef struct {
   uint32_t graphs_enabled;          /* 1 while small batches replay captured hipGraphs (pipeline children only); the library
                                        switches them off for good when captures keep evicting live entries               */
   uint64_t graph_hits, graph_misses;/* replays / captures so far                                                          */
-  uint64_t hiz_culled_entries;      /* bin records the tile kernel dropped before their walk: second facing, behind the depth
-                                       bound of every 8x8 block their box touches (the back of every closed link, whatever a
-                                       near link hides)                                                                    */
 } rtuf_stats;
 int rtuf_get_stats(rtuf_context *ctx, rtuf_stats *out);
 /* Per-kernel HIP-event timing (off by default: every event costs a few microseconds of stream

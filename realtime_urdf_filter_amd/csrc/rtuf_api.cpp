@@ -309,10 +309,9 @@ static int regrow(rtuf_context* c, T*& buf, size_t new_bytes, const char* what)
   return RTUF_OK;
 }
 
-// (cap = records per HALF-bin: a (stream, tile) bin is two of them, one per facing)
 static size_t lane_bins_bytes(const rtuf_context* c, int G, uint32_t cap, uint32_t fcap)
 {
-  return (size_t)G * (size_t)c->tiles_x * c->tiles_y * ((size_t)2 * cap * sizeof(PackedTri) + (size_t)fcap * sizeof(Frag));
+  return (size_t)G * (size_t)c->tiles_x * c->tiles_y * ((size_t)cap * sizeof(PackedTri) + (size_t)fcap * sizeof(Frag));
 }
 
 // The per-batch counter blocks (one per launch group) follow the number of groups a full batch is split into.
@@ -354,7 +353,7 @@ static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
     for (int l = 0; l < c->n_lanes && e == hipSuccess; l++) {
       rtuf_context::Lane& ln = c->lane[l];
       // (a smaller group with deeper bins may fit the allocation that is there)
-      const size_t want = (size_t)G * c->tiles_x * c->tiles_y * (size_t)2 * cap * sizeof(PackedTri);
+      const size_t want = (size_t)G * c->tiles_x * c->tiles_y * (size_t)cap * sizeof(PackedTri);
       const size_t fwant = (size_t)G * c->tiles_x * c->tiles_y * (size_t)fcap * sizeof(Frag);
       auto have = [&](void* q) { auto it = c->dev_blocks.find(q); return (q && it != c->dev_blocks.end()) ? it->second : (size_t)0; };
       if (have(ln.d_bins) < want) e = realloc_dev(c, ln.d_bins, want);
@@ -706,21 +705,20 @@ static int alloc_frame_buffers(rtuf_context* c)
   // the size: 1024 records + 4096 fragments per bin to start with (64 KiB per bin), grown on the first
   // batch to a quarter above the fullest bin that batch produced (the 250 k-triangle robot: 3840 + 13568; round 2
   // reserved 8192 + 32768 whatever the scene).  rtuf_params.bin_capacity fixes the starting point.
-  // (capacity = records per half-bin, one half per facing; rtuf_params.bin_capacity counts per (stream, tile) bin)
-  uint32_t cap = c->params.bin_capacity ? std::max(c->params.bin_capacity / 2u, 1u) : 512u;
+  uint32_t cap = c->params.bin_capacity ? c->params.bin_capacity : 1024u;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
   c->memory_budget = std::max(free_b / 3, (size_t)1 << 30);
   if (c->params.memory_limit_mb) c->memory_budget = (size_t)c->params.memory_limit_mb << 20;
   c->capacity = cap;
-  c->fcapacity = std::max<uint32_t>(8 * cap, 1024);   // 8-byte fragments of all boxes up to 4x4 pixel centres
+  c->fcapacity = std::max<uint32_t>(4 * cap, 1024);   // 8-byte fragments of all boxes up to 4x4 pixel centres
   while (G > 1 && (size_t)c->n_lanes * lane_bins_bytes(c, G, c->capacity, c->fcapacity) > c->memory_budget) G = (G + 1) / 2;
   c->group = G;
   c->clip_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 8192 / kCounterShards, 1024), (size_t)1 << 22);   // per shard
   c->big_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 64, 1024), (size_t)1 << 20);                 // per shard
   for (int l = 0; l < c->n_lanes; l++) {
     rtuf_context::Lane& ln = c->lane[l];
-    HIP_TRY(c, dev_alloc(c, &ln.d_bins, (size_t)G * tiles * 2 * cap * sizeof(PackedTri)));
+    HIP_TRY(c, dev_alloc(c, &ln.d_bins, (size_t)G * tiles * cap * sizeof(PackedTri)));
     HIP_TRY(c, dev_alloc(c, &ln.d_bin_hdr, (size_t)G * tiles * sizeof(BinHeader)));
     HIP_TRY(c, dev_alloc(c, &ln.d_fbins, (size_t)G * tiles * c->fcapacity * sizeof(Frag)));
     HIP_TRY(c, dev_alloc(c, &ln.d_fbin_count, (size_t)G * tiles * sizeof(uint32_t)));
@@ -1565,7 +1563,7 @@ static int retire_oldest(rtuf_context* c)
     if (!c->pending || !b.active) { c->pending = 0; return RTUF_OK; }
     for (int l = 0; l < c->n_lanes; l++)
       if (b.lanes_used >> l & 1u) HIP_TRY(c, hipEventSynchronize(b.done[l]));
-    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0, occluded = 0, raster_atomics = 0, drawn_pixels = 0, work_items = 0, hiz_culled = 0;
+    struct { unsigned long long tris_binned = 0, bin_entries = 0, clip_count = 0, frags = 0, occluded = 0, raster_atomics = 0, drawn_pixels = 0, work_items = 0;
              unsigned max_bin_fill = 0, max_fbin_fill = 0, clip_overflow = 0, uncovered = 0, max_big_fill = 0, cover_tiles = 0, exact_tiles = 0, zero_items = 0,
                       max_items = 0; } k;
     bool list_over = false;                    // some group's set-up grid was sized too small for its work list
@@ -1582,7 +1580,7 @@ static int retire_oldest(rtuf_context* c)
         k.max_fbin_fill = std::max(k.max_fbin_fill, sh.max_fbin_fill); k.frags += sh.frags; k.uncovered |= sh.uncovered;
         k.max_big_fill = std::max(k.max_big_fill, sh.max_big_fill);
         k.occluded += sh.occluded; k.cover_tiles += sh.cover_tiles; k.exact_tiles += sh.exact_tiles; k.zero_items += sh.zero_items;
-        k.raster_atomics += sh.raster_atomics; k.drawn_pixels += sh.drawn_pixels; k.hiz_culled += sh.hiz_culled;
+        k.raster_atomics += sh.raster_atomics; k.drawn_pixels += sh.drawn_pixels;
       }
     }
     group_streams = (b.n + b.n_groups - 1) / std::max(b.n_groups, 1);
@@ -1601,7 +1599,6 @@ static int retire_oldest(rtuf_context* c)
     c->stats.raster_atomics = k.raster_atomics; c->stats.drawn_pixels = k.drawn_pixels;
     c->stats.cover_pass = b.cover_pass ? 1u : 0u;
     c->stats.groups_last_batch = (uint32_t)b.n_groups;
-    c->stats.hiz_culled_entries = k.hiz_culled;
     const bool bin_over = k.max_bin_fill > c->capacity || k.max_fbin_fill > c->fcapacity;
     const bool clip_over = k.clip_overflow != 0;
     const bool big_over = k.max_big_fill > c->big_capacity;

@@ -16,10 +16,9 @@
 //   rasteriser working set of ONE RASTER LANE (a context has one or two: a lane is a HIP stream plus the arrays below; the
 //   launch groups of a batch alternate between the lanes, so one group's set-up runs under the other's tile kernel),
 //   per stream g of the launch group and screen tile
-//     bin_hdr   BinHeader[G][tiles]   four fill counters ({front-facing, back-facing} x {small boxes, larger boxes}) and the
-//                                     tile's cover (nearest triangle that covers the WHOLE tile): 32 bytes, one scalar load in the tile kernel
-//     bins      PackedTri[G][tiles][2][capacity]  (32 B records; one half-bin per facing, each filled with small boxes from
-//                                     the front and larger ones from the back)
+//     bin_hdr   BinHeader[G][tiles]   records binned from the front (small boxes) and from the back of the bin, and the tile's
+//                                     cover (nearest triangle that covers the WHOLE tile): 16 bytes, one scalar load in the tile kernel
+//     bins      PackedTri[G][tiles][capacity]  (32 B records: small boxes from the front, larger from the back)
 //     fbin_count u32[G][tiles], fbins Frag[G][tiles][fcapacity]    (pixels of small triangles, 8 B; top bit of the count: the
 //                                                                    record bin holds a near record, see KeyFmt)
 //     clip_list ClipItem[shards][clip_capacity]   triangles that cross a frustum plane (set-up kernel -> clip kernel)
@@ -90,11 +89,6 @@ static_assert(sizeof(PackedTri) == 32, "PackedTri must be 32 bytes");
 // the near distance of the camera), where the float z the shader sees is finer than the 24-bit depth: only such records
 // are looked at by the tile kernel's exact-z pass.
 constexpr uint32_t kNearBit = 1u << 31;
-// Set when set-up had to swap two vertices to orient the triangle (its snapped area was negative): the two values of this bit
-// are the two facings of a mesh.  Records are binned by it, and the tile kernel rasterises one facing first, takes the
-// largest depth left in every 8x8 pixel block, and drops records of the other facing that lie behind it in every block
-// their box touches -- for a closed mesh those are its back faces (hierarchical depth test, see tile_body).
-constexpr uint32_t kSwappedBit = 1u << 30;
 constexpr uint32_t kOrderMask = (1u << 29) - 1u;
 
 // A record whose bounding box touches more than kCoopTiles tiles is not appended to its bins by the lane that made it
@@ -118,16 +112,14 @@ static_assert(kMaxOrder == kOrderMask, "records and fragments carry the same 29-
 struct alignas(8) Frag { unsigned long long v; };
 static_assert(sizeof(Frag) == 8, "Frag must be 8 bytes");
 
-// Per-bin header: the four fill counters of the tile's two half-bins and the tile's cover -- the nearest triangle that covers
-// the whole tile (bigrec_kernel<0>): largest 24-bit depth it has there << 32 | its index in big_list; kNoCover = none.
+// Per-bin header: the two fill counters of the record bin and the tile's cover -- the nearest triangle that covers the whole
+// tile (bigrec_kernel<0>): largest 24-bit depth it has there << 32 | its index in big_list; kNoCover = none.
 constexpr unsigned long long kNoCover = ~0ull;
-struct alignas(32) BinHeader {
-  uint32_t count[4];             // [2 * facing + size class]: half-bin `facing` (0: not swapped, 1: swapped), records binned from its
-                                 // front (boxes of at most kFrontArea pixel centres) / from its back
+struct alignas(16) BinHeader {
+  uint32_t count[2];             // records binned from the front (boxes of at most kFrontArea pixel centres) / from the back
   unsigned long long cover;
-  unsigned long long pad;
 };
-static_assert(sizeof(BinHeader) == 32, "one scalar load (s_load_dwordx8), two 16-byte stores");
+static_assert(sizeof(BinHeader) == 16, "one scalar load, one store");
 
 struct Chunk {                  // <= 256 consecutive triangles of one draw + their vertex list
   uint32_t tri_begin;           // into ctris
@@ -193,8 +185,7 @@ struct alignas(128) CounterShard {
   unsigned long long occluded;  // (record, tile) pairs not appended because they lie behind a whole-cover triangle (statistics)
   unsigned long long raster_atomics;   // RTUF_COUNT builds only: depth tests issued by the tile kernel (LDS atomics)
   unsigned long long drawn_pixels;     // RTUF_COUNT builds only: pixels whose final key is not the background's
-  unsigned long long hiz_culled;       // bin records of the second facing the tile kernel dropped behind the blocks' depth bounds (statistics)
-  unsigned int pad[8];
+  unsigned int pad[10];
 };
 static_assert(sizeof(CounterShard) == 128, "CounterShard must be one 128-byte line");
 struct alignas(128) WorkCount { unsigned int n_items; unsigned int pad[31]; };
@@ -258,7 +249,7 @@ struct SetupArgs {
   const float* mvp;              // [n_streams][n_draws + 1][16]
   const uint64_t* model_mask;    // [n_streams] bit m set: stream renders model m
   const BgInfo* bg;              // [n_streams]
-  PackedTri* bins;               // [G][tiles][2][capacity]   triangles that are not resolved to fragments (a half-bin per facing)
+  PackedTri* bins;               // [G][tiles][capacity]   triangles that are not resolved to fragments
   BinHeader* bin_hdr;            // [G][tiles]
   Frag* fbins;                   // [G][tiles][fcapacity]  covered pixels of the small (<= 4x4, single-tile) boxes
   uint32_t* fbin_count;          // [G][tiles]
@@ -274,7 +265,7 @@ struct SetupArgs {
   int group_size;
   int n_draws;
   int width, height, tiles_x, tiles_y;
-  uint32_t capacity;             // records per half-bin
+  uint32_t capacity;
   uint32_t clip_capacity;        // per shard segment
   uint32_t bg_chunk;             // index of the background-quad chunk
   uint32_t flags;                // rtuf_params.flags

@@ -443,9 +443,8 @@ __device__ __forceinline__ int sext21(int v) { return (v << 11) >> 11; }
 // and bx/by hold the inclusive pixel bounding box.
 __device__ __forceinline__ bool orient_and_bound(Win& v0, Win& v1, const Win& v2, int width, int height,
                                                  int& x0, int& y0, int& x1, int& y1, int& x2, int& y2,
-                                                 int& bx0, int& bx1, int& by0, int& by1, uint32_t& swapped)
+                                                 int& bx0, int& bx1, int& by0, int& by1)
 {
-  swapped = 0u;
   // vertices of unclipped triangles lie inside the frustum: snapped values are in [-128, 2048*256+128]
   // (clipper-made vertices, a few units more, never come here).
   // The (value-preserving) 21-bit sign extension tells the compiler so, which turns the 64-bit
@@ -465,7 +464,6 @@ __device__ __forceinline__ bool orient_and_bound(Win& v0, Win& v1, const Win& v2
     int t = x0; x0 = x1; x1 = t;
     t = y0; y0 = y1; y1 = t;
     Win tw = v0; v0 = v1; v1 = tw;
-    swapped = kSwappedBit;
   }
   return true;
 }
@@ -536,12 +534,10 @@ __device__ __forceinline__ bool make_record(Win v0, Win v1, Win v2, uint32_t ord
   if (bx1 < bx0 || by1 < by0) return false;
   const long long area = (long long)(x0 - x1) * (y2 - y0) - (long long)(x2 - x0) * (y0 - y1);
   if (area == 0) return false;
-  uint32_t swapped = 0u;
   if (area < 0) {   // orient: swap vertices 0 and 1 (fixed and float)
     int t = x0; x0 = x1; x1 = t;
     t = y0; y0 = y1; y1 = t;
     Win tw = v0; v0 = v1; v1 = tw;
-    swapped = kSwappedBit;
   }
   edges_from_snapped(x0, y0, x1, y1, x2, y2, width, height, r);
   // z plane from the unsnapped float vertices
@@ -562,7 +558,7 @@ __device__ __forceinline__ bool make_record(Win v0, Win v1, Win v2, uint32_t ord
   pk.v01 = (unsigned long long)(uint32_t)(x0 + kCoordBias) | ((unsigned long long)(uint32_t)(y0 + kCoordBias) << 20) | ((unsigned long long)(uint32_t)(x1 + kCoordBias) << 40);
   pk.v12 = (unsigned long long)(uint32_t)(y1 + kCoordBias) | ((unsigned long long)(uint32_t)(x2 + kCoordBias) << 20) | ((unsigned long long)(uint32_t)(y2 + kCoordBias) << 40);
   pk.a0 = r.a0; pk.dzdx = r.dzdx; pk.dzdy = r.dzdy;
-  pk.order = order | swapped | near_bit(r.a0, r.dzdx, r.dzdy, (int)(r.bbx & 0xffff), (int)(r.bbx >> 16), (int)(r.bby & 0xffff), (int)(r.bby >> 16));
+  pk.order = order | near_bit(r.a0, r.dzdx, r.dzdy, (int)(r.bbx & 0xffff), (int)(r.bbx >> 16), (int)(r.bby & 0xffff), (int)(r.bby >> 16));
   return true;
 }
 
@@ -626,10 +622,10 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int sha
   }
   const int tiles = a.tiles_x * a.tiles_y;
   uint32_t n = 0;
-  // A half-bin per facing (kSwappedBit), and two size classes per half-bin: records with a box of at most kFrontArea pixel
-  // centres fill it from the front, larger ones from the back, so the tile kernel's waves get boxes of similar size (its
-  // lane-per-triangle walk runs as long as the largest box in the wave).  cls = 2 * facing + size class = the counter.
-  const int cls = (((int)(bbx >> 16) - (int)(bbx & 0xffff) + 1) * ((int)(bby >> 16) - (int)(bby & 0xffff) + 1) > kFrontArea ? 1 : 0) | (int)((pk.order >> 29) & 2u);
+  // Two size classes per bin: records with a box of at most kFrontArea pixel centres fill the bin from
+  // the front, larger ones from the back, so the tile kernel's waves get boxes of similar size (its
+  // lane-per-triangle walk runs as long as the largest box in the wave).
+  const int cls = ((int)(bbx >> 16) - (int)(bbx & 0xffff) + 1) * ((int)(bby >> 16) - (int)(bby & 0xffff) + 1) > kFrontArea ? 1 : 0;
   const bool big = have && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kCoopTiles;
   if (__ballot(big)) list_big_records_wave(a, shard_id, slot, big, pk);          // (their bin entries are counted by bigrec_kernel)
   have = have && !big;
@@ -638,7 +634,7 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int sha
     const bool act = have && ty <= ty1;
     unsigned long long pending = __ballot(act);
     if (!pending) break;
-    const int bin = act ? 4 * (__mul24(slot, tiles) + __mul24(ty, a.tiles_x) + tx) + cls : -1;      // (bin, class) = one counter
+    const int bin = act ? 2 * (__mul24(slot, tiles) + __mul24(ty, a.tiles_x) + tx) + cls : -1;      // (bin, class) = one counter
     if (++tx > tx1) { tx = tx0; ty++; }
     unsigned long long mymask = 0;
     int myleader = lane;
@@ -650,14 +646,14 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int sha
       pending &= ~m;
     }
     uint32_t base = 0;
-    if (act && lane == myleader) base = atomicAdd(&a.bin_hdr[bin >> 2].count[cls], (uint32_t)__popcll(mymask));
+    if (act && lane == myleader) base = atomicAdd(&a.bin_hdr[bin >> 1].count[cls], (uint32_t)__popcll(mymask));
     // a near record (it may produce window z <= 0.5) marks its bin: top bit of the fragment counter, read by the tile kernel
     const unsigned long long nearm = __ballot(act && (pk.order & kNearBit) != 0u);
-    if (nearm && act && lane == myleader && (mymask & nearm)) atomicOr(&a.fbin_count[bin >> 2], 0x80000000u);
+    if (nearm && act && lane == myleader && (mymask & nearm)) atomicOr(&a.fbin_count[bin >> 1], 0x80000000u);
     base = __shfl(base, myleader);
     if (act) {
       const uint32_t pos = base + (uint32_t)__popcll(mymask & ((1ull << lane) - 1ull));
-      if (pos < a.capacity) store_record(a.bins + (size_t)(bin >> 1) * a.capacity + ((cls & 1) ? a.capacity - 1u - pos : pos), pk);      // (bin >> 1 = 2 * bin index + facing)
+      if (pos < a.capacity) store_record(a.bins + (size_t)(bin >> 1) * a.capacity + (cls ? a.capacity - 1u - pos : pos), pk);
       n++;
     }
   }
@@ -1139,12 +1135,11 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
       v2.x = s_win[k][0][j2]; v2.y = s_win[k][1][j2]; v2.z = s_win[k][2][j2];
       const int2 q0 = s_snap[k][j0], q1 = s_snap[k][j1], q2 = s_snap[k][j2];        // snapped in phase 1 (y << 8 | clip mask)
       int x0 = q0.x, y0 = q0.y >> 8, x1 = q1.x, y1 = q1.y >> 8, x2 = q2.x, y2 = q2.y >> 8, bx0, bx1, by0, by1;
-      uint32_t swapped;
-      have = orient_and_bound(v0, v1, v2, a.width, a.height, x0, y0, x1, y1, x2, y2, bx0, bx1, by0, by1, swapped);
+      have = orient_and_bound(v0, v1, v2, a.width, a.height, x0, y0, x1, y1, x2, y2, bx0, bx1, by0, by1);
       if (have) {
         float a0, dzdx, dzdy;
         z_plane(v0, v1, v2, a0, dzdx, dzdy);
-        pk = pack_record(x0, y0, x1, y1, x2, y2, a0, dzdx, dzdy, a.corder[ch.tri_begin + t] | swapped | near_bit(a0, dzdx, dzdy, bx0, bx1, by0, by1));
+        pk = pack_record(x0, y0, x1, y1, x2, y2, a0, dzdx, dzdy, a.corder[ch.tri_begin + t] | near_bit(a0, dzdx, dzdy, bx0, bx1, by0, by1));
         bbx = (uint32_t)bx0 | ((uint32_t)bx1 << 16);
         bby = (uint32_t)by0 | ((uint32_t)by1 << 16);
       }
@@ -1387,7 +1382,6 @@ __global__ __launch_bounds__(256) void bigrec_kernel(SetupArgs a)
       dst[0] = src[0]; dst[1] = src[1];
     }
     const int qslot = (int)rec->slot;
-    const int facing = (int)((q.order >> 30) & 1u);
     const TriRec r = unpack_record(q, a.width, a.height);
     const int bx0 = (int)(r.bbx & 0xffff), bx1 = (int)(r.bbx >> 16), by0 = (int)(r.bby & 0xffff), by1 = (int)(r.bby >> 16);
     const int tx0 = bx0 / kTileW, tx1 = bx1 / kTileW;
@@ -1444,7 +1438,7 @@ __global__ __launch_bounds__(256) void bigrec_kernel(SetupArgs a)
             }
             if (touches) {
               bin[jj] = b;
-              pos[jj] = atomicAdd(&a.bin_hdr[b].count[2 * facing + 1], 1u);          // many-tile records are large: back of their half-bin
+              pos[jj] = atomicAdd(&a.bin_hdr[b].count[1], 1u);          // many-tile records are large: back of the bin
               if (q.order & kNearBit) atomicOr(&a.fbin_count[b], 0x80000000u);
               mine++;
             }
@@ -1453,7 +1447,7 @@ __global__ __launch_bounds__(256) void bigrec_kernel(SetupArgs a)
       }
 #pragma unroll
       for (int jj = 0; jj < kPerRound; jj++)
-        if (bin[jj] >= 0 && pos[jj] < a.capacity) store_record(a.bins + ((size_t)bin[jj] * 2 + facing) * a.capacity + (a.capacity - 1u - pos[jj]), q);
+        if (bin[jj] >= 0 && pos[jj] < a.capacity) store_record(a.bins + (size_t)bin[jj] * a.capacity + (a.capacity - 1u - pos[jj]), q);
     }
   }
   if (PHASE == 0) return;
@@ -1600,88 +1594,17 @@ __device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriR
 // that lie behind it over their whole part of the tile are dropped when they are loaded.  MODE 1 looks only at records the
 // set-up marked as near (kNearBit) and, of those, only at the ones that can reach the lower half of the depth range here.
 
-// Depth bounds of the key tile, taken once between the two facings (tile_body): the largest 24-bit depth any key of an 8x8
-// pixel block / a 16x16 block / the whole tile has at that moment.  Keys only get nearer afterwards, so a record whose
-// smallest depth over its part of the tile is larger than the bound of every block it touches cannot win a pixel.
-constexpr int kHizW0 = kTileW / 8, kHizH0 = kTileH / 8, kHizW1 = kTileW / 16, kHizH1 = kTileH / 16;
-struct HizLevels { uint32_t l0[kHizW0 * kHizH0]; uint32_t l1[kHizW1 * kHizH1]; uint32_t l2; uint32_t culled; uint32_t n_survivors; };
-constexpr int kHizChunk = 1024;      // records of the second facing tested per round trip through the survivor list (4 KiB of LDS, shared with s_prec)
-static_assert(kTileW % 16 == 0 && kTileH % 16 == 0, "the depth-bound levels tile the key tile exactly");
-
-// Bound for the box [lx0, lx1] x [ly0, ly1] (tile-local pixels): the finest level at which the box spans at most two
-// blocks per axis, so that the four corner blocks are all the blocks it touches.
-__device__ __forceinline__ uint32_t hiz_bound(const HizLevels* hz, int lx0, int lx1, int ly0, int ly1)
-{
-  if ((lx1 >> 3) - (lx0 >> 3) <= 1 && (ly1 >> 3) - (ly0 >> 3) <= 1) {
-    const int x0 = lx0 >> 3, x1 = lx1 >> 3, y0 = (ly0 >> 3) * kHizW0, y1 = (ly1 >> 3) * kHizW0;
-    return max(max(hz->l0[y0 + x0], hz->l0[y0 + x1]), max(hz->l0[y1 + x0], hz->l0[y1 + x1]));
-  }
-  if ((lx1 >> 4) - (lx0 >> 4) <= 1 && (ly1 >> 4) - (ly0 >> 4) <= 1) {
-    const int x0 = lx0 >> 4, x1 = lx1 >> 4, y0 = (ly0 >> 4) * kHizW1, y1 = (ly1 >> 4) * kHizW1;
-    return max(max(hz->l1[y0 + x0], hz->l1[y0 + x1]), max(hz->l1[y1 + x0], hz->l1[y1 + x1]));
-  }
-  return hz->l2;
-}
-#ifndef RTUF_FIRST_FACING
-#define RTUF_FIRST_FACING 0      // the facing (kSwappedBit) the tile kernel rasterises first
-#endif
-
-// Second facing, stage A: records [first, first + count) of the half-bin (iteration order: small boxes from the front, larger
-// from the back) against the depth bounds.  A record whose smallest depth over its part of the tile is larger than the bound
-// of every block its box touches (or than the tile's cover) cannot win a pixel; the others' places go on the survivor list,
-// which stage B -- raster_bin over the list -- walks with full waves.  (Testing in place and walking what is left keeps every
-// wave as busy as its largest survivor: measured, no gain from dropping 44 % of all records.)
-__device__ __forceinline__ void cull_bin(const PackedTri* recs, uint32_t first, uint32_t count, uint32_t n_front, uint32_t capacity, int x_base, int y_base,
-                                         int tid, int width, int height, uint32_t zcover, HizLevels* hz, uint32_t* list)
-{
-  const int lane = tid & 63;
-  for (uint32_t base = 0; base < count; base += kTileThreads) {
-    const uint32_t i = first + base + tid;
-    const bool have = base + tid < count;
-    const uint32_t ri = i < n_front ? i : capacity - 1u - (i - n_front);
-    bool keep = false;
-    if (have) {
-      const uint4* src = reinterpret_cast<const uint4*>(recs + ri);
-      const uint4 w0 = src[0], w1 = src[1];
-      const unsigned long long v01 = ((unsigned long long)w0.y << 32) | w0.x, v12 = ((unsigned long long)w0.w << 32) | w0.z;
-      const int x0 = (int)(v01 & 0xfffffu) - kCoordBias, y0 = (int)((v01 >> 20) & 0xfffffu) - kCoordBias, x1 = (int)((v01 >> 40) & 0xfffffu) - kCoordBias;
-      const int y1 = (int)(v12 & 0xfffffu) - kCoordBias, x2 = (int)((v12 >> 20) & 0xfffffu) - kCoordBias, y2 = (int)((v12 >> 40) & 0xfffffu) - kCoordBias;
-      // the box exactly as edges_from_snapped / raster_bin derive it
-      const int minx = min(x0, min(x1, x2)), maxx = max(x0, max(x1, x2)), miny = min(y0, min(y1, y2)), maxy = max(y0, max(y1, y2));
-      const int bx0 = max((minx + 255) >> 8, 0), bx1 = min((maxx - 1) >> 8, width - 1);
-      const int by0 = max((miny + 255) >> 8, 0), by1 = min((maxy - 1) >> 8, height - 1);
-      const int lx0 = max(bx0 - x_base, 0), lx1 = min(bx1 - x_base, kTileW - 1), ly0 = max(by0 - y_base, 0), ly1 = min(by1 - y_base, kTileH - 1);
-      if (lx1 >= lx0 && ly1 >= ly0) {
-        const float a0 = __uint_as_float(w1.x), dzdx = __uint_as_float(w1.y), dzdy = __uint_as_float(w1.z);
-        const uint32_t zmin24 = z24_of(plane_min(a0, dzdx, dzdy, x_base + lx0, x_base + lx1, y_base + ly0, y_base + ly1));
-        keep = !(zmin24 > min(zcover, hiz_bound(hz, lx0, lx1, ly0, ly1)));
-      }
-    }
-    const unsigned long long km = __ballot(keep);
-    if (km) {
-      const int leader = __ffsll((long long)km) - 1;
-      uint32_t at = 0;
-      if (lane == leader) at = atomicAdd(&hz->n_survivors, (uint32_t)__popcll(km));
-      at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader);
-      if (keep) list[at + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = ri;
-    }
-  }
-}
-
 template <int MODE, bool LOW>
 __device__ __forceinline__ void raster_bin(unsigned long long* keys, const PackedTri* recs, uint32_t n,
                                            int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, uint32_t n_front, uint32_t capacity,
-                                           uint32_t* s_huge, TriRec* s_prec, uint4* s_pmeta, uint32_t zcover, const uint32_t* s_winners, const KeyFmt& kf,
-                                           const uint32_t* list, int dbg_skip = 0)
+                                           uint32_t* s_huge, TriRec* s_prec, uint4* s_pmeta, uint32_t zcover, const uint32_t* s_winners, const KeyFmt& kf, int dbg_skip = 0)
 {
   const int lane = tid & 63;
   const uint32_t zdrop = MODE == 1 ? min(zcover, kf.zexact - 1u) : zcover;      // MODE 1: only what can reach a depth that needs the pass
   for (uint32_t base = 0; base < n; base += kTileThreads) {
     const uint32_t i = base + tid;
     bool have = i < n;
-    // small boxes from the front, larger ones from the back -- or, for the second facing, the records that survived the
-    // depth-bound test, by their places in the half-bin (list: uniform)
-    const uint32_t ri = list ? (have ? list[i] : 0u) : (i < n_front ? i : capacity - 1u - (i - n_front));
+    const uint32_t ri = i < n_front ? i : capacity - 1u - (i - n_front);      // small boxes from the front, larger ones from the back
     TriRec r;
     int lx0 = 0, lx1 = -1, ly0 = 0, ly1 = -1;
     PackedTri pk;
@@ -1707,7 +1630,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     }
     const int w = lx1 - lx0 + 1, h = ly1 - ly0 + 1;
     int area = (have && w > 0 && h > 0) ? w * h : 0;
-    if (zdrop != 0xffffffffu && list == nullptr) {        // (uniform) behind the tile's cover / out of the exact-z range: cannot matter here
+    if (zdrop != 0xffffffffu) {               // (uniform) behind the tile's cover / out of the exact-z range: cannot matter here
       if (area > 0 && z24_of(plane_min(r.a0, r.dzdx, r.dzdy, x_base + lx0, x_base + lx1, y_base + ly0, y_base + ly1)) > zdrop) area = 0;
     }
     if (dbg_load_only) { if (r.order == 0xdeadbeefu) keys[0] = 0; area = 0; }
@@ -2016,7 +1939,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   __shared__ uint32_t s_winners[kWinnerWords];     // exact-z pass: filter of the draw-order keys that won a pixel in need
   __shared__ TriRec s_prec[64];                    // ... a batch of them unpacked by the first wave for all four,
   __shared__ uint4 s_pmeta[64];                    //     with {class, smallest depth, largest depth if it covers the whole tile}
-  __shared__ HizLevels s_hiz;                      // depth bounds per block of the key tile, taken between the two facings
 
   const int tid = threadIdx.x;
   const int tiles = a.tiles_x * a.tiles_y;
@@ -2026,14 +1948,14 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   const int stream = a.group_base + slot;
   const int x_base = txi * kTileW, y_base = tyi * kTileH;
 
-  // the four fill counters of the tile's two half-bins and the tile's cover (the nearest triangle that covers this whole
-  // tile, if any: bound of every key's depth, and its plane) in ONE 32-byte scalar load, the fragment bin's counter in a second one
-  uint32_t cnt[4];
+  // the record bin's two fill counters and the tile's cover (the nearest triangle that covers this whole tile, if any:
+  // bound of every key's depth, and its plane) in ONE 16-byte scalar load, the fragment bin's counter in a second one
+  uint32_t count_front, count_back;
   unsigned long long cover;
   {
-    const uint4 h0 = reinterpret_cast<const uint4*>(a.bin_hdr + bin)[0], h1 = reinterpret_cast<const uint4*>(a.bin_hdr + bin)[1];
-    cnt[0] = h0.x; cnt[1] = h0.y; cnt[2] = h0.z; cnt[3] = h0.w;
-    cover = COVER ? ((unsigned long long)h1.y << 32) | h1.x : kNoCover;
+    const uint4 h = *reinterpret_cast<const uint4*>(a.bin_hdr + bin);
+    count_front = h.x; count_back = h.y;
+    cover = COVER ? ((unsigned long long)h.w << 32) | h.z : kNoCover;
   }
   // fragment count, and in the top bit: the bin holds a near record (or its cover is one): the depth keys of this tile
   // carry the low bits of the float z (KeyFmt)
@@ -2044,7 +1966,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   kf.shift = a.key_shift;
   kf.lowmask = near_tile ? (1u << a.key_shift) - 1u : 0u;
   kf.zexact = near_tile ? 1u << (26 - a.key_shift) : 8388609u;
-  const uint32_t fill0 = cnt[0] + cnt[1], fill1 = cnt[2] + cnt[3], count = fill0 + fill1;
+  const uint32_t count = count_front + count_back;
   // (the stream's background entry after the bin's header in program order: the compiler then issues the three scalar loads
   // together -- with the background first it waited for it before it even computed the header's address)
   const BgInfo bi = a.bg[stream];
@@ -2084,16 +2006,9 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       }
     }
   };
-  // (an over-full half-bin is detected from the counters and the batch run again; until then stay inside the array)
-  // half h of the bin: records [0, nh_front[h]) from its front (small boxes), the rest from its back
-  uint32_t nh_front[2], nh[2];
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    nh_front[h] = min(cnt[2 * h], a.capacity);
-    nh[h] = nh_front[h] + min(cnt[2 * h + 1], a.capacity - nh_front[h]);
-  }
-  const uint32_t n = nh[0] + nh[1], nf = min(fcount, a.fcapacity);
-  const PackedTri* recs = a.bins + (size_t)bin * 2 * a.capacity;
+  // (an over-full bin is detected from the counters and the batch run again; until then stay inside the array)
+  const uint32_t n_front = min(count_front, a.capacity), n = n_front + min(count_back, a.capacity - n_front), nf = min(fcount, a.fcapacity);
+  const PackedTri* recs = a.bins + (size_t)bin * a.capacity;
   const unsigned long long* frags = reinterpret_cast<const unsigned long long*>(a.fbins) + (size_t)bin * a.fcapacity;
   // (RTUF_ABLATE builds only: flags bits 8.. are timing experiments, e.g. 0x100 skip rasterisation, 0x200 skip pixel loops)
   const bool empty = (n == 0 && nf == 0 && !has_cover) || RTUF_ABL(a.flags, 0x100u);   // no geometry in this tile: pure streaming compare
@@ -2124,96 +2039,34 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
     } else {
       for (int i = tid; i < kTileW * kTileH; i += kTileThreads) keys[i] = bgkey;
     }
-    if (tid == 0) { s_huge[0] = 0; s_huge[1 + kHugeMax] = n <= (uint32_t)kParkBelow ? (uint32_t)kQuarterArea : (uint32_t)kWallArea; s_hiz.culled = 0u; }
+    if (tid == 0) { s_huge[0] = 0; s_huge[1 + kHugeMax] = n <= (uint32_t)kParkBelow ? (uint32_t)kQuarterArea : (uint32_t)kWallArea; }
 #ifdef RTUF_COUNT
     if (tid < 2) count_words()[tid] = 0u;
 #endif
     __syncthreads();
     if (tid == 0) {
-      reinterpret_cast<uint4*>(a.bin_hdr + bin)[0] = make_uint4(0u, 0u, 0u, 0u);      // ready for the next batch: nothing binned, no cover
-      reinterpret_cast<uint4*>(a.bin_hdr + bin)[1] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+      *reinterpret_cast<uint4*>(a.bin_hdr + bin) = make_uint4(0u, 0u, 0xffffffffu, 0xffffffffu);      // ready for the next batch: nothing binned, no cover
       a.fbin_count[bin] = 0;
       CounterShard& sh = a.counters->shard[bin % kCounterShards];
-      if (count) atomicMax(&sh.max_bin_fill, max(fill0, fill1));
+      if (count) atomicMax(&sh.max_bin_fill, count);
       if (fcount) atomicMax(&sh.max_fbin_fill, fcount);
       if (has_cover) atomicAdd(&sh.cover_tiles, 1u);
     }
-    // The two facings one after the other (kSwappedBit: for a closed mesh, its front and its back).  After the first --
-    // and the fragments of the small triangles, most of a robot's surface at arm's length -- every 8x8 block of the key tile
-    // gets the largest depth left in it; a record of the second facing whose smallest depth over its part of the tile lies
-    // behind the bound of every block it touches cannot win a pixel and is dropped before its walk: the back of every link,
-    // and whatever a near link hides.  Exact: keys only get nearer, and equal depths stay (draw order decides those).
-    // (Two instances of the rasterisation: tiles without near geometry -- every tile of a robot at arm's length -- do not
-    // pay the instruction that puts the float's low bits into the key.)
-    int dbg_skip = 0;
-    bool dbg_load_only = false, dbg_no_records = false, dbg_no_frags = false;
+    // (two instances of the rasterisation: tiles without near geometry -- every tile of a robot at arm's length -- do not
+    // pay the instruction that puts the float's low bits into the key)
 #ifdef RTUF_ABLATE
-    dbg_skip = (int)((a.flags >> 12) & 3u); dbg_load_only = (a.flags & 0x200u) != 0; dbg_no_records = (a.flags & 0x800u) != 0; dbg_no_frags = (a.flags & 0x400u) != 0;
+    if (!(a.flags & 0x800u)) {
+      if (near_tile) raster_bin<0, true>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, (int)((a.flags >> 12) & 3u));
+      else raster_bin<0, false>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, (int)((a.flags >> 12) & 3u));
+    }
+    if (!(a.flags & 0x400u)) raster_frags(keys, frags, nf, tid, zcover, kf.shift);
+#else
+    if (near_tile) raster_bin<0, true>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf);
+    else raster_bin<0, false>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf);
+    raster_frags(keys, frags, nf, tid, zcover, kf.shift);
 #endif
-#pragma nounroll
-    for (int pass = 0; pass < 2; pass++) {
-      const int h = pass ^ RTUF_FIRST_FACING;
-      const uint32_t n_h = h ? nh[1] : nh[0], n_h_front = h ? nh_front[1] : nh_front[0];
-      HizLevels* hz = nullptr;
-      if (pass == 1) {
-        if (n_h == 0u || RTUF_ABL(a.flags, 0x2000000u)) { if (n_h == 0u) break; }
-        else {
-          __syncthreads();                       // the first facing and the fragments are in the keys
-          if (tid < kHizW0 * kHizH0) s_hiz.l0[tid] = 0u;
-          if (tid == 0) { s_hiz.l2 = 0u; s_huge[0] = 0; }
-          __syncthreads();
-          for (int i = tid; i < kTileW * kTileH / 8; i += kTileThreads) {      // 8 consecutive keys of one row each
-            const int row = i / (kTileW / 8), seg = i % (kTileW / 8);
-            const unsigned long long* kp = keys + row * kTileW + 8 * seg;
-            uint32_t m = 0u;
-#pragma unroll
-            for (int j = 0; j < 8; j++) m = max(m, (uint32_t)(kp[j] >> 32));
-            atomicMax(&s_hiz.l0[(row >> 3) * kHizW0 + seg], m);
-          }
-          __syncthreads();
-          if (tid < kHizW1 * kHizH1) {
-            const int bx = tid % kHizW1, by = tid / kHizW1;
-            const uint32_t* q = &s_hiz.l0[2 * by * kHizW0 + 2 * bx];
-            const uint32_t m = max(max(q[0], q[1]), max(q[kHizW0], q[kHizW0 + 1]));
-            s_hiz.l1[tid] = m;
-            atomicMax(&s_hiz.l2, m);
-          }
-          __syncthreads();
-          hz = &s_hiz;
-        }
-        if (pass == 1 && hz == nullptr) { __syncthreads(); if (tid == 0) s_huge[0] = 0; __syncthreads(); }      // (ablation build only)
-      }
-      const PackedTri* recs_h = recs + (size_t)h * a.capacity;
-      // First facing: the half-bin as it is.  Second facing: a chunk of records at a time is tested against the depth bounds
-      // (cull_bin) and the survivors' places go on a list, which is then walked with full waves.
-      uint32_t* const list = reinterpret_cast<uint32_t*>(s_prec);          // (s_prec is free between two parked passes; kHizChunk entries fit)
-      static_assert(sizeof(TriRec) * 64 >= sizeof(uint32_t) * kHizChunk, "the survivor list lives in s_prec");
-      const bool culling = hz != nullptr;
-#pragma nounroll
-      for (uint32_t c0 = 0; c0 < n_h && !dbg_no_records;) {
-        const uint32_t nc = culling ? min((uint32_t)kHizChunk, n_h - c0) : n_h;
-        uint32_t ns = nc, nfr = n_h_front;
-        if (culling) {
-          if (c0) __syncthreads();                 // the chunk before is done with the list (and with s_prec)
-          if (tid == 0) { s_hiz.n_survivors = 0u; s_huge[0] = 0; }
-          __syncthreads();
-          cull_bin(recs_h, c0, nc, n_h_front, a.capacity, x_base, y_base, tid, a.width, a.height, zcover, hz, list);
-          __syncthreads();
-          ns = s_hiz.n_survivors;
-          nfr = 0u;
-          if (tid == 0) s_hiz.culled += nc - ns;
-        }
-        if (near_tile) raster_bin<0, true>(keys, recs_h, ns, x_base, y_base, tid, dbg_load_only, a.width, a.height, nfr, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, culling ? list : nullptr, dbg_skip);
-        else raster_bin<0, false>(keys, recs_h, ns, x_base, y_base, tid, dbg_load_only, a.width, a.height, nfr, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, culling ? list : nullptr, dbg_skip);
-        c0 += nc;
-      }
-      if (pass == 0 && !dbg_no_frags) raster_frags(keys, frags, nf, tid, zcover, kf.shift);
-    }
     __syncthreads();
-    if (tid == 0) {
-      s_huge[0] = 0;             // the exact-z pass below builds its list again
-      if (s_hiz.culled) atomicAdd(&a.counters->shard[bin % kCounterShards].hiz_culled, (unsigned long long)s_hiz.culled);
-    }
+    if (tid == 0) s_huge[0] = 0;             // the exact-z pass below builds its list again
 
     // Does any pixel need a second look for the exact float z of its winner?  In the upper half of the depth range
     // (z24 > 2^23) float z == (z24 + 1) * 2^-24 exactly; below, a tile with near geometry has the float's low bits in its
@@ -2237,12 +2090,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
         }
       }
       __syncthreads();
-#pragma nounroll
-      for (int h = 0; h < 2; h++) {
-        if (h == 1) { __syncthreads(); if (tid == 0) s_huge[0] = 0; __syncthreads(); }
-        raster_bin<1, true>(keys, recs + (size_t)h * a.capacity, h ? nh[1] : nh[0], x_base, y_base, tid, false, a.width, a.height, h ? nh_front[1] : nh_front[0], a.capacity,
-                            s_huge, s_prec, s_pmeta, zcover, s_winners, kf, nullptr);
-      }
+      raster_bin<1, true>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf);
       if (has_cover) {                       // ... and the cover triangle, which is in no bin
         const CoverPlane c = cover_plane();
         for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
@@ -2461,10 +2309,7 @@ __global__ void publish_counters_kernel(const Counters* __restrict__ src, Counte
 __global__ void init_headers_kernel(BinHeader* hdr, size_t n_bins)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_bins) {
-    reinterpret_cast<uint4*>(hdr + i)[0] = make_uint4(0u, 0u, 0u, 0u);
-    reinterpret_cast<uint4*>(hdr + i)[1] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
-  }
+  if (i < n_bins) *reinterpret_cast<uint4*>(hdr + i) = make_uint4(0u, 0u, 0xffffffffu, 0xffffffffu);
 }
 
 // host-callable launchers ---------------------------------------------------------------

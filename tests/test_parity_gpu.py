@@ -1491,7 +1491,7 @@ def test_memory_limit_shrinks_the_launch_group_instead_of_failing():
     n = 48
     ctx, P, geo, depth, per = run_soups(128, 96, n, seed=78, bin_capacity=1, memory_limit_mb=1)
     before = ctx.stats()
-    assert before["launch_group"] == 6, before          # 2 lanes x 6 streams x 6 tiles x 2 x 32 B + 4096 x 8 B fragments: under 1 MiB (12 streams: over)
+    assert before["launch_group"] == 6, before          # 2 lanes x 6 streams x 6 tiles x (32 + 1024 x 8) B = 0.56 MiB (12 streams: 1.13)
     masked, mask = ctx.filter_batch(depth)
     check_vs_oracle(masked, mask, P, geo, depth, per)
     st = ctx.stats()
