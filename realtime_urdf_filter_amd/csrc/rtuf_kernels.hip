@@ -745,21 +745,25 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
     const unsigned long long c0 = __ballot(act && (cnt & 1u)), c1 = __ballot(act && (cnt & 2u)), c2 = __ballot(act && (cnt & 4u)),
                              c3 = __ballot(act && (cnt & 8u)), c4 = __ballot(act && (cnt & 16u));
     const unsigned long long below = (1ull << lane) - 1ull;
-    uint32_t base_in_group = 0, group_total = 0;
+    // The loop only finds every lane's group (the lanes that target the same bin) -- a few instructions per distinct bin.
+    // The lane's offset inside its group's reservation and the group's total are then computed ONCE, from the group mask
+    // and the five bit planes of the counts (they used to be recomputed inside the loop for every distinct bin: with the
+    // three to six bins a wave of small triangles touches, that was most of this function).
+    unsigned long long mymask = 0ull;
     int myleader = lane;
     while (pending) {
       const int leader = __ffsll((long long)pending) - 1;
       const int lbin = __builtin_amdgcn_readlane(bin, leader);      // leader is wave-uniform: no LDS crossbar round trip
       const bool mine = act && bin == lbin;
       const unsigned long long m = __ballot(mine);
-      if (mine) {
-        const unsigned long long lo = m & below;
-        base_in_group = (uint32_t)(__popcll(c0 & lo) + 2 * __popcll(c1 & lo) + 4 * __popcll(c2 & lo) + 8 * __popcll(c3 & lo) + 16 * __popcll(c4 & lo));
-        group_total = (uint32_t)(__popcll(c0 & m) + 2 * __popcll(c1 & m) + 4 * __popcll(c2 & m) + 8 * __popcll(c3 & m) + 16 * __popcll(c4 & m));
-        myleader = leader;
-      }
+      if (mine) { mymask = m; myleader = leader; }
       pending &= ~m;
     }
+    const unsigned long long lo = mymask & below;
+    const uint32_t base_in_group = (uint32_t)(__popcll(c0 & lo) + 2 * __popcll(c1 & lo) + 4 * __popcll(c2 & lo) + 8 * __popcll(c3 & lo) + 16 * __popcll(c4 & lo));
+    // the group's total = offset + count of the group's highest lane
+    const int top = 63 - __clzll((long long)(mymask | 1ull));
+    const uint32_t group_total = (uint32_t)__shfl((int)(base_in_group + cnt), top);
     uint32_t base = 0;
     if (act && lane == myleader) base = atomicAdd(&a.fbin_count[bin], group_total) & 0x7fffffffu;      // (top bit: the bin's near flag)
     base = __shfl(base, myleader);
@@ -972,8 +976,11 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
   }
   __syncthreads();
 
+#ifndef RTUF_SPLIT_PHASES
+#define RTUF_SPLIT_PHASES 1      // phase 1 of all streams of the item, ONE barrier, then phase 2 of all (0: a barrier per stream)
+#endif
+#if RTUF_SPLIT_PHASES
   for (int k = 0; k < kStreamsPerBlock; k++) {
-    const int slot = s_slot[k];
     if (!s_on[k]) continue;                              // uniform per workgroup
     // phase 1
     if (have_vert) {
@@ -990,7 +997,30 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
       s_win[k][0][tid] = w.x; s_win[k][1][tid] = w.y; s_win[k][2][tid] = w.z;
       s_snap[k][tid] = make_int2(snap(w.x), (int)(((unsigned)snap(w.y) << 8) | cm));
     }
+  }
+  __syncthreads();
+#endif
+  for (int k = 0; k < kStreamsPerBlock; k++) {
+    const int slot = s_slot[k];
+    if (!s_on[k]) continue;                              // uniform per workgroup
+#if !RTUF_SPLIT_PHASES
+    // phase 1
+    if (have_vert) {
+      float M[16];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float4 col = reinterpret_cast<const float4*>(s_mvp[k])[q];
+        M[4 * q] = col.x; M[4 * q + 1] = col.y; M[4 * q + 2] = col.z; M[4 * q + 3] = col.w;
+      }
+      float c[4];
+      vs_position(M, pv.x, pv.y, pv.z, c);
+      const Win w = viewport_vs(c, sx, sy);
+      const unsigned cm = clipmask_of(c);
+      s_win[k][0][tid] = w.x; s_win[k][1][tid] = w.y; s_win[k][2][tid] = w.z;
+      s_snap[k][tid] = make_int2(snap(w.x), (int)(((unsigned)snap(w.y) << 8) | cm));
+    }
     __syncthreads();
+#endif
     // phase 2
     bool survive = false, needs_clip = false, tiny = false, small = false;
     if (have_tri) {

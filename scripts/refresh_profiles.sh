@@ -4,45 +4,53 @@
 #   bench.py reads: pmc_counters.json, valu_peak.json; llvmpipe_baseline.json comes from the development container)
 # rocprofv3 passes are separate runs: --kernel-trace --stats, then one --pmc pass per counter group (never together
 # with other trace domains).
-tag=${1:-r03}
+tag=${1:-r04}
 export TMPDIR=/tmp
 root=$PWD
 out=$root/gpurun_out/profiles
 rm -rf $out; mkdir -p $out
 B="python $root/bench.py"
-PROF_ARGS="--steps 20 --min-seconds 0 --cpu-seconds 0 --check-frames 0 --overlap-pipelines 0"
+# The counters and the per-kernel trace are taken on the ONE-LANE launch shape (--lanes 1: every kernel alone on the GPU, the
+# whole batch per launch): that is what bench.py's `roofline` describes (its one-lane leg); the default context overlaps the
+# kernels of two launch groups, whose per-launch times describe no single kernel (traced too, as *_two_lanes).
+PROF_ARGS="--steps 20 --min-seconds 0 --cpu-seconds 0 --check-frames 0 --lanes 1 --isolated-seconds 0 --host-copy-seconds 0"
 
 # ---- 1. bench lines ---------------------------------------------------------------------------------------------
-$B --cpu-seconds 0 --overlap-pipelines 0 > /dev/null 2> $out/bench.err      # first run on a fresh box is the slowest: warm-up
-$B > $out/${tag}_bench.json 2>> $out/bench.err
-$B --cpu-seconds 0 --two-kernel > $out/${tag}_bench_two_kernel.json 2>> $out/bench.err
-$B --cpu-seconds 0 --two-kernel --streams 1024 --steps 30 > $out/${tag}_bench_two_kernel_1024.json 2>> $out/bench.err
-$B --cpu-seconds 0 --streams 1024 --steps 30 > $out/${tag}_bench_1024.json 2>> $out/bench.err
-$B --cpu-seconds 0 --u16 > $out/${tag}_bench_u16.json 2>> $out/bench.err
-$B --steps 500 --cpu-seconds 0 --streams 1 --overlap-pipelines 0 > $out/${tag}_bench_batch1.json 2>> $out/bench.err
-$B --steps 500 --cpu-seconds 0 --streams 1 --overlap-pipelines 0 --pipelines 2 > $out/${tag}_bench_batch1_pipelines2.json 2>> $out/bench.err
-$B --steps 500 --cpu-seconds 0 --streams 1 --overlap-pipelines 0 --pipelines 3 > $out/${tag}_bench_batch1_pipelines3.json 2>> $out/bench.err
-$B --cpu-seconds 0 --host-poses > $out/${tag}_bench_host_poses.json 2>> $out/bench.err
-$B --cpu-seconds 0 --pipelines 2 > $out/${tag}_bench_pipelines2.json 2>> $out/bench.err
-$B --cpu-seconds 0 --workload c4 --shard-of 8 --steps 50 > $out/${tag}_bench_c4_share.json 2>> $out/bench.err
-$B --cpu-seconds 0 --workload c5 --shard-of 8 --steps 30 > $out/${tag}_bench_c5_share.json 2>> $out/bench.err
-$B --cpu-seconds 0 --near-arm --steps 40 > $out/${tag}_bench_near_arm.json 2>> $out/bench.err      # every stream: forearm 0.1-0.35 m in front of the lens
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29561 $root/bench.py --gpus 1 --cpu-seconds 0 2>> $out/bench.err | grep '^{' | tail -1 > $out/${tag}_bench_rccl_world1.json      # (RCCL prints its banner on stdout)
+Q="--cpu-seconds 0 --host-copy-seconds 0 --min-seconds 3"       # the side lines: no CPU legs, no host-plane legs, 3 s timed
+$B $Q > /dev/null 2> $out/bench.err      # first run on a fresh box is the slowest: warm-up
+$B > $out/${tag}_bench.json 2>> $out/bench.err                   # THE line: defaults, exactly what the driver runs
+$B $Q --lanes 1 > $out/${tag}_bench_one_lane.json 2>> $out/bench.err
+$B $Q --launch-group 64 > $out/${tag}_bench_groups_of_64.json 2>> $out/bench.err
+$B $Q --launch-group 32 > $out/${tag}_bench_groups_of_32.json 2>> $out/bench.err
+$B $Q --two-kernel > $out/${tag}_bench_two_kernel.json 2>> $out/bench.err
+$B $Q --two-kernel --streams 1024 --steps 30 > $out/${tag}_bench_two_kernel_1024.json 2>> $out/bench.err
+$B $Q --streams 1024 --steps 30 > $out/${tag}_bench_1024.json 2>> $out/bench.err
+$B $Q --u16 > $out/${tag}_bench_u16.json 2>> $out/bench.err
+$B $Q --steps 500 --streams 1 > $out/${tag}_bench_batch1.json 2>> $out/bench.err
+$B $Q --steps 500 --streams 1 --lanes 1 > $out/${tag}_bench_batch1_one_lane.json 2>> $out/bench.err
+$B $Q --steps 500 --streams 1 --pipelines 3 > $out/${tag}_bench_batch1_pipelines3.json 2>> $out/bench.err
+$B $Q --host-poses > $out/${tag}_bench_host_poses.json 2>> $out/bench.err
+$B $Q --workload c4 --shard-of 8 --steps 50 > $out/${tag}_bench_c4_share.json 2>> $out/bench.err
+$B $Q --workload c5 --shard-of 8 --steps 30 > $out/${tag}_bench_c5_share.json 2>> $out/bench.err
+$B $Q --near-arm --steps 40 > $out/${tag}_bench_near_arm.json 2>> $out/bench.err      # every stream: forearm 0.1-0.35 m in front of the lens
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29561 $root/bench.py --gpus 1 $Q 2>> $out/bench.err | grep '^{' | tail -1 > $out/${tag}_bench_rccl_world1.json      # (RCCL prints its banner on stdout)
 python $root/scripts/clip_stress.py > $out/${tag}_clip_stress.txt 2>> $out/bench.err
 bash $root/scripts/overdraw.sh > $out/overdraw.json 2>> $out/bench.err
 python $root/scripts/host_planes_rate.py > $out/${tag}_host_planes.json 2>> $out/bench.err
+python $root/scripts/clip_stress.py > /dev/null 2>&1
 
 # ---- 2. kernel traces -------------------------------------------------------------------------------------------
 cd /tmp
 trace() {   # name, bench args: the bench's own default step counts (only the CPU legs and the second context are left out)
-  rm -rf /tmp/rp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp -o t -- $B --cpu-seconds 0 --check-frames 0 --overlap-pipelines 0 $2 > /dev/null 2>&1
+  rm -rf /tmp/rp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp -o t -- $B --cpu-seconds 0 --check-frames 0 --host-copy-seconds 0 --isolated-seconds 0 --min-seconds 1 $2 > /dev/null 2>&1
   cp $(find /tmp/rp -name '*kernel_stats.csv' | head -1) $out/${tag}_kernel_stats$1.csv
 }
-trace "" ""
-trace "_two_kernel" "--two-kernel"
-trace "_two_kernel_1024" "--two-kernel --streams 1024 --steps 30"
-trace "_c4_share" "--workload c4 --shard-of 8 --steps 50"
-trace "_near_arm" "--near-arm --steps 40"
+trace "" "--lanes 1"                       # the roofline's launch shape: one lane, 256 streams per launch
+trace "_two_lanes" ""                      # the headline context: two lanes, 128 streams per launch, kernels of the two groups overlap
+trace "_two_kernel" "--two-kernel --lanes 1"
+trace "_two_kernel_1024" "--two-kernel --streams 1024 --steps 30 --lanes 1"
+trace "_c4_share" "--workload c4 --shard-of 8 --steps 50 --lanes 1"
+trace "_near_arm" "--near-arm --steps 40 --lanes 1"
 
 # ---- 3. counters (one pass per group) ---------------------------------------------------------------------------
 pmc() {     # output file, bench args, counters...
