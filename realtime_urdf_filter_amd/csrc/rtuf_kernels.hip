@@ -976,34 +976,10 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
   }
   __syncthreads();
 
-#ifndef RTUF_SPLIT_PHASES
-#define RTUF_SPLIT_PHASES 1      // phase 1 of all streams of the item, ONE barrier, then phase 2 of all (0: a barrier per stream)
-#endif
-#if RTUF_SPLIT_PHASES
-  for (int k = 0; k < kStreamsPerBlock; k++) {
-    if (!s_on[k]) continue;                              // uniform per workgroup
-    // phase 1
-    if (have_vert) {
-      float M[16];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const float4 col = reinterpret_cast<const float4*>(s_mvp[k])[q];
-        M[4 * q] = col.x; M[4 * q + 1] = col.y; M[4 * q + 2] = col.z; M[4 * q + 3] = col.w;
-      }
-      float c[4];
-      vs_position(M, pv.x, pv.y, pv.z, c);
-      const Win w = viewport_vs(c, sx, sy);
-      const unsigned cm = clipmask_of(c);
-      s_win[k][0][tid] = w.x; s_win[k][1][tid] = w.y; s_win[k][2][tid] = w.z;
-      s_snap[k][tid] = make_int2(snap(w.x), (int)(((unsigned)snap(w.y) << 8) | cm));
-    }
-  }
-  __syncthreads();
-#endif
   for (int k = 0; k < kStreamsPerBlock; k++) {
     const int slot = s_slot[k];
     if (!s_on[k]) continue;                              // uniform per workgroup
-#if !RTUF_SPLIT_PHASES
+    // (phase 1 of all three streams before ONE barrier, then phase 2 of all three: measured, no difference)
     // phase 1
     if (have_vert) {
       float M[16];
@@ -1020,7 +996,6 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
       s_snap[k][tid] = make_int2(snap(w.x), (int)(((unsigned)snap(w.y) << 8) | cm));
     }
     __syncthreads();
-#endif
     // phase 2
     bool survive = false, needs_clip = false, tiny = false, small = false;
     if (have_tri) {
