@@ -19,8 +19,9 @@ streams with no data-path collective; RCCL carries the barriers around the timed
 elapsed time and the tiny end-of-run gather of per-rank frame and parity counts.
 
 Timed region: exactly `--steps` steps, repeated back to back until at least `--min-seconds` have passed (repetitions
-are whole multiples of `--steps`; `timed_steps` in the output says how many steps were timed in total).  The default, 6 s,
-is long enough for an outside sampler (amd-smi every 5 s) to land inside it.
+are whole multiples of `--steps`; `timed_steps` in the output says how many steps were timed in total).  The default, 7 s
+(the repetition count comes from a short probe, so the region ends up a few per cent either side of it), is long enough
+for an outside sampler (amd-smi every 5 s) to land inside it.
 
 `value` comes from ONE default-configured context: two raster lanes, a batch split into four launch groups whose kernels
 overlap (rtuf_params.raster_lanes).  Overlapping kernels share the GPU, so their per-launch times describe no single
@@ -73,7 +74,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--min-seconds", type=float, default=6.0, help="the timed region repeats the --steps steps until it is at least this long")
+    ap.add_argument("--min-seconds", type=float, default=7.0, help="the timed region repeats the --steps steps until it is at least this long")
     ap.add_argument("--workload", choices=["c3", "c4", "c5"], default="c3", help="BASELINE.json config: c3 (headline, weak scaling), c4, c5 (fixed totals, sharded)")
     ap.add_argument("--streams", type=int, default=None, help="c3: concurrent camera streams per GPU (256); c4: streams in total (512); c5: cameras per URDF (128)")
     ap.add_argument("--urdfs", type=int, default=64, help="c5: distinct URDFs in total")
@@ -572,8 +573,11 @@ def main():
                     go(k)
                     ctx.sync()
                 share.stage(ctx, kq + 2)
-                tq = time.perf_counter()
                 go(kq + 2)
+                ctx.sync()
+                share.stage(ctx, kq + 3)
+                tq = time.perf_counter()                          # (the steps before this one paid for the staging buffers)
+                go(kq + 3)
                 ctx.sync()
                 est = time.perf_counter() - tq
                 steps_h = max(4, int(np.ceil(args.host_copy_seconds / max(est, 1e-9))))
