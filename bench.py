@@ -518,7 +518,7 @@ def main():
                        "streams_per_gpu": n if share.scaling == "weak" else [x["streams"] for x in per_rank], "streams_total": sum(x["streams"] for x in per_rank),
                        "poses": "host matrices" if args.host_poses else "joint positions, forward kinematics on the GPU", "mode": "two-kernel" if two else "fused", "mask_output": (not args.no_mask),
                        "parallelism": ("stream-sharded x%d" % world) + (" (shares of a %d-GPU job)" % job_world if args.shard_of else ""), "pipelines_per_gpu": P,
-                       "raster_lanes": lanes, "launch_groups_per_batch": groups_per_batch, "streams_per_launch_group": st["launch_group"],
+                       "raster_lanes": lanes, "lanes_side_by_side": bool(st["lanes_side_by_side"]), "launch_groups_per_batch": groups_per_batch, "streams_per_launch_group": st["launch_group"],
                        "host_threads_pinned_to_gpu_numa_node": pinned_cpus},
             "per_stream_fps": value / max(sum(x["streams"] for x in per_rank), 1),
             "collectives": ({"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "world": world,

@@ -56,7 +56,8 @@ class Stats(ctypes.Structure):
                 ("cover_pass", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
                 ("raster_atomics", ctypes.c_uint64), ("drawn_pixels", ctypes.c_uint64),
                 ("raster_lanes", ctypes.c_uint32), ("launch_group", ctypes.c_uint32), ("groups_last_batch", ctypes.c_uint32),
-                ("graphs_enabled", ctypes.c_uint32), ("graph_hits", ctypes.c_uint64), ("graph_misses", ctypes.c_uint64)]
+                ("graphs_enabled", ctypes.c_uint32), ("graph_hits", ctypes.c_uint64), ("graph_misses", ctypes.c_uint64),
+                ("lanes_side_by_side", ctypes.c_uint32), ("reserved1", ctypes.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -129,6 +130,7 @@ struct rtuf_context {
   // 466 k instead of 478 k at two: both kernels are bound by VALU issue, and side by side the set-up kernel loses the
   // occupancy its latency hiding needs.  What the lanes buy is each kernel's ramp, tail and launch gap filled by the other
   // lane)
+  bool lanes_share_queue = false;      // no stream was found that runs beside lane 0's: the lanes work, one after the other
   int next_lane = 0;                   // lane of the next batch that is not split
   int last_lane = 0;                   // lane of the newest batch's last group (debug read-back of the z-surface)
   int group = 0;                       // streams per launch group at most (= streams a lane's bins are sized for)
@@ -422,6 +424,48 @@ static void settle_order(rtuf_context* c, int j, bool accepted)
     return rc_;                                                                            \
   }
 
+// Do kernels of streams a and b run side by side?  The HIP runtime maps streams onto a handful of hardware queues
+// (GPU_MAX_HW_QUEUES, 4 by default) in the order they are created, across everything in the process; two streams on one queue
+// execute strictly one after the other.  Whether a new stream shares the queue of another cannot be asked, only measured: an
+// idle kernel of 300 us on each, timed against one alone.  (Found the hard way: with an RCCL communicator in the process the
+// two raster lanes of a context landed on one queue -- 381 k instead of 484 k frames/s, per-launch times those of kernels
+// running alone.)
+static bool streams_run_side_by_side(hipStream_t a, hipStream_t b)
+{
+  using clk = std::chrono::steady_clock;
+  const unsigned long long ticks = 30000;      // 300 us at 100 MHz
+  launch_spin(100, a); launch_spin(100, b);    // (code object load, queue creation)
+  if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return true; }
+  auto timed = [&](bool both) {
+    const auto t0 = clk::now();
+    launch_spin(ticks, a);
+    if (both) launch_spin(ticks, b);
+    (void)hipStreamSynchronize(a);
+    if (both) (void)hipStreamSynchronize(b);
+    return std::chrono::duration<double>(clk::now() - t0).count();
+  };
+  const double one = std::min(timed(false), timed(false)), two = std::min(timed(true), timed(true));
+  return two < 1.5 * one;
+}
+
+// A new non-blocking stream that runs beside `ref` (nullptr: any stream).  Streams that turn out to share ref's hardware
+// queue are set aside -- still alive, so that the runtime places the next one elsewhere -- and released afterwards; after
+// eight of them the last one is taken as it is (*beside = false: the two will work, one after the other).
+static hipError_t create_stream_beside(hipStream_t ref, hipStream_t* out, bool* beside)
+{
+  *beside = true;
+  hipError_t e = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+  if (e != hipSuccess || !ref) return e;
+  std::vector<hipStream_t> rejected;
+  while (e == hipSuccess && !streams_run_side_by_side(ref, *out)) {
+    if (rejected.size() >= 8) { *beside = false; break; }
+    rejected.push_back(*out);
+    e = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+  }
+  for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+  return e;
+}
+
 extern "C" {
 
 int rtuf_abi_version(void) { return RTUF_ABI_VERSION; }
@@ -488,7 +532,12 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
   // and two pipelines whose main streams share a queue do not overlap at all)
   const bool front = c->params.pipelines > 1;
   c->n_lanes = c->params.raster_lanes ? (int)c->params.raster_lanes : kMaxLanes;
-  for (int l = 0; l < c->n_lanes && e == hipSuccess && !front; l++) e = hipStreamCreateWithFlags(&c->lane[l].stream, hipStreamNonBlocking);
+  for (int l = 0; l < c->n_lanes && e == hipSuccess && !front; l++) {
+    // every further lane must be able to run beside the first
+    bool beside = true;
+    e = create_stream_beside(l > 0 ? c->lane[0].stream : nullptr, &c->lane[l].stream, &beside);
+    if (!beside) c->lanes_share_queue = true;
+  }
   if (e == hipSuccess && !front) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
   if (e != hipSuccess) {
     snprintf(g_create_error, sizeof g_create_error, "hip init failed: %s", hipGetErrorString(e));
@@ -506,6 +555,17 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
       const int rc = rtuf_create(&k, device_id, width, height, max_streams, &kp);
       if (rc != RTUF_OK) { rtuf_destroy(c); return rc; }
       k->graphs_ok = true;
+      if (!c->kids.empty()) {
+        // the pipelines exist to overlap: a child whose raster stream shares the first child's hardware queue gets another
+        hipStream_t fresh = nullptr;
+        bool beside = true;
+        if (!streams_run_side_by_side(c->kids[0]->lane[0].stream, k->lane[0].stream) &&
+            create_stream_beside(c->kids[0]->lane[0].stream, &fresh, &beside) == hipSuccess && fresh) {
+          (void)hipStreamDestroy(k->lane[0].stream);
+          k->lane[0].stream = fresh;
+          if (!beside) c->lanes_share_queue = true;
+        }
+      }
       c->kids.push_back(k);
     }
   }
@@ -2018,7 +2078,7 @@ int rtuf_get_stats(rtuf_context* c, rtuf_stats* out)
     out->bin_capacity = c->kids[c->last_kid]->capacity;
     out->raster_lanes = (uint32_t)c->kids[c->last_kid]->n_lanes; out->launch_group = (uint32_t)c->kids[c->last_kid]->group;
     out->regrowths = 0; out->timed_batches = 0; out->device_bytes = 0;
-    out->graphs_enabled = 1u; out->graph_hits = out->graph_misses = 0;
+    out->graphs_enabled = 1u; out->graph_hits = out->graph_misses = 0; out->lanes_side_by_side = c->lanes_share_queue ? 0u : 1u;
     for (const rtuf_context* k : c->kids) { out->device_bytes += k->device_bytes; out->graphs_enabled &= k->graphs_ok ? 1u : 0u; out->graph_hits += k->graph_hits; out->graph_misses += k->graph_misses; }
     out->sum_ms_pose = out->sum_ms_setup = out->sum_ms_raster = out->sum_ms_compare = out->sum_ms_total = out->sum_ms_clip = 0;
     for (const rtuf_context* k : c->kids) {
@@ -2033,6 +2093,7 @@ int rtuf_get_stats(rtuf_context* c, rtuf_stats* out)
   out->device_bytes = c->device_bytes;
   out->raster_lanes = (uint32_t)c->n_lanes; out->launch_group = (uint32_t)c->group;
   out->graphs_enabled = c->graphs_ok ? 1u : 0u; out->graph_hits = c->graph_hits; out->graph_misses = c->graph_misses;
+  out->lanes_side_by_side = c->lanes_share_queue ? 0u : 1u;
   return RTUF_OK;
 }
 

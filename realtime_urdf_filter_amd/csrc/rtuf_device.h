@@ -334,5 +334,6 @@ void launch_init_headers(BinHeader* hdr, size_t n_bins, hipStream_t st);
 void launch_publish_counters(const Counters* src, Counters* host_dst, int first, int stride, int count, hipStream_t st);
 void launch_tile(const TileArgs& a, bool two_kernel, bool cover_pass, hipStream_t st);   // a.io_u16 selects the 16UC1 variant
 void launch_compare(const CompareArgs& a, hipStream_t st);
+void launch_spin(unsigned long long ticks, hipStream_t st);      // a one-wave kernel that idles for `ticks` of the 100 MHz clock
 
 }  // namespace rtuf

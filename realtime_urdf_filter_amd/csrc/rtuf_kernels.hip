@@ -2186,9 +2186,18 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
 #ifdef RTUF_COUNT
             if (r_px + j < a.width) atomicAdd(&count_words()[1], 1u);
 #endif
+            // float z of the winner: written by the exact-z pass (rare), or (z24 + 1) * 2^-24 in the upper half of the depth
+            // range, or -- only in tiles with near geometry (uniform test: the headline workload never gets there) -- from
+            // z24 and the low bits of the float the key carries
             const uint32_t khi = (uint32_t)(k >> 32);
-            z[j] = (k & kResolvedBit) ? __uint_as_float((uint32_t)k)
-                 : (khi > 8388608u ? __fmul_rn((float)(khi + 1u), 5.9604644775390625e-08f) : near_z_from_key(khi, (uint32_t)k & kf.lowmask, kf.shift));
+            if (k & kResolvedBit) {
+              z[j] = __uint_as_float((uint32_t)k);
+            } else {
+              z[j] = __fmul_rn((float)(khi + 1u), 5.9604644775390625e-08f);
+              if (near_tile) {
+                if (khi <= 8388608u) z[j] = near_z_from_key(khi, (uint32_t)k & kf.lowmask, kf.shift);
+              }
+            }
             if (!TWO_KERNEL) thr[j] = shade_threshold(z[j], sc);
           }
         }
@@ -2316,6 +2325,16 @@ __global__ void init_headers_kernel(BinHeader* hdr, size_t n_bins)
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_bins) *reinterpret_cast<uint4*>(hdr + i) = make_uint4(0u, 0u, 0xffffffffu, 0xffffffffu);
 }
+
+// One wave that does nothing for `ticks` of the constant-rate clock: rtuf_create uses two of them to find out whether two HIP
+// streams can run side by side (the runtime multiplexes streams onto a few hardware queues, and two streams that share a
+// queue run their kernels one after the other).
+__global__ void spin_kernel(unsigned long long ticks)
+{
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+void launch_spin(unsigned long long ticks, hipStream_t st) { hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, ticks); }
 
 // host-callable launchers ---------------------------------------------------------------
 void launch_publish_counters(const Counters* src, Counters* host_dst, int first, int stride, int count, hipStream_t st)

@@ -1439,7 +1439,7 @@ def test_raster_lanes_split_a_batch_into_launch_groups(lanes, group, want_groups
     masked, mask = ctx.filter_batch(depth)
     check_vs_oracle(masked, mask, P, geo, depth, per)
     st = ctx.stats()
-    assert st["raster_lanes"] == lanes and st["groups_last_batch"] == want_groups and st["regrowths"] >= 1, st
+    assert st["raster_lanes"] == lanes and st["groups_last_batch"] == want_groups and st["regrowths"] >= 1 and st["lanes_side_by_side"] == 1, st
     assert st["work_items"] > 0 and st["triangles_submitted"] == n * 350
     assert (ctx.stream_handle() is None) == (lanes == 2)
     # three device batches back to back (two in flight): the lanes run ahead of each other across batch boundaries
