@@ -1966,7 +1966,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   // carry the low bits of the float z (KeyFmt)
   const uint32_t fraw = a.fbin_count[bin];
   const uint32_t fcount = fraw & 0x7fffffffu;
-  const bool near_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(fraw >> 31)) != 0u;
+  const bool near_tile = (fraw >> 31) != 0u;              // (wave-uniform: a scalar load of a workgroup-uniform address)
   KeyFmt kf;
   kf.shift = a.key_shift;
   kf.lowmask = near_tile ? (1u << a.key_shift) - 1u : 0u;

@@ -1503,3 +1503,28 @@ def test_memory_limit_shrinks_the_launch_group_instead_of_failing():
     ctx.close()
     with pytest.raises(R.RtufError):
         R.Context(128, 96, n, 0, params(raster_lanes=3))
+
+
+def test_lanes_that_share_a_hardware_queue_still_filter_exactly(tmp_path):
+    """The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues; rtuf_create measures whether the second lane's
+    stream runs beside the first's and looks for another if not.  With ONE hardware queue no stream can: the context must
+    say so (rtuf_stats.lanes_side_by_side == 0) and still produce the oracle's frames, split batches included."""
+    import subprocess
+    import sys
+    prog = r'''
+import sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np
+import test_parity_gpu as T
+ctx, P, geo, depth, per = T.run_soups(128, 96, 40, seed=91)
+masked, mask = ctx.filter_batch(depth)
+T.check_vs_oracle(masked, mask, P, geo, depth, per)
+st = ctx.stats()
+print("side_by_side", st["lanes_side_by_side"], "groups", st["groups_last_batch"])
+ctx.close()
+'''
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, cwd=root, env=dict(os.environ, GPU_MAX_HW_QUEUES="1"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "side_by_side 0 groups 2" in r.stdout, r.stdout
