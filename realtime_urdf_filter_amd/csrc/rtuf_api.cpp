@@ -761,7 +761,7 @@ static int alloc_frame_buffers(rtuf_context* c)
                                          : (c->n_lanes > 1 && N >= kSplitMin ? std::min((N + 1) / 2, 1024) : 1024);
   G = std::min(G, N);
   // Bins: fixed capacity per (stream, tile), direct addressing (one atomicAdd gives the slot: anything cleverer -- paged
-  // bins were built and measured, DESIGN.md section 4b -- costs the two big kernels 8 to 24 %).  What is NOT fixed any more is
+  // bins were built and measured, DESIGN.md appendix A.2 -- costs the two big kernels 8 to 24 %).  What is NOT fixed any more is
   // the size: 1024 records + 4096 fragments per bin to start with (64 KiB per bin), grown on the first
   // batch to a quarter above the fullest bin that batch produced (the 250 k-triangle robot: 3840 + 13568; round 2
   // reserved 8192 + 32768 whatever the scene).  rtuf_params.bin_capacity fixes the starting point.
