@@ -1087,6 +1087,9 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
         ent = e;
         const int k = (int)(e >> 8), t = (int)(e & 255u);
         slot = s_slot[k];
+        // (the draw-order number is asked for right away, not where it is needed: its global-memory latency then passes
+        // under the coverage arithmetic instead of after it)
+        order = a.corder[ch.tri_begin + t];
         const uint32_t p = s_packed[t];
         const uint32_t j0 = p & 1023u, j1 = (p >> 10) & 1023u, j2 = (p >> 20) & 1023u;
         v0.x = s_win[k][0][j0]; v0.y = s_win[k][1][j0]; v0.z = s_win[k][2][j0];
@@ -1097,7 +1100,6 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
                         : small_box_coverage<4>(v0, v1, v2, q0.x, q0.y >> 8, q1.x, q1.y >> 8, q2.x, q2.y >> 8, a.width, a.height, bx0, by0);
         if (mask) {
           z_plane(v0, v1, v2, a0, dzdx, dzdy);
-          order = a.corder[ch.tri_begin + t];
           // z is monotone along x and along y (also as evaluated in float), so its minimum over the box
           // is at a corner.  Anything that may reach window z <= 0.5 needs its plane in the tile
           // kernel (exact float z): it goes out as a record instead (geometry within ~2 x near of the camera).
@@ -1132,6 +1134,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
       const uint32_t e = s_list[j];
       const int k = (int)(e >> 8), t = (int)(e & 255u);
       slot = s_slot[k];
+      const uint32_t order = a.corder[ch.tri_begin + t];      // (asked for early, see above)
       const uint32_t p = s_packed[t];
       const uint32_t j0 = p & 1023u, j1 = (p >> 10) & 1023u, j2 = (p >> 20) & 1023u;
       Win v0, v1, v2;
@@ -1144,7 +1147,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
       if (have) {
         float a0, dzdx, dzdy;
         z_plane(v0, v1, v2, a0, dzdx, dzdy);
-        pk = pack_record(x0, y0, x1, y1, x2, y2, a0, dzdx, dzdy, a.corder[ch.tri_begin + t] | near_bit(a0, dzdx, dzdy, bx0, bx1, by0, by1));
+        pk = pack_record(x0, y0, x1, y1, x2, y2, a0, dzdx, dzdy, order | near_bit(a0, dzdx, dzdy, bx0, bx1, by0, by1));
         bbx = (uint32_t)bx0 | ((uint32_t)bx1 << 16);
         bby = (uint32_t)by0 | ((uint32_t)by1 << 16);
       }
@@ -1602,7 +1605,8 @@ __device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriR
 template <int MODE, bool LOW>
 __device__ __forceinline__ void raster_bin(unsigned long long* keys, const PackedTri* recs, uint32_t n,
                                            int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, uint32_t n_front, uint32_t capacity,
-                                           uint32_t* s_huge, TriRec* s_prec, uint4* s_pmeta, uint32_t zcover, const uint32_t* s_winners, const KeyFmt& kf, int dbg_skip = 0)
+                                           uint32_t* s_huge, TriRec* s_prec, uint4* s_pmeta, uint32_t zcover, const uint32_t* s_winners, const KeyFmt& kf,
+                                           uint4 first0, uint4 first1, bool have_first, int dbg_skip = 0)
 {
   const int lane = tid & 63;
   const uint32_t zdrop = MODE == 1 ? min(zcover, kf.zexact - 1u) : zcover;      // MODE 1: only what can reach a depth that needs the pass
@@ -1614,9 +1618,13 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     int lx0 = 0, lx1 = -1, ly0 = 0, ly1 = -1;
     PackedTri pk;
     if (have) {
-      const uint4* src = reinterpret_cast<const uint4*>(recs + ri);
       uint4* dst = reinterpret_cast<uint4*>(&pk);
-      dst[0] = src[0]; dst[1] = src[1];
+      if (have_first && base == 0u) {
+        dst[0] = first0; dst[1] = first1;      // (the caller asked for this lane's first record before it initialised the key tile)
+      } else {
+        const uint4* src = reinterpret_cast<const uint4*>(recs + ri);
+        dst[0] = src[0]; dst[1] = src[1];
+      }
       if (MODE == 1) {          // only near records whose draw-order key won a pixel that needs resolving
         const uint32_t h = winner_slot(pk.order & kOrderMask);
         if (!(pk.order & kNearBit) || !((s_winners[h >> 5] >> (h & 31u)) & 1u)) have = false;
@@ -1861,25 +1869,32 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
   }
 }
 
-// Fragments of the small triangles: 8 bytes each, perfectly coalesced, one LDS atomic each.  They never
-// need the exact-float-z pass (the set-up kernel keeps anything with window z near 0.5 or below as a record).
-__device__ __forceinline__ void raster_frags(unsigned long long* keys, const unsigned long long* frags, uint32_t nf, int tid, uint32_t zcover, int shift)
+#ifndef RTUF_FRAG_UNROLL
+#define RTUF_FRAG_UNROLL 4
+#endif
+constexpr int kFragUnroll = RTUF_FRAG_UNROLL;
+// Fragments of the small triangles: 8 bytes each, perfectly coalesced, one LDS atomic each.  They never need the exact-float-z
+// pass (the set-up kernel keeps anything with window z near 0.5 or below as a record).  kFragUnroll fragments per lane and
+// trip, ALL their loads issued before the first is used: the loop used to be load -> wait -> one LDS atomic, one exposed
+// global-memory latency per 256 fragments of a tile (a tile of the headline workload holds ~1,000): tile kernel 297 -> 285 us.
+// The first trip's loads are issued by the caller before the key tile is initialised (load_frags / apply_frags).
+__device__ __forceinline__ void load_frags(unsigned long long (&f)[kFragUnroll], const unsigned long long* frags, uint32_t nf, uint32_t base, int tid)
 {
-  if (zcover == 0xffffffffu) {                 // (uniform) no cover: nothing to test per fragment
-    for (uint32_t i = tid; i < nf; i += kTileThreads) {
-      const unsigned long long f = frags[i];
-      const int lidx = (int)((uint32_t)f & ((1u << kFragPosBits) - 1u));
-      const unsigned long long key = ((f >> 40) << 32) | (((uint32_t)(f >> kFragPosBits) & kMaxOrder) << shift);
-      RTUF_COUNT_TEST();
-      atomicMin(&keys[lidx], key);
-    }
-    return;
+#pragma unroll
+  for (int u = 0; u < kFragUnroll; u++) {
+    const uint32_t i = base + (uint32_t)u * kTileThreads + (uint32_t)tid;
+    f[u] = i < nf ? frags[i] : ~0ull;
   }
-  for (uint32_t i = tid; i < nf; i += kTileThreads) {
-    const unsigned long long f = frags[i];
-    const int lidx = (int)((uint32_t)f & ((1u << kFragPosBits) - 1u));
-    const unsigned long long key = ((f >> 40) << 32) | (((uint32_t)(f >> kFragPosBits) & kMaxOrder) << shift);
-    if ((uint32_t)(f >> 40) <= zcover) { RTUF_COUNT_TEST(); atomicMin(&keys[lidx], key); }        // (behind the tile's cover: cannot win)
+}
+__device__ __forceinline__ void apply_frags(unsigned long long* keys, const unsigned long long (&f)[kFragUnroll], uint32_t nf, uint32_t base, int tid, uint32_t zcover, int shift)
+{
+#pragma unroll
+  for (int u = 0; u < kFragUnroll; u++) {
+    const uint32_t i = base + (uint32_t)u * kTileThreads + (uint32_t)tid;
+    const int lidx = (int)((uint32_t)f[u] & ((1u << kFragPosBits) - 1u));
+    const unsigned long long key = ((f[u] >> 40) << 32) | (((uint32_t)(f[u] >> kFragPosBits) & kMaxOrder) << shift);
+    // (zcover == 0xffffffff: no cover, every fragment passes; behind the tile's cover: cannot win)
+    if (i < nf && (uint32_t)(f[u] >> 40) <= zcover) { RTUF_COUNT_TEST(); atomicMin(&keys[lidx], key); }
   }
 }
 
@@ -2034,6 +2049,18 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       c.order = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl.w) & kOrderMask;
       return c;
     };
+    // Ask for the first things this lane will need from the bins BEFORE the key tile is initialised: its first record and
+    // its first fragments (their latency then passes under the initialisation and the barrier instead of after it).
+#ifndef RTUF_PRELOAD
+#define RTUF_PRELOAD 1           // (0: A/B switch -- first record and first fragments are requested after the barrier, as before)
+#endif
+    uint4 first_rec0 = make_uint4(0u, 0u, 0u, 0u), first_rec1 = make_uint4(0u, 0u, 0u, 0u);
+    if (RTUF_PRELOAD && (uint32_t)tid < n) {
+      const uint4* src = reinterpret_cast<const uint4*>(recs + ((uint32_t)tid < n_front ? (uint32_t)tid : a.capacity - 1u - ((uint32_t)tid - n_front)));
+      first_rec0 = src[0]; first_rec1 = src[1];
+    }
+    unsigned long long first_frags[kFragUnroll];
+    if (RTUF_PRELOAD) load_frags(first_frags, frags, nf, 0u, tid);
     if (has_cover) {
       const CoverPlane c = cover_plane();
       for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
@@ -2057,19 +2084,29 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       if (fcount) atomicMax(&sh.max_fbin_fill, fcount);
       if (has_cover) atomicAdd(&sh.cover_tiles, 1u);
     }
+    // fragments first (one LDS atomic each; the first trip's are in registers already), then the records
     // (two instances of the rasterisation: tiles without near geometry -- every tile of a robot at arm's length -- do not
     // pay the instruction that puts the float's low bits into the key)
+    {
+      bool do_frags = true, do_records = true, load_only = false;
+      int skip = 0;
 #ifdef RTUF_ABLATE
-    if (!(a.flags & 0x800u)) {
-      if (near_tile) raster_bin<0, true>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, (int)((a.flags >> 12) & 3u));
-      else raster_bin<0, false>(keys, recs, n, x_base, y_base, tid, (a.flags & 0x200u) != 0, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, (int)((a.flags >> 12) & 3u));
-    }
-    if (!(a.flags & 0x400u)) raster_frags(keys, frags, nf, tid, zcover, kf.shift);
-#else
-    if (near_tile) raster_bin<0, true>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf);
-    else raster_bin<0, false>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf);
-    raster_frags(keys, frags, nf, tid, zcover, kf.shift);
+      do_frags = !(a.flags & 0x400u); do_records = !(a.flags & 0x800u); load_only = (a.flags & 0x200u) != 0; skip = (int)((a.flags >> 12) & 3u);
 #endif
+      if (do_frags) {
+        if (!RTUF_PRELOAD) load_frags(first_frags, frags, nf, 0u, tid);
+        apply_frags(keys, first_frags, nf, 0u, tid, zcover, kf.shift);
+        for (uint32_t base = kFragUnroll * kTileThreads; base < nf; base += kFragUnroll * kTileThreads) {
+          unsigned long long f[kFragUnroll];
+          load_frags(f, frags, nf, base, tid);
+          apply_frags(keys, f, nf, base, tid, zcover, kf.shift);
+        }
+      }
+      if (do_records) {
+        if (near_tile) raster_bin<0, true>(keys, recs, n, x_base, y_base, tid, load_only, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, first_rec0, first_rec1, RTUF_PRELOAD != 0, skip);
+        else raster_bin<0, false>(keys, recs, n, x_base, y_base, tid, load_only, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, first_rec0, first_rec1, RTUF_PRELOAD != 0, skip);
+      }
+    }
     __syncthreads();
     if (tid == 0) s_huge[0] = 0;             // the exact-z pass below builds its list again
 
@@ -2095,7 +2132,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
         }
       }
       __syncthreads();
-      raster_bin<1, true>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf);
+      raster_bin<1, true>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, first_rec0, first_rec1, false);
       if (has_cover) {                       // ... and the cover triangle, which is in no bin
         const CoverPlane c = cover_plane();
         for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
@@ -2106,6 +2143,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       }
       __syncthreads();
     }
+    // (requested here, not before the scan above: with the eight registers live from there the kernel sits at its 80-register
+    // limit and the allocation of everything before it suffers -- measured once more in round 4: tile kernel 296 instead of 280 us)
     request_sensor();
   }
 
