@@ -2083,6 +2083,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       if (count) atomicMax(&sh.max_bin_fill, count);
       if (fcount) atomicMax(&sh.max_fbin_fill, fcount);
       if (has_cover) atomicAdd(&sh.cover_tiles, 1u);
+#ifdef RTUF_HIST            // (scripts/bin_hist.sh, never the product: how much of the bins lies beyond a direct capacity of RTUF_HIST)
+      {
+        const uint32_t cls_count = RTUF_HIST_BACK ? count_back : count_front;
+        if (cls_count > (uint32_t)RTUF_HIST) atomicAdd(&sh.raster_atomics, (1ull << 40) + (cls_count - (uint32_t)RTUF_HIST));
+        if (fcount > 4u * RTUF_HIST) atomicAdd(&sh.drawn_pixels, (1ull << 40) + (fcount - 4u * RTUF_HIST));
+      }
+#endif
     }
     // fragments first (one LDS atomic each; the first trip's are in registers already), then the records
     // (two instances of the rasterisation: tiles without near geometry -- every tile of a robot at arm's length -- do not
@@ -2267,13 +2274,22 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
 #endif
 }
 
-// (held at 6 waves/SIMD = 80 VGPRs; left alone the compiler takes 84 = 5 waves/SIMD; the two-kernel variant spills 13
-// registers at 7 waves/SIMD = 72)
+// Registers: 7 waves/SIMD (72 VGPRs; seven workgroups' key tiles are 159.6 of the CU's 160 KB of LDS) for the variants
+// without the cover pass -- the compiler spills two or three registers there and the kernel is still 5 % faster than at
+// 6 waves/SIMD (80 VGPRs, where it needs 74: tile kernel 275 -> 261 us on the 256-stream VGA workload), the seventh
+// workgroup per CU hides what the lanes wait for; the cover variants (walls: C4) are left at 6, where they measure the
+// same alone and 2 % better beside the other lane's set-up kernel.  Left alone the compiler takes 84 registers = 5 waves/SIMD.
+#ifndef RTUF_TILE_WAVES
+#define RTUF_TILE_WAVES 7
+#endif
+#ifndef RTUF_TILE_WAVES_COVER
+#define RTUF_TILE_WAVES_COVER 6
+#endif
 template <bool TWO_KERNEL, bool U16, bool COVER>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6))) void tile_kernel(TileArgs a) { tile_body<TWO_KERNEL, U16, false, COVER>(a); }
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(COVER ? RTUF_TILE_WAVES_COVER : RTUF_TILE_WAVES))) void tile_kernel(TileArgs a) { tile_body<TWO_KERNEL, U16, false, COVER>(a); }
 // mask-only output, one bit per pixel (rtuf_filter_batch_bits*): 4 (2) B/pixel in, 1/8 B/pixel out
 template <bool U16, bool COVER>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(6))) void tile_bits_kernel(TileArgs a) { tile_body<false, U16, true, COVER>(a); }
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(COVER ? RTUF_TILE_WAVES_COVER : RTUF_TILE_WAVES))) void tile_bits_kernel(TileArgs a) { tile_body<false, U16, true, COVER>(a); }
 
 // ---------------------------------------------------------------------------------------
 // compare_kernel (two-kernel mode): streaming, 13 B/pixel (4 sensor + 4 z + 4 masked + 1 mask)
