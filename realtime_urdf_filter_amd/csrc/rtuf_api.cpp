@@ -448,22 +448,34 @@ static bool streams_run_side_by_side(hipStream_t a, hipStream_t b)
   return two < 1.5 * one;
 }
 
-// A new non-blocking stream that runs beside `ref` (nullptr: any stream).  Streams that turn out to share ref's hardware
-// queue are set aside -- still alive, so that the runtime places the next one elsewhere -- and released afterwards; after
-// eight of them the last one is taken as it is (*beside = false: the two will work, one after the other).
-static hipError_t create_stream_beside(hipStream_t ref, hipStream_t* out, bool* beside)
+// A new non-blocking stream that runs beside every stream of `refs` (none: any stream).  Streams that turn out to share a
+// hardware queue with one of them are set aside -- still alive, so that the runtime places the next one elsewhere -- and
+// released afterwards; after eight of them the last one is taken as it is (*beside = false: it will work, behind whatever
+// is queued in front of it).
+static hipError_t create_stream_beside(const std::vector<hipStream_t>& refs, hipStream_t* out, bool* beside)
 {
   *beside = true;
   hipError_t e = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
-  if (e != hipSuccess || !ref) return e;
+  if (e != hipSuccess || refs.empty()) return e;
   std::vector<hipStream_t> rejected;
-  while (e == hipSuccess && !streams_run_side_by_side(ref, *out)) {
+  auto beside_all = [&](hipStream_t s) { for (hipStream_t r : refs) if (r && !streams_run_side_by_side(r, s)) return false; return true; };
+  while (e == hipSuccess && !beside_all(*out)) {
     if (rejected.size() >= 8) { *beside = false; break; }
     rejected.push_back(*out);
     e = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
   }
   for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
   return e;
+}
+static hipError_t create_stream_beside(hipStream_t ref, hipStream_t* out, bool* beside)
+{
+  return create_stream_beside(ref ? std::vector<hipStream_t>{ref} : std::vector<hipStream_t>{}, out, beside);
+}
+static std::vector<hipStream_t> lane_streams(const rtuf_context* c)
+{
+  std::vector<hipStream_t> v;
+  for (int l = 0; l < c->n_lanes; l++) v.push_back(c->lane[l].stream);
+  return v;
 }
 
 extern "C" {
@@ -538,7 +550,14 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
     e = create_stream_beside(l > 0 ? c->lane[0].stream : nullptr, &c->lane[l].stream, &beside);
     if (!beside) c->lanes_share_queue = true;
   }
-  if (e == hipSuccess && !front) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+  // The pose stage's stream must not share a hardware queue with a lane either: its few microseconds of kernels (forward
+  // kinematics, matrix stacks, the first cull) would queue behind a quarter of a millisecond of set-up or tile kernel, and
+  // every lane waits for them.  (Seen with an RCCL communicator in the process: 463 k instead of 504 k frames/s.)
+  if (e == hipSuccess && !front) {
+    bool beside = true;
+    e = create_stream_beside(lane_streams(c), &c->side, &beside);
+    if (!beside) c->lanes_share_queue = true;
+  }
   if (e != hipSuccess) {
     snprintf(g_create_error, sizeof g_create_error, "hip init failed: %s", hipGetErrorString(e));
     delete c;
@@ -1906,8 +1925,13 @@ static int submit_host_batch(rtuf_context* c, int n, const void* const* depth_in
   for (int s = 0; s < n; s++)
     if (!depth_in[s] || (bits_out ? !bits_out[s] : !masked_out[s])) return c->fail(RTUF_ERR_INVALID, "null plane for stream %d", s);
   hipSetDevice(c->device);
-  if (!c->h2d) HIP_TRY(c, hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking));
-  if (!c->d2h) HIP_TRY(c, hipStreamCreateWithFlags(&c->d2h, hipStreamNonBlocking));
+  // (copy streams beside the lanes as well: an upload queued behind a lane's kernels would hold up the next batch)
+  if (!c->h2d || !c->d2h) {
+    bool beside = true;
+    sync_lanes(c);                      // (the probe times idle kernels: nothing else may be running; first host-plane call only)
+    if (!c->h2d) HIP_TRY(c, create_stream_beside(lane_streams(c), &c->h2d, &beside));
+    if (!c->d2h) HIP_TRY(c, create_stream_beside(lane_streams(c), &c->d2h, &beside));
+  }
   const int limit = (c->params.flags & RTUF_FLAG_TWO_KERNEL) ? 1 : kMaxInflight;
   while (c->pending >= limit) { const int rc = retire_oldest(c); if (rc != RTUF_OK) return rc; }
   rtuf_context::Batch& b = c->batch[(c->oldest + c->pending) % kMaxInflight];     // the slot submit_batch takes next
