@@ -76,8 +76,8 @@ typedef struct {
                                        0 = automatic: half of max_streams with two raster lanes (256 streams: two groups of
                                        128, one per lane), the whole batch up to 1024 with one; fewer if the bins would
                                        exceed a third of the free device memory or memory_limit_mb.  Smaller groups trade
-                                       frames/s for memory: 256 VGA streams of a 250 k-triangle robot run at 478 k frames/s
-                                       in 8.8 GB with groups of 128, at 457 k in 4.5 GB with groups of 64 */
+                                       frames/s for memory: 256 VGA streams of a 250 k-triangle robot run at 504 k frames/s
+                                       in 8.8 GB with groups of 128, at 483 k in 4.45 GB with groups of 64 */
   uint32_t pipelines;               /* 0 / 1: one raster pipeline.  2..4: that many complete pipelines (HIP streams, bins,
                                        staging, geometry copy) inside the context; batches alternate between them, so the
                                        small and low-occupancy kernels of one batch (pose stage, cull, clip, kernel tails)

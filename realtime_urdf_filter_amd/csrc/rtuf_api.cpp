@@ -773,8 +773,8 @@ static int alloc_frame_buffers(rtuf_context* c)
   // the work lose 4x less to their ramp and tail: 1024 streams in one group 522 k frames/s, in four groups of 256 one
   // after the other 460 k).  Two lanes: half of the streams -- a full batch is two groups, one per lane, the lanes'
   // kernels fill each other's ramps, tails and launch gaps, and the bins are what one group for all streams would take.
-  // (Measured on the 256-stream VGA workload: two groups of 128 478 k frames/s in 8.8 GB, four of 64 457 k in 4.5 GB,
-  // eight of 32 365 k in 2.2 GB, one lane 446 k in 8.7 GB; rtuf_params.memory_limit_mb / max_inflight_streams pick the
+  // (Measured on the 256-stream VGA workload: two groups of 128 504 k frames/s in 8.8 GB, four of 64 483 k in 4.45 GB,
+  // eight of 32 367 k in 2.2 GB, one lane 469 k in 8.7 GB; rtuf_params.memory_limit_mb / max_inflight_streams pick the
   // smaller working sets.)
   int G = c->params.max_inflight_streams ? (int)c->params.max_inflight_streams
                                          : (c->n_lanes > 1 && N >= kSplitMin ? std::min((N + 1) / 2, 1024) : 1024);

@@ -1473,6 +1473,12 @@ constexpr unsigned long long kNoFragment = 0x00ffffff00000000ull;   // cleared d
 constexpr unsigned long long kResolvedBit = 1ull << 63;
 
 
+// The key tile's rows may be padded in LDS (RTUF_KEY_PAD keys per row: an A/B switch, 0 in the product -- 2 moves vertically
+// adjacent pixels four banks apart; measured).
+#ifndef RTUF_KEY_PAD
+#define RTUF_KEY_PAD 0
+#endif
+constexpr int kKeyStride = kTileW + RTUF_KEY_PAD, kKeyCount = kKeyStride * kTileH;
 // MODE 0: depth test (atomicMin of {z24, order});  MODE 1: write the exact float z of the
 // fragment that won (needed only for window z <= 0.5, where float z is finer than 24 bits).
 // Instrumented builds (-DRTUF_COUNT, scripts/overdraw.sh; never the product): every depth test the tile kernel issues and
@@ -1589,9 +1595,9 @@ __device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriR
   const int e0 = __mul24(q.A[0], px) + __mul24(q.B[0], py) + q.C[0];
   const int e1 = __mul24(q.A[1], px) + __mul24(q.B[1], py) + q.C[1];
   const int e2 = __mul24(q.A[2], px) + __mul24(q.B[2], py) + q.C[2];
-  const int lidx = ly * kTileW + lx;
+  const int lidx = ly * kKeyStride + lx;
   if (min(e0, min(e1, e2)) > 0) fragment<MODE, LOW>(keys, q, px, py, lidx, kf);
-  if (min(e0 + q.B[0], min(e1 + q.B[1], e2 + q.B[2])) > 0 && ly < qy1) fragment<MODE, LOW>(keys, q, px, py + 1, lidx + kTileW, kf);
+  if (min(e0 + q.B[0], min(e1 + q.B[1], e2 + q.B[2])) > 0 && ly < qy1) fragment<MODE, LOW>(keys, q, px, py + 1, lidx + kKeyStride, kf);
 }
 
 // Rasterises the bin's records into the LDS key tile.  Every wave works on the records it loaded:
@@ -1658,7 +1664,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     // instructions per candidate and a quarter of the loop trips.
     {
       const int px0 = x_base + lx0, px1 = x_base + lx1, py_last = y_base + ly1;
-      int px = px0, py = y_base + ly0, lidx = ly0 * kTileW + lx0;
+      int px = px0, py = y_base + ly0, lidx = ly0 * kKeyStride + lx0;
       int e0 = __mul24(r.A[0], px) + __mul24(r.B[0], py) + r.C[0];
       int e1 = __mul24(r.A[1], px) + __mul24(r.B[1], py) + r.C[1];
       int e2 = __mul24(r.A[2], px) + __mul24(r.B[2], py) + r.C[2];
@@ -1666,7 +1672,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       const int back = 2 * (qcols - 1);                                    // x distance from the last quad of a row to the first
       const int s0 = 2 * r.B[0] - __mul24(back, r.A[0]), s1 = 2 * r.B[1] - __mul24(back, r.A[1]), s2 = 2 * r.B[2] - __mul24(back, r.A[2]);
       const int a0x2 = 2 * r.A[0], a1x2 = 2 * r.A[1], a2x2 = 2 * r.A[2];
-      const int row_step = 2 * kTileW - back;
+      const int row_step = 2 * kKeyStride - back;
       const int px_lastq = px0 + back;
       int todo = small ? __mul24(qcols, (ly1 - ly0 + 2) >> 1) : 0;
       while (__ballot(todo > 0)) {
@@ -1675,8 +1681,8 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
           const int f0 = e0 + r.B[0], f1 = e1 + r.B[1], f2 = e2 + r.B[2];
           if (min(e0, min(e1, e2)) > 0) fragment<MODE, LOW>(keys, r, px, py, lidx, kf);
           if (min(e0 + r.A[0], min(e1 + r.A[1], e2 + r.A[2])) > 0 && right) fragment<MODE, LOW>(keys, r, px + 1, py, lidx + 1, kf);
-          if (min(f0, min(f1, f2)) > 0 && below) fragment<MODE, LOW>(keys, r, px, py + 1, lidx + kTileW, kf);
-          if (min(f0 + r.A[0], min(f1 + r.A[1], f2 + r.A[2])) > 0 && right && below) fragment<MODE, LOW>(keys, r, px + 1, py + 1, lidx + kTileW + 1, kf);
+          if (min(f0, min(f1, f2)) > 0 && below) fragment<MODE, LOW>(keys, r, px, py + 1, lidx + kKeyStride, kf);
+          if (min(f0 + r.A[0], min(f1 + r.A[1], f2 + r.A[2])) > 0 && right && below) fragment<MODE, LOW>(keys, r, px + 1, py + 1, lidx + kKeyStride + 1, kf);
           const bool wrap = px == px_lastq;
           e0 += wrap ? s0 : a0x2;
           e1 += wrap ? s1 : a1x2;
@@ -1842,7 +1848,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
         for (int ly = qy0 + (tid >> 6); ly <= qy1; ly += kTileThreads / 64) {
           const float z = __fmaf_rn(q.dzdy, (float)(y_base + ly), zc);
           const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | (LOW ? (q.order | (__float_as_uint(z) & kf.lowmask)) : q.order);
-          const int lidx = ly * kTileW + lane;
+          const int lidx = ly * kKeyStride + lane;
           if (MODE == 0) {
             RTUF_COUNT_TEST();
             atomicMin(&keys[lidx], key);
@@ -1854,9 +1860,9 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
         for (int idx = tid; idx < npair; idx += kTileThreads) {
           const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
           const int lx = qx0 + idx - __mul24(yy, qw), ly = qy0 + 2 * yy;
-          const int lidx = ly * kTileW + lx;
+          const int lidx = ly * kKeyStride + lx;
           fragment<MODE, LOW>(keys, q, x_base + lx, y_base + ly, lidx, kf);
-          if (ly < qy1) fragment<MODE, LOW>(keys, q, x_base + lx, y_base + ly + 1, lidx + kTileW, kf);
+          if (ly < qy1) fragment<MODE, LOW>(keys, q, x_base + lx, y_base + ly + 1, lidx + kKeyStride, kf);
         }
       } else {
         for (int idx = tid; idx < npair; idx += kTileThreads) {
@@ -1891,7 +1897,8 @@ __device__ __forceinline__ void apply_frags(unsigned long long* keys, const unsi
 #pragma unroll
   for (int u = 0; u < kFragUnroll; u++) {
     const uint32_t i = base + (uint32_t)u * kTileThreads + (uint32_t)tid;
-    const int lidx = (int)((uint32_t)f[u] & ((1u << kFragPosBits) - 1u));
+    const int fpos = (int)((uint32_t)f[u] & ((1u << kFragPosBits) - 1u));      // row * kTileW + column, as the set-up kernel wrote it
+    const int lidx = RTUF_KEY_PAD ? fpos + (fpos / kTileW) * RTUF_KEY_PAD : fpos;
     const unsigned long long key = ((f[u] >> 40) << 32) | (((uint32_t)(f[u] >> kFragPosBits) & kMaxOrder) << shift);
     // (zcover == 0xffffffff: no cover, every fragment passes; behind the tile's cover: cannot win)
     if (i < nf && (uint32_t)(f[u] >> 40) <= zcover) { RTUF_COUNT_TEST(); atomicMin(&keys[lidx], key); }
@@ -1954,7 +1961,7 @@ __device__ __forceinline__ float shade(float sensor, float z, const ShadeConsts&
 template <bool TWO_KERNEL, bool U16, bool BITS, bool COVER>
 __device__ __forceinline__ void tile_body(const TileArgs& a)
 {
-  __shared__ unsigned long long keys[kTileW * kTileH];
+  __shared__ unsigned long long keys[kKeyCount];
   __shared__ uint32_t s_huge[2 + kHugeMax];        // raster_bin's list of whole-tile triangles (+ count in front, area threshold behind)
   __shared__ uint32_t s_winners[kWinnerWords];     // exact-z pass: filter of the draw-order keys that won a pixel in need
   __shared__ TriRec s_prec[64];                    // ... a batch of them unpacked by the first wave for all four,
@@ -2063,13 +2070,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
     if (RTUF_PRELOAD) load_frags(first_frags, frags, nf, 0u, tid);
     if (has_cover) {
       const CoverPlane c = cover_plane();
-      for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
-        const float z = __fmaf_rn(c.dzdy, (float)(y_base + i / kTileW), __fmaf_rn(c.dzdx, (float)(x_base + i % kTileW), c.a0));
+      for (int i = tid; i < kKeyCount; i += kTileThreads) {        // (padding columns, if any, hold the background key: the scans below skip them like any pixel nothing was drawn to)
+        const float z = __fmaf_rn(c.dzdy, (float)(y_base + i / kKeyStride), __fmaf_rn(c.dzdx, (float)(x_base + i % kKeyStride), c.a0));
         const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | (c.order << kf.shift) | (__float_as_uint(z) & kf.lowmask);
-        keys[i] = min(key, bgkey);
+        keys[i] = (RTUF_KEY_PAD == 0 || i % kKeyStride < kTileW) ? min(key, bgkey) : bgkey;
       }
     } else {
-      for (int i = tid; i < kTileW * kTileH; i += kTileThreads) keys[i] = bgkey;
+      for (int i = tid; i < kKeyCount; i += kTileThreads) keys[i] = bgkey;
     }
     if (tid == 0) { s_huge[0] = 0; s_huge[1 + kHugeMax] = n <= (uint32_t)kParkBelow ? (uint32_t)kQuarterArea : (uint32_t)kWallArea; }
 #ifdef RTUF_COUNT
@@ -2122,7 +2129,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
     // keys, which settle everything but the last micrometres in front of the near plane (z24 < zexact); a tile without
     // them has no record that could get there at all (the set-up marks those near) -- the test stays, it costs nothing.
     bool need = false;
-    for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
+    for (int i = tid; i < kKeyCount; i += kTileThreads) {
       const unsigned long long k = keys[i];
       if (k != bgkey && (uint32_t)(k >> 32) < kf.zexact) need = true;
     }
@@ -2131,7 +2138,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       if (tid < kWinnerWords) s_winners[tid] = 0u;
       if (tid == 0) atomicAdd(&a.counters->shard[bin % kCounterShards].exact_tiles, 1u);
       __syncthreads();
-      for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
+      for (int i = tid; i < kKeyCount; i += kTileThreads) {
         const unsigned long long k = keys[i];
         if (k != bgkey && (uint32_t)(k >> 32) < kf.zexact) {
           const uint32_t h = winner_slot((uint32_t)k >> kf.shift);
@@ -2142,8 +2149,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       raster_bin<1, true>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, first_rec0, first_rec1, false);
       if (has_cover) {                       // ... and the cover triangle, which is in no bin
         const CoverPlane c = cover_plane();
-        for (int i = tid; i < kTileW * kTileH; i += kTileThreads) {
-          const float z = __fmaf_rn(c.dzdy, (float)(y_base + i / kTileW), __fmaf_rn(c.dzdx, (float)(x_base + i % kTileW), c.a0));
+        for (int i = tid; i < kKeyCount; i += kTileThreads) {
+          const float z = __fmaf_rn(c.dzdy, (float)(y_base + i / kKeyStride), __fmaf_rn(c.dzdx, (float)(x_base + i % kKeyStride), c.a0));
           const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | (c.order << kf.shift) | (__float_as_uint(z) & kf.lowmask);
           if (keys[i] == key) keys[i] = kResolvedBit | (unsigned long long)__float_as_uint(z);
         }
@@ -2224,7 +2231,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
         bool frag[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const unsigned long long k = keys[r_ly * kTileW + r_lx + j];
+          const unsigned long long k = keys[r_ly * kKeyStride + r_lx + j];
           frag[j] = true;
           thr[j] = thr_bg;
           if (k == bgkey) { z[j] = bgz; frag[j] = analytic_bg; }
