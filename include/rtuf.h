@@ -324,9 +324,10 @@ typedef struct {
   uint32_t graphs_enabled;          /* 1 while small batches replay captured hipGraphs (pipeline children only); the library
                                        switches them off for good when captures keep evicting live entries               */
   uint64_t graph_hits, graph_misses;/* replays / captures so far                                                          */
-  uint32_t lanes_side_by_side;      /* 1: the lanes' HIP streams were measured to execute side by side at rtuf_create (always 1 with
-                                       one lane).  0: every stream the runtime handed out shared lane 0's hardware queue -- the
-                                       lanes then work, one after the other; raise GPU_MAX_HW_QUEUES (HIP runtime, default 4)  */
+  uint32_t lanes_side_by_side;      /* 1: the lanes' HIP streams and the pose stage's stream were measured to execute side by
+                                       side at rtuf_create (with one lane: the lane's and the pose stage's).  0: every stream the
+                                       runtime handed out shared a hardware queue with one of them -- everything then works, one
+                                       kernel after the other; raise GPU_MAX_HW_QUEUES (HIP runtime, default 4)  */
   uint32_t reserved1;
 } rtuf_stats;
 int rtuf_get_stats(rtuf_context *ctx, rtuf_stats *out);
