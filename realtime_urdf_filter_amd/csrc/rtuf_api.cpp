@@ -119,8 +119,8 @@ struct rtuf_context {
     float4* d_clip_spill = nullptr;
     BigRec* d_big_list = nullptr;                                // many-tile records (per counter shard), see bigrec_kernel
     WorkItem* d_items[kMaxInflight] = {};                        // the launch group's set-up work list (cull_kernel -> setup_kernel), one per
-                                                                 // batch slot: with one lane a batch's first cull runs in its pose stage,
-                                                                 // under the set-up kernel of the batch before it
+                                                                 // batch slot: the cull of a lane's first group runs in the batch's pose
+                                                                 // stage, under the set-up kernel of the batch before it
     float* d_zsurface = nullptr;
   };
   Lane lane[kMaxLanes];
@@ -1342,8 +1342,8 @@ static constexpr int kGraphMaxStreams = 32;     // batches up to this size repla
 enum { kEvStart = 0, kEvPoseEnd = 1, kEvLaneEnd = 2, kEvGroup0 = 2 + kMaxLanes, kEvPerGroup = 5 };
 
 // Enqueues the kernels of a plan: pose stage (forward kinematics, matrix stacks) on `sp`, then every launch group on the
-// stream of its lane, which waits for the pose stage through the batch's `posed` event.  With one lane the first group's
-// cull still belongs to the pose stage (it then runs under the previous batch's raster kernels).
+// stream of its lane, which waits for the pose stage through the batch's `posed` event.  The cull of every lane's first
+// group still belongs to the pose stage (it then runs under the previous batch's raster kernels).
 static int issue_plan(rtuf_context* c, rtuf_context::Batch& b, const BatchPlan& plan, hipStream_t sp, bool worst_case_grid)
 {
   const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
