@@ -23,7 +23,7 @@ are whole multiples of `--steps`; `timed_steps` in the output says how many step
 (the repetition count comes from a short probe, so the region ends up a few per cent either side of it), is long enough
 for an outside sampler (amd-smi every 5 s) to land inside it.
 
-`value` comes from ONE default-configured context: two raster lanes, a batch split into four launch groups whose kernels
+`value` comes from ONE default-configured context: three raster lanes, a batch split into three launch groups whose kernels
 overlap (rtuf_params.raster_lanes).  Overlapping kernels share the GPU, so their per-launch times describe no single
 kernel; the `roofline` object is therefore measured live in the same run on a second context with ONE lane (every kernel
 alone on the GPU, the whole batch per launch, HIP events over its own timed region), and `roofline.in_headline_run`
@@ -84,9 +84,9 @@ def main():
     ap.add_argument("--triangles", type=int, default=250000, help="triangle budget of the PR2-like model")
     ap.add_argument("--variants", type=int, default=2, help="distinct input batches rotated through the steps")
     ap.add_argument("--pipelines", type=int, default=1, help="contexts (HIP stream + bins each) per GPU that the batches alternate between: with 2 or 3, one batch's small and low-occupancy kernels overlap another's heavy ones, but kernels then share the GPU and per-launch times (roofline) no longer describe one kernel; default 1")
-    ap.add_argument("--launch-group", type=int, default=0, help="rtuf_params.max_inflight_streams: streams rasterised per internal launch group (0 = automatic: a quarter of the streams with two raster lanes, the whole batch up to 1024 with one); smaller groups shrink the tile bins and cost a kernel sequence per group")
+    ap.add_argument("--launch-group", type=int, default=0, help="rtuf_params.max_inflight_streams: streams rasterised per internal launch group (0 = automatic: the streams divided by the raster lanes, the whole batch up to 1024 with one lane); smaller groups shrink the tile bins and cost a kernel sequence per group")
     ap.add_argument("--overlap-pipelines", type=int, default=0, help="(obsolete, ignored: the overlap is the library default now, rtuf_params.raster_lanes; kept so that older command lines still run)")
-    ap.add_argument("--lanes", type=int, default=0, help="rtuf_params.raster_lanes of the headline context (0 = the library's default, 2: launch groups alternate between two HIP streams with bins of their own; 1: one lane)")
+    ap.add_argument("--lanes", type=int, default=0, help="rtuf_params.raster_lanes of the headline context (0 = the library's default, 3: launch groups alternate between three HIP streams with bins of their own; 1: one lane)")
     ap.add_argument("--isolated-seconds", type=float, default=2.0, help="length of the one-lane leg the roofline is measured on (N=1 only; 0 disables: the roofline then carries the headline run's per-launch times)")
     ap.add_argument("--host-copy-seconds", type=float, default=3.0, help="length of each with_host_copies leg (planes in pinned host memory; N=1 only; 0 disables)")
     ap.add_argument("--two-kernel", action="store_true", help="rasteriser + separate compare kernel")

@@ -73,11 +73,12 @@ typedef struct {
   uint32_t bin_capacity;            /* triangles per (stream, screen tile) bin to start with; 0 = automatic (1024); grown from what
                                        the first batches ask for */
   uint32_t max_inflight_streams;    /* streams rasterised per internal launch group (= streams a raster lane's bins are sized for);
-                                       0 = automatic: half of max_streams with two raster lanes (256 streams: two groups of
-                                       128, one per lane), the whole batch up to 1024 with one; fewer if the bins would
-                                       exceed a third of the free device memory or memory_limit_mb.  Smaller groups trade
-                                       frames/s for memory: 256 VGA streams of a 250 k-triangle robot run at 504 k frames/s
-                                       in 8.8 GB with groups of 128, at 483 k in 4.45 GB with groups of 64 */
+                                       0 = automatic: max_streams divided by the raster lanes (256 streams, three lanes: three
+                                       groups of 86, one per lane), the whole batch up to 1024 with one lane; fewer if the bins
+                                       would exceed a third of the free device memory or memory_limit_mb.  Smaller groups trade
+                                       frames/s for memory: 256 VGA streams of a 250 k-triangle robot run at 514-525 k frames/s
+                                       in 8.9 GB with three groups of 86, at 480 k in 4.5 GB with six groups of 43 (490 k in
+                                       4.45 GB with two lanes and four groups of 64) */
   uint32_t pipelines;               /* 0 / 1: one raster pipeline.  2..4: that many complete pipelines (HIP streams, bins,
                                        staging, geometry copy) inside the context; batches alternate between them, so the
                                        small and low-occupancy kernels of one batch (pose stage, cull, clip, kernel tails)
@@ -86,12 +87,14 @@ typedef struct {
                                        may be in flight; rtuf_filter() and the debug read-backs use the first / the last-used
                                        pipeline.  Fixed at rtuf_create. */
   /* ABI 5 */
-  uint32_t raster_lanes;            /* 0 = automatic (2).  A raster lane is a HIP stream plus a set of tile bins sized for ONE launch
-                                       group.  With 2, a batch of >= 32 streams is split into an even number of launch groups that
-                                       alternate between the lanes, which run free of each other: every kernel's ramp, tail and
-                                       launch gap is filled by the other lane's kernels.  Smaller batches take one lane each, in
-                                       turn.  1 = one lane, every kernel alone on the GPU (what per-kernel timings and rooflines
-                                       should be measured with).  Fixed at rtuf_create. */
+  uint32_t raster_lanes;            /* 0 = automatic (3; at most 3).  A raster lane is a HIP stream plus a set of tile bins sized for
+                                       ONE launch group.  With several, a batch of >= 32 streams is split into launch groups (a
+                                       multiple of the lanes) that alternate between the lanes, which run free of each other: every
+                                       kernel's ramp, tail and launch gap is filled by the other lanes' kernels.  Smaller batches
+                                       take one lane each, in turn.  Three lanes and the pose stage's stream are one HIP stream per
+                                       hardware queue of the runtime's default four (GPU_MAX_HW_QUEUES).  1 = one lane, every kernel
+                                       alone on the GPU (what per-kernel timings and rooflines should be measured with).  Fixed at
+                                       rtuf_create. */
   uint32_t memory_limit_mb;         /* upper bound of the rasteriser's working set (tile bins of all lanes), MiB; 0 = a third of
                                        the free device memory at rtuf_finalize_models.  When the bins a scene needs would exceed it
                                        the launch groups shrink (more, smaller launches) instead of the call failing. */

@@ -33,7 +33,8 @@ struct HostDraw {
 };
 struct HostLink { std::vector<HostDraw> draws; };
 static constexpr int kMaxInflight = 2;      // device batches that may be in flight at once
-static constexpr int kMaxLanes = 2;         // raster lanes of a context (rtuf_params.raster_lanes)
+static constexpr int kMaxLanes = 3;         // raster lanes a context can have (rtuf_params.raster_lanes; the default is kDefaultLanes)
+static constexpr int kDefaultLanes = 3;     // (three lanes + the pose stage's stream = the HIP runtime's four hardware queues)
 static constexpr int kSplitMin = 32;        // batches of at least this many streams are split over the lanes; smaller ones
                                             // take one lane each, in turn (their cost is launches, not kernel time)
 
@@ -109,7 +110,8 @@ struct rtuf_context {
   // bins, clip list, many-tile list, work list); the launch groups of a batch alternate between the lanes, so group B's
   // set-up kernel runs under group A's tile kernel and every kernel's ramp, tail and launch gap is filled by the other
   // lane -- what two contexts of half the streams gave a caller by hand (509 k instead of 455 k frames/s on the 256-stream
-  // VGA workload), now inside one context and with bins for two quarter-batches instead of two halves.  Kernels of one lane
+  // VGA workload in round 3), now inside one context.  Three lanes by default: with the pose stage's stream that is one HIP
+  // stream per hardware queue of the runtime's default four.  Kernels of one lane
   // are ordered by its stream, which is all the hand-over its arrays need; lanes share nothing that is written per group.
   struct Lane {
     hipStream_t stream = nullptr;
@@ -271,7 +273,7 @@ static void dev_free(rtuf_context* c, T*& p)
 static int groups_for(const rtuf_context* c, int n)
 {
   int k = (n + c->group - 1) / std::max(c->group, 1);
-  if (c->n_lanes > 1 && n >= kSplitMin) k = std::max(2, k + (k & 1));
+  if (c->n_lanes > 1 && n >= kSplitMin) k = ((std::max(k, 1) + c->n_lanes - 1) / c->n_lanes) * c->n_lanes;      // a multiple of the lanes
   return std::max(k, 1);
 }
 
@@ -543,11 +545,13 @@ int rtuf_create(rtuf_context** out, int device_id, int width, int height, int ma
   // (a front context of several pipelines owns no streams of its own: HIP multiplexes streams onto a few hardware queues,
   // and two pipelines whose main streams share a queue do not overlap at all)
   const bool front = c->params.pipelines > 1;
-  c->n_lanes = c->params.raster_lanes ? (int)c->params.raster_lanes : kMaxLanes;
+  c->n_lanes = c->params.raster_lanes ? (int)c->params.raster_lanes : kDefaultLanes;
   for (int l = 0; l < c->n_lanes && e == hipSuccess && !front; l++) {
-    // every further lane must be able to run beside the first
+    // every further lane must be able to run beside the ones before it
     bool beside = true;
-    e = create_stream_beside(l > 0 ? c->lane[0].stream : nullptr, &c->lane[l].stream, &beside);
+    std::vector<hipStream_t> before;
+    for (int k = 0; k < l; k++) before.push_back(c->lane[k].stream);
+    e = create_stream_beside(before, &c->lane[l].stream, &beside);
     if (!beside) c->lanes_share_queue = true;
   }
   // The pose stage's stream must not share a hardware queue with a lane either: its few microseconds of kernels (forward
@@ -771,13 +775,13 @@ static int alloc_frame_buffers(rtuf_context* c)
   // rasteriser working set
   // Launch group = the streams one lane's bins are sized for.  One lane: the whole batch up to 1024 streams (kernels of 4x
   // the work lose 4x less to their ramp and tail: 1024 streams in one group 522 k frames/s, in four groups of 256 one
-  // after the other 460 k).  Two lanes: half of the streams -- a full batch is two groups, one per lane, the lanes'
-  // kernels fill each other's ramps, tails and launch gaps, and the bins are what one group for all streams would take.
-  // (Measured on the 256-stream VGA workload: two groups of 128 504 k frames/s in 8.8 GB, four of 64 483 k in 4.45 GB,
-  // eight of 32 367 k in 2.2 GB, one lane 469 k in 8.7 GB; rtuf_params.memory_limit_mb / max_inflight_streams pick the
-  // smaller working sets.)
+  // after the other 460 k).  Several lanes: the streams divided by the lanes -- a full batch is one group per lane, the
+  // lanes' kernels fill each other's ramps, tails and launch gaps, and the bins are what one group for all streams would
+  // take.  (Measured on the 256-stream VGA workload: three lanes x 86 streams 514-525 k frames/s in 8.9 GB, two lanes x 128
+  // 497-508 k in 8.8 GB, two x four groups of 64 490 k in 4.45 GB, one lane 469 k in 8.7 GB; 64 x 720p with two walls:
+  // three lanes 180 k, two 168 k, one 143 k.  rtuf_params.memory_limit_mb / max_inflight_streams pick smaller working sets.)
   int G = c->params.max_inflight_streams ? (int)c->params.max_inflight_streams
-                                         : (c->n_lanes > 1 && N >= kSplitMin ? std::min((N + 1) / 2, 1024) : 1024);
+                                         : (c->n_lanes > 1 && N >= kSplitMin ? std::min((N + c->n_lanes - 1) / c->n_lanes, 1024) : 1024);
   G = std::min(G, N);
   // Bins: fixed capacity per (stream, tile), direct addressing (one atomicAdd gives the slot: anything cleverer -- paged
   // bins were built and measured, DESIGN.md appendix A.2 -- costs the two big kernels 8 to 24 %).  What is NOT fixed any more is

@@ -47,11 +47,11 @@ for name, radius, tri_scale, nt in (("far cloud", 3.0, 0.02, 200000), ("around c
 
     # stage times are per-kernel figures: ONE raster lane (with two, kernels of the two launch groups overlap and the sums
     # would count the overlap twice); the default two-lane context's time per batch is printed beside them
-    _, two_lane_ms, _ = run(2)
+    _, two_lane_ms, _ = run(0)
     st, one_lane_ms, cams = run(1)
     bad = 0
     for s in (0, n - 1):
         om, ok = O.filter_frame(depth[s], P, [(ident, 0, [0.0, 0.0, 0.0], v, t)], cams[s][0], cams[s][1], replace_value=5.0)
         bad += int((ok != dk[s].cpu().numpy()).sum()) + int((om.view(np.uint32) != dm[s].cpu().numpy().view(np.uint32)).sum())
-    print("%-24s pose %.3f setup+clip %.3f raster %.3f total %.3f ms (one lane, one batch alone) | per batch, two in flight: one lane %.3f, two lanes %.3f ms | clipped %d binned %d entries %d frags %d regrow %d | mismatches %d" % (
+    print("%-24s pose %.3f setup+clip %.3f raster %.3f total %.3f ms (one lane, one batch alone) | per batch, two in flight: one lane %.3f, default lanes %.3f ms | clipped %d binned %d entries %d frags %d regrow %d | mismatches %d" % (
         name, st["ms_pose"], st["ms_setup"], st["ms_raster"], st["ms_total"], one_lane_ms, two_lane_ms, st["triangles_clipped"], st["triangles_binned"], st["bin_entries"], st["fragments_binned"], st["regrowths"], bad))

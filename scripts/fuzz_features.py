@@ -1,7 +1,7 @@
 """Randomised differential test of the feature paths around the rasteriser (run on a GPU box):
    python scripts/fuzz_features.py [n_scenes] [first_seed]
-Every scene: 1-9 streams (work items with partial stream triples; every sixth scene 32-40, which a context of two raster lanes
-splits into launch groups), one or two raster lanes, 1-3 models with per-stream model selection,
+Every scene: 1-9 streams (work items with partial stream triples; every sixth scene 32-40, which a context of several raster lanes
+splits into launch groups), one to three raster lanes, 1-3 models with per-stream model selection,
 links made of primitives (boxes incl. the reference's second box, spheres, cylinders: fans, strips, quads with
 scale / translate ops) and of procedural meshes of up to several chunks, 32FC1 or 16UC1 frames, with or
 without the mask, fused or two-kernel, one pipeline or several inside the context (small batches then replay captured
@@ -46,7 +46,7 @@ for sc in range(n_scenes):
             links.append(draws)
         models.append(links)
     n_streams = int(rng.integers(1, 10))
-    if rng.integers(0, 6) == 0: n_streams = int(rng.integers(32, 41))      # large enough for a context of two raster lanes to split the batch
+    if rng.integers(0, 6) == 0: n_streams = int(rng.integers(32, 41))      # large enough for a context of several raster lanes to split the batch
     two = bool(rng.integers(0, 2)); u16 = bool(rng.integers(0, 3) == 0) and (W % 4 == 0); want_mask = bool(rng.integers(0, 4) != 0)
     p = R.default_params(); p.filter_replace_value = float(rng.choice([5.0, 0.0, 7.25])); p.depth_distance_threshold = float(rng.choice([0.05, 0.1, 0.0]))
     if two: p.flags |= R.FLAG_TWO_KERNEL
@@ -54,7 +54,7 @@ for sc in range(n_scenes):
     if rng.integers(0, 4) == 0: p.max_inflight_streams = int(rng.integers(1, 4))      # several launch groups per batch
     pipes = int(rng.choice([0, 0, 2, 3]))
     p.pipelines = pipes
-    p.raster_lanes = int(rng.choice([0, 0, 1, 2]))       # (0 = the default: two lanes; batches below 32 streams take the lanes in turn)
+    p.raster_lanes = int(rng.choice([0, 0, 1, 2, 3]))    # (0 = the default: three lanes; batches below 32 streams take the lanes in turn)
     bits = (not two) and (W % 4 == 0) and bool(rng.integers(0, 3) == 0)
     ctx = R.Context(W, H, n_streams, 0, p)
     ids = []

@@ -12,7 +12,7 @@ rm -rf $out; mkdir -p $out
 B="python $root/bench.py"
 # The counters and the per-kernel trace are taken on the ONE-LANE launch shape (--lanes 1: every kernel alone on the GPU, the
 # whole batch per launch): that is what bench.py's `roofline` describes (its one-lane leg); the default context overlaps the
-# kernels of two launch groups, whose per-launch times describe no single kernel (traced too, as *_two_lanes).
+# kernels of several launch groups, whose per-launch times describe no single kernel (traced too, as *_default_lanes).
 PROF_ARGS="--steps 20 --min-seconds 0 --cpu-seconds 0 --check-frames 0 --lanes 1 --isolated-seconds 0 --host-copy-seconds 0"
 
 # ---- 1. bench lines ---------------------------------------------------------------------------------------------
@@ -20,8 +20,10 @@ Q="--cpu-seconds 0 --host-copy-seconds 0 --min-seconds 3"       # the side lines
 $B $Q > /dev/null 2> $out/bench.err      # first run on a fresh box is the slowest: warm-up
 $B > $out/${tag}_bench.json 2>> $out/bench.err                   # THE line: defaults, exactly what the driver runs
 $B $Q --lanes 1 > $out/${tag}_bench_one_lane.json 2>> $out/bench.err
-$B $Q --launch-group 64 > $out/${tag}_bench_groups_of_64.json 2>> $out/bench.err
-$B $Q --launch-group 32 > $out/${tag}_bench_groups_of_32.json 2>> $out/bench.err
+$B $Q --lanes 2 > $out/${tag}_bench_two_lanes.json 2>> $out/bench.err
+$B $Q --launch-group 43 > $out/${tag}_bench_groups_of_43.json 2>> $out/bench.err
+$B $Q --lanes 2 --launch-group 64 > $out/${tag}_bench_two_lanes_groups_of_64.json 2>> $out/bench.err
+$B $Q --launch-group 22 > $out/${tag}_bench_groups_of_22.json 2>> $out/bench.err
 $B $Q --two-kernel > $out/${tag}_bench_two_kernel.json 2>> $out/bench.err
 $B $Q --two-kernel --streams 1024 --steps 30 > $out/${tag}_bench_two_kernel_1024.json 2>> $out/bench.err
 $B $Q --streams 1024 --steps 30 > $out/${tag}_bench_1024.json 2>> $out/bench.err
@@ -46,7 +48,7 @@ trace() {   # name, bench args: the bench's own default step counts (only the CP
   cp $(find /tmp/rp -name '*kernel_stats.csv' | head -1) $out/${tag}_kernel_stats$1.csv
 }
 trace "" "--lanes 1"                       # the roofline's launch shape: one lane, 256 streams per launch
-trace "_two_lanes" ""                      # the headline context: two lanes, 128 streams per launch, kernels of the two groups overlap
+trace "_default_lanes" ""                  # the headline context: three lanes, 86 streams per launch, kernels of the three groups overlap
 trace "_two_kernel" "--two-kernel --lanes 1"
 trace "_two_kernel_1024" "--two-kernel --streams 1024 --steps 30 --lanes 1"
 trace "_c4_share" "--workload c4 --shard-of 8 --steps 50 --lanes 1"

@@ -40,7 +40,7 @@ def test_bench_line_contract():
     # the roofline comes from the one-lane leg of the same run (every kernel alone on the GPU); the headline's own per-launch
     # figures sit beside it
     assert "one-lane context" in rf["measured_on"] and rf["in_headline_run"]["avg_launch_ms"] > 0 and rf["one_lane_leg"]["frames_per_s"] > 0
-    assert d["config"]["raster_lanes"] == 2 and d["config"]["launch_groups_per_batch"] == 1      # 8 streams: not split, the lanes in turn
+    assert d["config"]["raster_lanes"] == 3 and d["config"]["launch_groups_per_batch"] == 1      # 8 streams: not split, the lanes in turn
     hc = d["with_host_copies"]["modes"]
     assert len(hc) == 2 and all(m["frames_per_s"] > 0 and m["mismatching_values"] == 0 and 0 < m["fraction_of_link"]["host_to_device"] < 1.2 for m in hc.values())
     assert d["parity"]["mask_mismatch_pixels"] == 0 and d["parity"]["depth_mismatch_pixels"] == 0 and d["parity"]["frames_checked"] >= 2
@@ -50,14 +50,14 @@ def test_bench_line_contract():
 
 
 def test_bench_line_with_split_batches_and_every_stream_checked():
-    """64 streams: the headline context splits every batch into two launch groups, one per raster lane; by default every
+    """64 streams: the headline context splits every batch into three launch groups, one per raster lane; by default every
     stream of the last timed step is checked against the oracle."""
     args = ["--steps", "3", "--warmup", "1", "--streams", "64", "--triangles", "8000", "--width", "320", "--height", "192", "--cpu-seconds", "0",
             "--min-seconds", "0.3", "--isolated-seconds", "0.2", "--host-copy-seconds", "0"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
-    assert d["config"]["raster_lanes"] == 2 and d["config"]["launch_groups_per_batch"] == 2 and d["config"]["streams_per_launch_group"] == 32
+    assert d["config"]["raster_lanes"] == 3 and d["config"]["launch_groups_per_batch"] == 3 and d["config"]["streams_per_launch_group"] == 22
     assert d["parity"]["frames_checked"] == 64 and d["parity"]["mismatching_values"] == 0
     rf = d["roofline"]
     assert rf["streams_per_launch"] == 64 and rf["in_headline_run"]["streams_per_launch"] == 32 and rf["launches_per_step"] == 1

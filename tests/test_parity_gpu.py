@@ -1427,11 +1427,11 @@ def test_stl_facets_are_welded_at_load_and_the_image_does_not_change():
 
 
 # ---- raster lanes (ABI 5) -----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("lanes,group,want_groups", [(2, 0, 2), (2, 24, 4), (2, 8, 8), (1, 0, 1), (1, 24, 3)])
+@pytest.mark.parametrize("lanes,group,want_groups", [(0, 0, 3), (3, 8, 9), (2, 0, 2), (2, 24, 4), (2, 8, 8), (1, 0, 1), (1, 24, 3)])
 def test_raster_lanes_split_a_batch_into_launch_groups(lanes, group, want_groups):
-    """64 streams.  With two raster lanes (own HIP stream + own tile bins each) the batch is split into an even number of
-    launch groups that alternate between the lanes; with one lane into as many groups as the bins ask for, one after the
-    other.  Too-small bins force a regrowth (every lane's bins grow, both batches run again).  Every stream of every batch
+    """64 streams.  With several raster lanes (own HIP stream + own tile bins each; 0 = the default, three) the batch is
+    split into a multiple of the lanes of launch groups that alternate between the lanes; with one lane into as many groups
+    as the bins ask for, one after the other.  Too-small bins force a regrowth (every lane's bins grow, both batches run again).  Every stream of every batch
     equals the oracle, whatever the split; rtuf_stats reports it."""
     import torch
     n = 64
@@ -1439,9 +1439,9 @@ def test_raster_lanes_split_a_batch_into_launch_groups(lanes, group, want_groups
     masked, mask = ctx.filter_batch(depth)
     check_vs_oracle(masked, mask, P, geo, depth, per)
     st = ctx.stats()
-    assert st["raster_lanes"] == lanes and st["groups_last_batch"] == want_groups and st["regrowths"] >= 1 and st["lanes_side_by_side"] == 1, st
+    assert st["raster_lanes"] == (lanes or 3) and st["groups_last_batch"] == want_groups and st["regrowths"] >= 1 and st["lanes_side_by_side"] == 1, st
     assert st["work_items"] > 0 and st["triangles_submitted"] == n * 350
-    assert (ctx.stream_handle() is None) == (lanes == 2)
+    assert (ctx.stream_handle() is None) == (lanes != 1)
     # three device batches back to back (two in flight): the lanes run ahead of each other across batch boundaries
     dev = torch.device("cuda:0")
     d_in = [torch.from_numpy(np.roll(depth, k, axis=0).copy()).to(dev) for k in range(3)]
@@ -1465,7 +1465,7 @@ def test_raster_lanes_split_a_batch_into_launch_groups(lanes, group, want_groups
 
 
 def test_small_batches_take_the_lanes_in_turn():
-    """Batches below the split size are not split: each takes one lane, the next batch the other (so two small batches in
+    """Batches below the split size are not split: each takes one lane, the next batch the next lane (so two small batches in
     flight overlap on the GPU).  Six batches of 3 streams with different sensor planes, nothing waits in between."""
     import torch
     n, W, H = 3, 160, 120
@@ -1480,7 +1480,7 @@ def test_small_batches_take_the_lanes_in_turn():
     for k in range(6):
         check_vs_oracle(outs[k][0].cpu().numpy(), outs[k][1].cpu().numpy(), P, geo, (depth + 0.01 * k).astype(np.float32), per)
     st = ctx.stats()
-    assert st["raster_lanes"] == 2 and st["groups_last_batch"] == 1
+    assert st["raster_lanes"] == 3 and st["groups_last_batch"] == 1
     ctx.close()
 
 
@@ -1489,7 +1489,7 @@ def test_memory_limit_shrinks_the_launch_group_instead_of_failing():
     grown bins no longer fit the limit for the launch group the context started with, so the group shrinks (the same bytes
     hold deeper bins for fewer streams, the batch runs in more launches) -- the context stays usable and exact."""
     n = 48
-    ctx, P, geo, depth, per = run_soups(128, 96, n, seed=78, bin_capacity=1, memory_limit_mb=1)
+    ctx, P, geo, depth, per = run_soups(128, 96, n, seed=78, bin_capacity=1, memory_limit_mb=1, raster_lanes=2)
     before = ctx.stats()
     assert before["launch_group"] == 6, before          # 2 lanes x 6 streams x 6 tiles x (32 + 1024 x 8) B = 0.56 MiB (12 streams: 1.13)
     masked, mask = ctx.filter_batch(depth)
@@ -1502,7 +1502,7 @@ def test_memory_limit_shrinks_the_launch_group_instead_of_failing():
     assert bits_equal(masked, masked2) and np.array_equal(mask, mask2) and ctx.stats()["regrowths"] == st["regrowths"]
     ctx.close()
     with pytest.raises(R.RtufError):
-        R.Context(128, 96, n, 0, params(raster_lanes=3))
+        R.Context(128, 96, n, 0, params(raster_lanes=4))
 
 
 def test_lanes_that_share_a_hardware_queue_still_filter_exactly(tmp_path):
@@ -1527,4 +1527,4 @@ ctx.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, cwd=root, env=dict(os.environ, GPU_MAX_HW_QUEUES="1"), timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert "side_by_side 0 groups 2" in r.stdout, r.stdout
+    assert "side_by_side 0 groups 3" in r.stdout, r.stdout
