@@ -1427,7 +1427,7 @@ def test_stl_facets_are_welded_at_load_and_the_image_does_not_change():
 
 
 # ---- raster lanes (ABI 5) -----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("lanes,group,want_groups", [(0, 0, 3), (3, 8, 9), (2, 0, 2), (2, 24, 4), (2, 8, 8), (1, 0, 1), (1, 24, 3)])
+@pytest.mark.parametrize("lanes,group,want_groups", [(0, 0, 3), (3, 8, 8), (3, 6, 11), (2, 0, 2), (2, 24, 4), (2, 8, 8), (1, 0, 1), (1, 24, 3)])
 def test_raster_lanes_split_a_batch_into_launch_groups(lanes, group, want_groups):
     """64 streams.  With several raster lanes (own HIP stream + own tile bins each; 0 = the default, three) the batch is
     split into a multiple of the lanes of launch groups that alternate between the lanes; with one lane into as many groups
