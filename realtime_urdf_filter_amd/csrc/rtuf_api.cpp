@@ -269,7 +269,7 @@ static void dev_free(rtuf_context* c, T*& p)
 }
 
 // Launch groups a batch of n streams is split into: as many as the lanes' bins need (c->group streams each at most), and,
-// with two lanes, an even number (>= 2) for batches worth splitting, so that both lanes get the same amount of work.
+// with several lanes, a multiple of the lanes for batches worth splitting, so that every lane gets the same amount of work.
 static int groups_for(const rtuf_context* c, int n)
 {
   int k = (n + c->group - 1) / std::max(c->group, 1);
@@ -1420,7 +1420,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     if (n_groups == 1) { b.lanes_used = 1u << c->next_lane; c->next_lane = (c->next_lane + 1) % c->n_lanes; }
     else for (int l = 0; l < std::min(c->n_lanes, n_groups); l++) b.lanes_used |= 1u << l;
   } else if (n_groups > 1) {
-    // (a re-run after the launch group shrank may need both lanes where the first run needed one)
+    // (a re-run after the launch group shrank may need every lane where the first run needed one)
     for (int l = 0; l < std::min(c->n_lanes, n_groups); l++) b.lanes_used |= 1u << l;
   }
   const int lane0 = __builtin_ctz(b.lanes_used);
@@ -1701,7 +1701,7 @@ static int retire_oldest(rtuf_context* c)
     if (!bin_over && !clip_over && !list_over && !big_over) {
       if (b.host_io) HIP_TRY(c, hipEventSynchronize(b.downloaded));
       if (b.timing && b.events.size() >= (size_t)(kEvGroup0 + kEvPerGroup * b.n_groups)) {
-        // per launch group E0 .. E4 (see issue_plan).  With two lanes the kernels of different groups overlap: the sums
+        // per launch group E0 .. E4 (see issue_plan).  With several lanes the kernels of different groups overlap: the sums
         // below add up per-launch durations, they are not wall time.
         const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0 && !b.bits;
         auto el = [&](size_t i, size_t j) { float ms = 0; hipEventElapsedTime(&ms, b.events[i], b.events[j]); return ms; };

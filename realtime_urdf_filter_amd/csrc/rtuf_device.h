@@ -13,7 +13,7 @@
 //     link_tf f64[N][L][16]                                         (two slots: one per batch in flight)
 //     mvp    f32[N][D][16]  written by pose_kernel;  bg BgInfo[N];  items WorkItem[] written by cull_kernel (one list per raster lane)
 //     depth  f32[N][H][W] in, masked f32[N][H][W] + mask u8[N][H][W] out
-//   rasteriser working set of ONE RASTER LANE (a context has one or two: a lane is a HIP stream plus the arrays below; the
+//   rasteriser working set of ONE RASTER LANE (a context has one to three: a lane is a HIP stream plus the arrays below; the
 //   launch groups of a batch alternate between the lanes, so one group's set-up runs under the other's tile kernel),
 //   per stream g of the launch group and screen tile
 //     bin_hdr   BinHeader[G][tiles]   records binned from the front (small boxes) and from the back of the bin, and the tile's
