@@ -69,6 +69,113 @@ def pin_to_numa_node_of_gpu(local_rank):
     return None
 
 
+def side_leg(label, workload, job_world, near_arm, streams, seconds, local_rank, triangles, reuse_planes=None):
+    """One of the OTHER BASELINE.json configurations, timed for a few seconds after the headline's timed region (never
+    `value`): frames/s through a default context (pipelined, inputs resident in HBM, a new joint state every step, forward
+    kinematics on the GPU), the tile kernel's per-launch time from a one-lane context (every kernel alone on the GPU), and
+    8 streams of the last step against the oracle.  The reference's own timer wraps the whole call for whatever scene is
+    loaded (src/urdf_filter.cpp:211-244)."""
+    import torch
+    import realtime_urdf_filter_amd as R
+    from bench_support import configs as CF
+    from oracle import bindings as O
+    t_leg = time.perf_counter()
+    dev = torch.device("cuda", local_rank)
+    sh = CF.build(workload, job_world, 0, streams=streams, triangles=triangles, variants=2, near_arm=near_arm, host_fk=False)
+    n, W, H = sh.n, sh.width, sh.height
+    wl0 = sh.wl0
+    # sensor planes: the headline's resident ones where the frame size is the same, else a pool of 8 synthetic planes;
+    # stream s sees plane s % pool (the joint states, not the planes, are what changes from step to step)
+    if reuse_planes is not None and tuple(reuse_planes.shape[1:]) == (H, W) and reuse_planes.dtype == torch.float32:
+        pool = reuse_planes
+    else:
+        pool = torch.from_numpy(sh.depth_host(0, 8, tiled=False)).to(dev)
+    idx = torch.arange(n, device=dev) % pool.shape[0]
+    d_in = pool if (n == pool.shape[0]) else pool.index_select(0, idx)
+    sets = [(torch.empty((n, H, W), dtype=torch.float32, device=dev), torch.empty((n, H, W), dtype=torch.uint8, device=dev)) for _ in range(2)]
+    out = {"workload": sh.describe(), "streams": n, "size": [W, H]}
+
+    def run(lanes, secs, latency=False):
+        p = R.default_params()
+        p.filter_replace_value, p.depth_distance_threshold = wl0.replace_value, wl0.max_diff
+        p.raster_lanes = lanes
+        if lanes == 1:
+            p.max_inflight_streams = min(n, 1024)
+        ctx = R.Context(W, H, n, local_rank, p)
+        sh.load(ctx)
+
+        def submit(k):
+            ctx.filter_batch_device(n, d_in.data_ptr(), sets[k % 2][0].data_ptr(), sets[k % 2][1].data_ptr())
+
+        for k in range(3):                       # bin sizing, cover-pass decision
+            sh.stage(ctx, k)
+            submit(k)
+            ctx.sync()
+        k0 = 3
+        sh.stage(ctx, k0)
+        tq = time.perf_counter()
+        for k in range(k0, k0 + 4):
+            submit(k)
+            sh.stage(ctx, k + 1)
+        ctx.sync()
+        est = (time.perf_counter() - tq) / 4
+        steps = max(8, int(np.ceil(secs / max(est, 1e-9))))
+        k0 += 4
+        ctx.enable_timing(3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if latency:
+            for k in range(k0, k0 + steps):      # one frame in flight: stage, filter, wait
+                sh.stage(ctx, k)
+                submit(k)
+                ctx.sync()
+        else:
+            for k in range(k0, k0 + steps):
+                submit(k)
+                sh.stage(ctx, k + 1)
+            ctx.sync()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        st = ctx.stats()
+        g = max(1, st["groups_last_batch"])
+        res = {"frames_per_s": n * steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "device_memory_bytes": st["device_bytes"],
+               "launch_groups_per_batch": g, "raster_lanes": st["raster_lanes"], "regrowths": st["regrowths"],
+               "tile_ms": st["sum_ms_raster"] / max(st["timed_batches"], 1) / g, "setup_ms": st["sum_ms_setup"] / max(st["timed_batches"], 1) / g}
+        return ctx, res, k0 + steps - 1
+
+    ctx, head, k_last = run(0, seconds)
+    out.update({"frames_per_s": head["frames_per_s"], "ms_per_step": head["ms_per_step"], "steps": head["steps"],
+                "device_memory_bytes": head["device_memory_bytes"], "raster_lanes": head["raster_lanes"],
+                "launch_groups_per_batch": head["launch_groups_per_batch"]})
+    # parity: 8 streams of the last step, the oracle fed the matrices the device's forward kinematics produced
+    link_dev, cam_dev = ctx.read_poses(n, sh.n_links_total)
+    hm, hk = sets[k_last % 2][0].cpu().numpy(), sets[k_last % 2][1].cpu().numpy()
+    check = sorted(set(int(x) for x in np.linspace(0, n - 1, num=min(8, n))))
+    frames = [O.PreparedFrame(d_in[s].cpu().numpy(), *sh.oracle_frame(k_last, s, link_dev, cam_dev), max_diff=wl0.max_diff, replace_value=wl0.replace_value) for s in check]
+    O.run_prepared(frames, max(1, min(len(os.sched_getaffinity(0)), len(frames))))
+    bad = sum(int((pf.mask != hk[s]).sum()) + int((pf.masked.view(np.uint32) != hm[s].view(np.uint32)).sum()) for s, pf in zip(check, frames))
+    out.update({"frames_checked": len(check), "mismatching_values": bad})
+    ctx.close()
+    if n == 1:
+        # BASELINE config 2: one camera, one frame in flight -- the latency of a filter() call with resident planes
+        ctx, lat, _ = run(0, max(0.5, seconds / 2), latency=True)
+        out["latency_us_per_frame"] = lat["ms_per_step"] * 1e3
+        out["latency_note"] = "stage joint state -> rtuf_filter_batch_device -> rtuf_sync, one frame in flight, planes resident in HBM"
+        ctx.close()
+    # the tile kernel alone on the GPU: one-lane context, all streams per launch
+    ctx, one, _ = run(1, max(0.5, seconds / 2))
+    alg = 9 * W * H * (n / one["launch_groups_per_batch"])
+    out["tile_kernel"] = {"avg_launch_ms": one["tile_ms"], "streams_per_launch": n / one["launch_groups_per_batch"], "algorithmic_bytes_per_launch": int(alg),
+                          "frac": (alg / (one["tile_ms"] * 1e-3) / 1e9 / 8000.0) if one["tile_ms"] > 0 else None, "peak": 8000.0, "unit": "GB/s",
+                          "measured_on": "one-lane context of this leg (HIP events around the kernel, every eighth batch), %d steps" % one["steps"],
+                          "one_lane_frames_per_s": one["frames_per_s"], "setup_kernel_avg_launch_ms": one["setup_ms"]}
+    ctx.close()
+    del sets, d_in
+    torch.cuda.empty_cache()
+    out["leg_seconds"] = time.perf_counter() - t_leg
+    return label, out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +201,8 @@ def main():
     ap.add_argument("--u16", action="store_true", help="16UC1 depth in/out (uint16 millimetres) with the conversions fused into the kernels")
     ap.add_argument("--no-mask", action="store_true", help="need_mask_ == false: no mask output")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per leg (single thread, all cores); 0 disables")
+    ap.add_argument("--other-configs-seconds", type=float, default=2.0, help="length of each `other_configs` leg (BASELINE configs 2, 4, 5 and the arm-in-front-of-the-lens pose, timed after the headline's region; 0 disables)")
+    ap.add_argument("--other-configs", choices=["auto", "on", "off"], default="auto", help="auto: the legs run with the default c3 command at N=1 (what the driver runs); on: with any c3 command (the legs take --streams / --triangles, the tests' small sizes); off: never")
     ap.add_argument("--bin-capacity", type=int, default=0, help="rtuf_params.bin_capacity (records per tile bin; 0 = the library's default, grown on overflow)")
     ap.add_argument("--debug-flags", type=lambda x: int(x, 0), default=0, help="timing experiments only (needs the RTUF_ABLATE build; results are wrong)")
     ap.add_argument("--near-arm", action="store_true", help="c3 / c4: every stream poses the robot's right forearm 0.1-0.35 m in front of the lens (exact-z pass, near-plane clipping, whole-tile occluders)")
@@ -232,6 +341,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_rank = elapsed                          # this rank's own clock (the line's value uses the MAX over ranks)
     sts = [c.stats() for c in ctxs]
     timed = sum(st["timed_batches"] for st in sts)
     assert timed >= 1 and timed >= timed_steps // 8, ([st["timed_batches"] for st in sts], timed_steps)
@@ -295,14 +405,20 @@ def main():
         bad_depth += int((depth_f32_to_u16(pf.masked) != hm).sum()) if args.u16 else int((pf.masked.view(np.uint32) != hm.view(np.uint32)).sum())
     t_par = time.perf_counter() - t_par
     frames_total, bad_total, checked_total = frames_rank, bad_mask + bad_depth, len(check)
-    per_rank = [{"rank": rank, "streams": n, "frames": frames_rank, "frames_checked": len(check), "mismatching_values": bad_mask + bad_depth}]
+    per_rank = [{"rank": rank, "streams": n, "frames": frames_rank, "frames_checked": len(check), "mismatching_values": bad_mask + bad_depth,
+                 "frames_per_s": frames_rank / elapsed_rank}]
     if dist is not None:
         # the trivial end-of-run gather (a few numbers per rank): frames, parity counts
         frames_total, elapsed = sharding.gather_frame_counts(dist, frames_rank, elapsed, device=cdev)
         t = torch.tensor([n, frames_rank, len(check), bad_mask + bad_depth], dtype=torch.int64, device=cdev)
         outl = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(outl, t)
-        per_rank = [{"rank": r, "streams": int(o[0]), "frames": int(o[1]), "frames_checked": int(o[2]), "mismatching_values": int(o[3])} for r, o in enumerate(outl)]
+        tf = torch.tensor([elapsed_rank], dtype=torch.float64, device=cdev)
+        outf = [torch.zeros_like(tf) for _ in range(world)]
+        dist.all_gather(outf, tf)
+        # (every rank's own frames / own seconds between the two barriers: a straggler shows here, the line's value is frames / MAX)
+        per_rank = [{"rank": r, "streams": int(o[0]), "frames": int(o[1]), "frames_checked": int(o[2]), "mismatching_values": int(o[3]),
+                     "frames_per_s": int(o[1]) / float(f[0])} for r, (o, f) in enumerate(zip(outl, outf))]
         bad_total = sum(x["mismatching_values"] for x in per_rank)
         checked_total = sum(x["frames_checked"] for x in per_rank)
 
@@ -320,7 +436,9 @@ def main():
         iso_leg = None
         breakdown = None
         iso = None
-        if world == 1 and args.isolated_seconds > 0 and not (lanes == 1 and P == 1 and groups_per_batch == 1):
+        # (with several ranks: rank 0 measures it on its GPU while the others wait at the closing barrier -- after the timed
+        # region, so nothing of it is in `value`)
+        if args.isolated_seconds > 0 and not (lanes == 1 and P == 1 and groups_per_batch == 1):
             p1 = R.default_params()
             p1.filter_replace_value, p1.depth_distance_threshold, p1.flags = p.filter_replace_value, p.depth_distance_threshold, p.flags
             p1.raster_lanes, p1.max_inflight_streams, p1.bin_capacity = 1, min(n, 1024), args.bin_capacity
@@ -542,6 +660,11 @@ def main():
         }
         if fk_err is not None:
             out["fk"] = {"on_device": True, "max_abs_diff_vs_host_fk": fk_err}
+        # the whole path against the HBM roofline: algorithmic bytes of a frame (fused: sensor read + masked write + mask write;
+        # two-kernel: + the z-surface written and read) x frames/s over all GPUs / (GPUs x 8 TB/s)
+        bytes_per_frame = (((4 if args.u16 else 8) + mask_b) + (8 if two else 0)) * px
+        out["hbm_frac_end_to_end"] = {"value": value * bytes_per_frame / (world * peak * 1e9), "bytes_per_frame": bytes_per_frame, "peak_GB_per_s_per_gpu": peak, "n_gpus": world,
+                                      "note": "value x algorithmic bytes per frame / (n_gpus x 8 TB/s): pose, cull, set-up, clip and tile kernels of a step all inside it"}
         # ---- the whole path with the planes in host memory (the reference's own timer wraps upload + render + read-back,
         # src/urdf_filter.cpp:211-244, :332-353, :729-735).  Never `value`. ----------------------------------------------
         if world == 1 and args.host_copy_seconds > 0 and P == 1 and not two and not args.no_mask:
@@ -625,8 +748,23 @@ def main():
                           "(rtuf_filter_batch_async / rtuf_filter_batch_bits_u16_async: upload on one copy stream, kernels, read-back on another); "
                           "PCIe-bound. Never `value`: the contract's value has its inputs resident in HBM")
             out["with_host_copies"] = hc
+        # ---- the other BASELINE.json configurations, a few seconds each (never `value`) --------------------------------------
+        legs_on = args.other_configs == "on" or (args.other_configs == "auto" and default_cmd and not two and P == 1 and args.lanes == 0 and args.launch_group == 0 and args.debug_flags == 0)
+        if world == 1 and args.other_configs_seconds > 0 and legs_on and args.workload == "c3":
+            oc = {}
+            legs = (("c2_batch1", "c3", 1, False, 1), ("c3_near_arm", "c3", 1, True, n), ("c4_share", "c4", 8, False, None), ("c5_share", "c5", 8, False, None))
+            for label, wname, jw, near, streams_ in legs:
+                try:
+                    key, rec = side_leg(label, wname, jw, near, streams_, args.other_configs_seconds, local_rank, args.triangles, reuse_planes=d_depth[0])
+                    oc[key] = rec
+                except Exception as e:      # noqa: BLE001 - a side leg must not cost the bench line
+                    oc[label] = {"error": repr(e)}
+            oc["note"] = ("BASELINE.json configs 2, 4 (rank 0's share of the 8-GPU job: 64 x 720p streams, robot + two walls), 5 (rank 0's share: 8 distinct URDFs x 128 cameras) "
+                          "and config 3 with the right forearm 0.1-0.35 m in front of every lens; each timed for --other-configs-seconds after the headline's timed region "
+                          "through a default context (frames/s) and a one-lane context (tile kernel alone), 8 streams of the last step against the oracle")
+            out["other_configs"] = oc
         # ---- CPU baseline: the oracle port on this box's host cores, on a bounded sample of the same batch ----
-        if world == 1 and args.cpu_seconds > 0 and n > 0:
+        if args.cpu_seconds > 0 and n > 0:             # (rank 0 only: we are inside its branch)
             cores = host_threads
             # inputs: the first streams of the last batch (exactly what the GPU just filtered), prepared once
             n_in = min(n, 64)
@@ -676,6 +814,7 @@ def main():
     for c in ctxs:
         c.close()
     if dist is not None:
+        barrier()               # (ranks > 0 wait here while rank 0 runs its roofline leg and the CPU baseline)
         dist.destroy_process_group()
 
 

@@ -77,8 +77,10 @@ class RankShare:
 
     # ---- feeding a context --------------------------------------------------------------------
     def load(self, ctx, on_device_fk=True):
-        """Geometry (once), kinematic trees, intrinsics and model selection."""
+        """Geometry (once), kinematic trees, intrinsics and model selection.  (Loading the share into another context
+        starts its staging over: cameras and static extras go to the new context with the first stage() call.)"""
         base = 0
+        self._static_staged = self._cams_staged = False
         for g in self.groups:
             wl = g.variants[0]
             g.model_ids = []
@@ -123,12 +125,13 @@ class RankShare:
         self._cams_staged = True
         self._static_staged = True
 
-    def depth_host(self, variant):
-        """[n,H,W] float32 sensor planes of one variant (synthetic; shares larger than DEPTH_POOL reuse frames)."""
+    def depth_host(self, variant, pool_size=DEPTH_POOL, tiled=True):
+        """[n,H,W] float32 sensor planes of one variant (synthetic; shares larger than the pool reuse frames cyclically).
+        tiled=False returns only the pool's [min(n, pool_size),H,W] distinct planes (stream s sees plane s % len)."""
         wl = self.wl0
         gfirst = self.groups[0].global_first
-        pool = [wl.depth((gfirst + s) % 100003 + 7 * variant) for s in range(min(self.n, DEPTH_POOL))]
-        return np.stack([pool[s % len(pool)] for s in range(self.n)])
+        pool = [wl.depth((gfirst + s) % 100003 + 7 * variant) for s in range(min(self.n, pool_size))]
+        return np.stack([pool[s % len(pool)] for s in range(self.n)]) if tiled else np.stack(pool)
 
     # ---- the checker's view ---------------------------------------------------------------------
     def group_of(self, s):
@@ -168,7 +171,7 @@ class RankShare:
 
 
 def build(workload="c3", world=1, rank=0, streams=None, triangles=250000, variants=2, width=None, height=None,
-          urdfs=64, per_urdf=128, near_arm=False):
+          urdfs=64, per_urdf=128, near_arm=False, host_fk=True):
     """The share of `rank` in a `world`-GPU job of BASELINE config `workload`.  Seeds derive from GLOBAL stream and
     URDF numbers, so ranks never repeat each other's joint states and a share does not depend on how many ranks
     there are beyond which streams it holds."""
@@ -178,7 +181,7 @@ def build(workload="c3", world=1, rank=0, streams=None, triangles=250000, varian
         n = streams or 256
         sh = RankShare("C3", "c3", W, H, world, rank, "weak")
         gfirst = rank * n
-        vs = [WL.pr2_workload(n, W, H, triangles, first_state_seed=1000 + 100000 * v + 1000003 * rank, near_arm=near_arm) for v in range(variants)]
+        vs = [WL.pr2_workload(n, W, H, triangles, first_state_seed=1000 + 100000 * v + 1000003 * rank, near_arm=near_arm, host_fk=host_fk) for v in range(variants)]
         sh.groups = [Group(0, n, gfirst, vs, 0)]
         sh.n, sh.total_streams = n, n * world
         sh.near_arm = near_arm
@@ -189,7 +192,7 @@ def build(workload="c3", world=1, rank=0, streams=None, triangles=250000, varian
         if n <= 0:
             raise ValueError("c4: rank %d of %d has no streams (total %d)" % (rank, world, total))
         sh = RankShare("C4", "c4", W, H, world, rank, "strong")
-        vs = [WL.pr2_workload(n, W, H, triangles, first_state_seed=2000 + 100000 * v + first, walls=True, near_arm=near_arm) for v in range(variants)]
+        vs = [WL.pr2_workload(n, W, H, triangles, first_state_seed=2000 + 100000 * v + first, walls=True, near_arm=near_arm, host_fk=host_fk) for v in range(variants)]
         sh.groups = [Group(0, n, first, vs, 0)]
         sh.near_arm = near_arm
         sh.n, sh.total_streams = n, total
@@ -202,7 +205,7 @@ def build(workload="c3", world=1, rank=0, streams=None, triangles=250000, varian
         sh = RankShare("C5", "c5", W, H, world, rank, "strong")
         for i, m in enumerate(mine):
             budget = C5_BUDGETS[m % len(C5_BUDGETS)] if triangles == 250000 else max(triangles // (1 + m % 4), 500)
-            vs = [WL.pr2_workload(per, W, H, total_triangles=budget, seed=21 + m, first_state_seed=3000 + 1000 * m + 500 * v) for v in range(variants)]
+            vs = [WL.pr2_workload(per, W, H, total_triangles=budget, seed=21 + m, first_state_seed=3000 + 1000 * m + 500 * v, host_fk=host_fk) for v in range(variants)]
             sh.groups.append(Group(i * per, per, m * per, vs, m))
         sh.n, sh.total_streams = per * len(mine), per * urdfs
     else:

@@ -143,9 +143,12 @@ _robot_cache = {}
 
 
 def pr2_workload(n_streams, width=640, height=480, total_triangles=250000, seed=7, first_state_seed=1000,
-                 walls=False, near_arm=False):
+                 walls=False, near_arm=False, host_fk=True):
     """C2/C3 (and C4 with walls=True): synthetic PR2-like robot, one random joint state per stream,
-    camera = the head-mounted RGB optical frame, fixed frame = base_footprint."""
+    camera = the head-mounted RGB optical frame, fixed frame = base_footprint.
+    host_fk=False leaves out the host-side forward kinematics of every stream (3 ms each in Python): link_tf[0] and
+    cam_tf then stay zero, which is fine for callers that pose the robot with on-device forward kinematics and feed the
+    checker the matrices the device produced (bench.py's side legs)."""
     key = (total_triangles, seed)
     if key not in _robot_cache:
         _robot_cache[key] = synthetic.SyntheticRobot(total_triangles, seed)
@@ -171,8 +174,11 @@ def pr2_workload(n_streams, width=640, height=480, total_triangles=250000, seed=
         wall_rd = URDFRenderer(EXAMPLE_URDF, "/walls", robot.camera_frame, robot.fixed_frame, tf0, "visual", 1.0, [])
         w.models.append([r.draws for r in wall_rd.renderables_])
         wall_tf = np.zeros((n_streams, len(wall_rd.renderables_), 16))
-    for s in range(n_streams):
+    for s in range(n_streams if host_fk or walls else 0):
         q = joint_state(first_state_seed + s)
+        if not host_fk and s > 0:
+            wall_tf[s] = wall_tf[0]             # (the walls do not move: posed relative to the fixed frame)
+            continue
         fk = urdf.forward_kinematics(model, q)
         tf = urdf.StaticTransformProvider()
         tf.set_frames(fk, "/")
@@ -191,7 +197,7 @@ def pr2_workload(n_streams, width=640, height=480, total_triangles=250000, seed=
     w.offset_inv = np.tile(urdf.Transform().opengl_matrix(), (n_streams, 1))
     w.cam_tf = cam_tf
     w.meta = {"robot": "synthetic PR2-like", "links": len(robot.links), "links_with_geometry": L,
-              "triangles": w.n_triangles(), "vertices": w.n_vertices()}
+              "triangles": w.n_triangles(), "vertices": w.n_vertices(), "host_fk": bool(host_fk)}
     # on-device forward kinematics inputs: the tree once, joint positions per stream
     strip = lambda n: n[1:] if n.startswith("/") else n
     w.kinematics = urdf.kinematic_arrays(model, [strip(r.name) for r in rd.renderables_], [r.link_offset for r in rd.renderables_])

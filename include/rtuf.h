@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTUF_ABI_VERSION 5
+#define RTUF_ABI_VERSION 6
 
 typedef struct rtuf_context rtuf_context;
 
@@ -57,6 +57,12 @@ enum {
    * src/urdf_filter.cpp:591-596, and so does this library: there is nothing to switch.) */
   RTUF_FLAG_TWO_KERNEL      = 1u << 1,  /* rasteriser writes the z-surface to HBM and a separate compare kernel consumes it
                                            (default: compare fused into the tile kernel, the z-surface never leaves LDS)        */
+  RTUF_FLAG_STRICT_GRID     = 1u << 2,  /* ABI 6: every set-up launch takes the worst-case grid (every chunk visible in every
+                                           stream) instead of one sized from the previous batch's work lists, so a batch is never
+                                           run again because its work list outgrew the estimate (RTUF_STATUS_GRID_SHORT cannot
+                                           happen).  Costs empty workgroups: for consumers that read device planes before the
+                                           host has retired the batch (rtuf_batch_status_device) and want one reason less for a
+                                           provisional batch */
   RTUF_FLAG_DEFAULT = 0
   /* Any other bit makes rtuf_create / rtuf_set_params fail with RTUF_ERR_INVALID.  (The kernels' timing experiments
    * live only in a separate library built with -DRTUF_ABLATE for scripts/ablate_*.sh; the product has no such code.) */
@@ -97,7 +103,9 @@ typedef struct {
                                        rtuf_create. */
   uint32_t memory_limit_mb;         /* upper bound of the rasteriser's working set (tile bins of all lanes), MiB; 0 = a third of
                                        the free device memory at rtuf_finalize_models.  When the bins a scene needs would exceed it
-                                       the launch groups shrink (more, smaller launches) instead of the call failing. */
+                                       the launch groups shrink (more, smaller launches) instead of the call failing; when even
+                                       one stream's bins are larger the bins are grown all the same (up to what the device has)
+                                       and rtuf_stats.over_memory_limit says so. */
   uint32_t reserved[2];
 } rtuf_params;
 
@@ -288,8 +296,36 @@ void *rtuf_stream(rtuf_context *ctx);
 /* Makes `hip_stream` (a hipStream_t of the context's device; NULL = the legacy default stream) wait, on the device, for
  * every batch enqueued on this context so far: all raster lanes, all pipelines, and for host-plane batches their
  * downloads.  Does not block the host and does not retire anything (the batches' buffers stay owned by the library until
- * rtuf_wait_oldest / rtuf_sync).  ABI 5. */
+ * rtuf_wait_oldest / rtuf_sync).  ABI 5.
+ *
+ * WHAT THIS DOES NOT GUARANTEE: that the planes are final.  The rasteriser's working buffers (tile bins, clip list, many-tile
+ * list, the set-up grid) are sized from what earlier batches needed; whether a batch outgrew one of them is known only once
+ * its kernels have run, and the HOST acts on it when it retires the batch (rtuf_wait_oldest / rtuf_sync / the second-next
+ * filter call): it enlarges the buffer and runs the batch again into the same planes.  Until then the planes of such a batch
+ * hold pixels of a rasterisation that dropped triangles.  The reference's filter() returns with final pixels
+ * (src/urdf_filter.cpp:237, :729-735); so do all calls here that retire through the host.  A consumer that reads device
+ * planes behind this call, before the host has retired the batch, must check the batch's STATUS WORD on the device: */
 int rtuf_order_stream_after_batches(rtuf_context *ctx, void *hip_stream);
+/* ABI 6.  Device address of the status word (one uint32) of the batch the most recent rtuf_filter_batch* call enqueued
+ * (with pipelines: of the pipeline that took it).  The planes of that batch are final IF AND ONLY IF the word reads 0
+ * after the batch's kernels -- i.e. on a stream ordered behind them with rtuf_order_stream_after_batches.  Otherwise:
+ *   bits 0..15   launch groups of the batch that have not finished yet (non-zero only for a reader that is NOT ordered behind
+ *                the batch, or while the library runs the batch again)
+ *   RTUF_STATUS_*_OVERFLOW / _GRID_SHORT   a working buffer was too small: the planes are provisional, and the library will
+ *                run the batch again when the host retires it; the word reads 0 once that run has finished
+ *   RTUF_STATUS_UNCOVERED   mask-bits output only: the bits do not expand to the reference's planes (retiring the batch fails)
+ * The address belongs to one of the context's two batch slots: it is reused by the second-next batch, whose first kernel
+ * overwrites the word -- read it in the same stream-ordered work that reads the planes.  rtuf_stats.batch_status is the
+ * host's mirror for the batch retired last (what its first run left in the word). */
+enum {
+  RTUF_STATUS_PENDING_MASK  = 0xffffu,
+  RTUF_STATUS_BIN_OVERFLOW  = 1u << 16,   /* a (stream, tile) bin held more records or fragments than its capacity      */
+  RTUF_STATUS_CLIP_OVERFLOW = 1u << 17,   /* more triangles crossed a frustum plane than the clip list holds             */
+  RTUF_STATUS_LIST_OVERFLOW = 1u << 18,   /* more many-tile records than their list holds                               */
+  RTUF_STATUS_GRID_SHORT    = 1u << 19,   /* a launch group's work list outgrew the set-up grid sized from the last batch */
+  RTUF_STATUS_UNCOVERED     = 1u << 20    /* rtuf_filter_batch*_bits*: a pixel no fragment reached                       */
+};
+int rtuf_batch_status_device(rtuf_context *ctx, const uint32_t **d_status);
 
 /* Counters of the last batch and kernel timings measured with HIP events on the context's
  * stream (replaces the wall-clock statistics of src/urdf_filter.cpp:239-266). */
@@ -331,6 +367,12 @@ typedef struct {
                                        side at rtuf_create (with one lane: the lane's and the pose stage's).  0: every stream the
                                        runtime handed out shared a hardware queue with one of them -- everything then works, one
                                        kernel after the other; raise GPU_MAX_HW_QUEUES (HIP runtime, default 4)  */
+  /* ABI 6 */
+  uint32_t batch_status;            /* RTUF_STATUS_* bits the FIRST run of the batch retired last left in its device status word
+                                       (0: its planes were final as soon as its kernels had run)                            */
+  uint32_t batch_reruns;            /* times that batch (and everything in flight behind it) was run again before it was retired */
+  uint32_t over_memory_limit;       /* 1: the tile bins exceed rtuf_params.memory_limit_mb (or the automatic third of the free
+                                       memory): one stream's bins alone are larger, and launch groups cannot shrink below one   */
   uint32_t reserved1;
 } rtuf_stats;
 int rtuf_get_stats(rtuf_context *ctx, rtuf_stats *out);

@@ -16,7 +16,11 @@ RTUF_OK = 0
 RTUF_ERR_NO_DEVICE = -2
 OP_NONE, OP_SCALE, OP_TRANSLATE = 0, 1, 2
 FLAG_TWO_KERNEL = 2
-ABI_VERSION = 5
+FLAG_STRICT_GRID = 4
+ABI_VERSION = 6
+# rtuf_batch_status_device: bits of a batch slot's device status word (0 = the planes are final)
+STATUS_PENDING_MASK = 0xffff
+STATUS_BIN_OVERFLOW, STATUS_CLIP_OVERFLOW, STATUS_LIST_OVERFLOW, STATUS_GRID_SHORT, STATUS_UNCOVERED = 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20
 
 #: every symbol include/rtuf.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -28,7 +32,7 @@ SYMBOLS = [
     "rtuf_stream", "rtuf_get_stats", "rtuf_enable_timing", "rtuf_debug_read_zsurface",
     "rtuf_filter_batch_async", "rtuf_filter_batch_u16_async", "rtuf_wait_oldest", "rtuf_host_alloc", "rtuf_host_free",
     "rtuf_mask_bits_words", "rtuf_filter_batch_bits_async", "rtuf_filter_batch_bits_u16_async", "rtuf_filter_batch_device_bits",
-    "rtuf_filter_batch_device_bits_u16", "rtuf_expand_mask_bits", "rtuf_order_stream_after_batches",
+    "rtuf_filter_batch_device_bits_u16", "rtuf_expand_mask_bits", "rtuf_order_stream_after_batches", "rtuf_batch_status_device",
 ]
 
 
@@ -57,7 +61,9 @@ class Stats(ctypes.Structure):
                 ("raster_atomics", ctypes.c_uint64), ("drawn_pixels", ctypes.c_uint64),
                 ("raster_lanes", ctypes.c_uint32), ("launch_group", ctypes.c_uint32), ("groups_last_batch", ctypes.c_uint32),
                 ("graphs_enabled", ctypes.c_uint32), ("graph_hits", ctypes.c_uint64), ("graph_misses", ctypes.c_uint64),
-                ("lanes_side_by_side", ctypes.c_uint32), ("reserved1", ctypes.c_uint32)]
+                ("lanes_side_by_side", ctypes.c_uint32),
+                ("batch_status", ctypes.c_uint32), ("batch_reruns", ctypes.c_uint32), ("over_memory_limit", ctypes.c_uint32),
+                ("reserved1", ctypes.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
@@ -163,6 +169,7 @@ def load_library(path=None):
     lib.rtuf_filter_batch_device_bits_u16.argtypes = [vp, ci, vp, vp]
     lib.rtuf_expand_mask_bits.argtypes = [vp, ci, vp, ci, ci, ctypes.c_float, vp, vp]
     lib.rtuf_order_stream_after_batches.argtypes = [vp, vp]
+    lib.rtuf_batch_status_device.argtypes = [vp, ctypes.POINTER(vp)]
     if path is None:
         _lib = lib
     return lib
@@ -410,6 +417,13 @@ class Context:
         """Makes `hip_stream` (an int / c_void_p hipStream_t; None = the legacy default stream) wait on the device for every
         batch enqueued so far, whatever the number of lanes and pipelines."""
         self._check(self._lib.rtuf_order_stream_after_batches(self._h, ctypes.c_void_p(hip_stream) if hip_stream else None))
+
+    def batch_status_device(self):
+        """Device address (int) of the status word of the batch the last filter call enqueued: 0 there, read on a stream
+        ordered behind the batch (order_stream_after_batches), means its planes are final; STATUS_* bits say why not."""
+        p = ctypes.c_void_p()
+        self._check(self._lib.rtuf_batch_status_device(self._h, ctypes.byref(p)))
+        return p.value
 
     def enable_timing(self, on=True):
         # True/1: every stage; 2: only around the tile (and compare) kernel; False/0: off

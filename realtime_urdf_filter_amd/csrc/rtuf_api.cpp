@@ -59,7 +59,7 @@ struct HostModel { std::vector<HostLink> links; int link_base = 0; Kinematics ki
 
 char g_create_error[512] = "";
 
-constexpr uint32_t kKnownFlags = RTUF_FLAG_TWO_KERNEL;
+constexpr uint32_t kKnownFlags = RTUF_FLAG_TWO_KERNEL | RTUF_FLAG_STRICT_GRID;
 inline bool flags_valid(uint32_t flags)
 {
 #ifdef RTUF_ABLATE
@@ -140,6 +140,9 @@ struct rtuf_context {
   uint32_t capacity = 0, fcapacity = 0, clip_capacity = 0;
   uint32_t big_capacity = 0;           // many-tile list, per counter shard
   uint32_t items_hint = 0; int items_hint_streams = 0;      // longest work list of the last batch's groups, and their size
+  std::vector<uint32_t> group_items;   // work-list length of every launch group of the last retired batch ...
+  std::vector<int> group_streams;      // ... and its streams: a group of the same index and size takes its own list length as the hint
+  bool force_worst_grid = false;       // re-runs after a set-up grid that was too short: the worst-case grid, which cannot be
   size_t memory_budget = 0;            // upper bound of the lanes' tile bins (rtuf_params.memory_limit_mb or a third of the free memory)
   // every device allocation of the context goes through dev_alloc / dev_free: rtuf_stats.device_bytes is their sum
   std::unordered_map<void*, size_t> dev_blocks;
@@ -172,6 +175,7 @@ struct rtuf_context {
     Camera* d_cams = nullptr; double* d_link_tf = nullptr;
     float* d_mvp = nullptr; BgInfo* d_bg = nullptr;
     Counters* d_counters = nullptr;          // [max_groups]
+    uint32_t* d_status = nullptr;            // the slot's status word (kStatus* in rtuf_device.h; rtuf_batch_status_device)
     bool dirty_cams = true, dirty_link_tf = true;
     int uploaded_streams = 0;
     hipEvent_t posed = nullptr;              // recorded on the side stream after the pose stage
@@ -228,6 +232,9 @@ struct rtuf_context {
   std::deque<int> order;
 
   rtuf_stats stats{};
+#ifdef RTUF_LANECOUNT
+  unsigned long long lane_slots[kLaneLoops] = {}, lane_live[kLaneLoops] = {};      // of the last retired batch (instrumented build)
+#endif
   int timing = 0;            // 0 off, 1 every stage, 2 only around the tile (and compare) kernel, 3 = 2 on every fourth batch
   uint32_t timing_seq = 0;
   double acc_ms[6] = {0, 0, 0, 0, 0, 0};  // sums of ms_pose .. ms_total, ms_clip over the timed batches
@@ -348,10 +355,12 @@ static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
   size_t free_b = 0, total_b = 0;
   HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
   const size_t held = (size_t)c->n_lanes * lane_bins_bytes(c, c->group, c->capacity, c->fcapacity);
-  size_t budget = (size_t)((double)(free_b + held) * 0.9);
-  if (c->params.memory_limit_mb) budget = std::min(budget, (size_t)c->params.memory_limit_mb << 20);
+  // (the context's limit -- rtuf_params.memory_limit_mb, or the third of the free memory taken at rtuf_finalize_models -- and
+  // never more than the device can give)
+  const size_t budget = std::min((size_t)((double)(free_b + held) * 0.9), c->memory_budget);
   int G = c->group;
   while (G > 1 && (size_t)c->n_lanes * lane_bins_bytes(c, G, cap, fcap) > budget) G = (G + 1) / 2;
+  if ((size_t)c->n_lanes * lane_bins_bytes(c, G, cap, fcap) > c->memory_budget) c->stats.over_memory_limit = 1u;      // (G == 1: one stream's bins alone)
   for (;;) {
     hipError_t e = hipSuccess;
     for (int l = 0; l < c->n_lanes && e == hipSuccess; l++) {
@@ -601,7 +610,7 @@ static void free_frame_buffers(rtuf_context* c)
   hipSetDevice(c->device);
   auto hfree = [](auto*& p) { if (p) { hipHostFree(p); p = nullptr; } };
   dev_free(c, c->d_model_mask);
-  for (auto& b : c->batch) { dev_free(c, b.d_cams); dev_free(c, b.d_link_tf); dev_free(c, b.d_mvp); dev_free(c, b.d_bg); dev_free(c, b.d_counters); }
+  for (auto& b : c->batch) { dev_free(c, b.d_cams); dev_free(c, b.d_link_tf); dev_free(c, b.d_mvp); dev_free(c, b.d_bg); dev_free(c, b.d_counters); dev_free(c, b.d_status); }
   for (auto& ln : c->lane) {
     dev_free(c, ln.d_bins); dev_free(c, ln.d_bin_hdr); dev_free(c, ln.d_fbins); dev_free(c, ln.d_fbin_count); dev_free(c, ln.d_clip_list);
     dev_free(c, ln.d_clip_spill); dev_free(c, ln.d_big_list); dev_free(c, ln.d_zsurface);
@@ -755,6 +764,8 @@ static int alloc_frame_buffers(rtuf_context* c)
     HIP_TRY(c, dev_alloc(c, &b.d_link_tf, sizeof(double) * 16 * L * N));
     HIP_TRY(c, dev_alloc(c, &b.d_mvp, sizeof(float) * 16 * (size_t)(c->n_draws + 1) * N));
     HIP_TRY(c, dev_alloc(c, &b.d_bg, sizeof(BgInfo) * N));
+    HIP_TRY(c, dev_alloc(c, &b.d_status, 64));
+    HIP_TRY(c, hipMemset(b.d_status, 0, 64));
     b.dirty_cams = b.dirty_link_tf = true; b.uploaded_streams = 0;
     if (!b.posed) HIP_TRY(c, hipEventCreateWithFlags(&b.posed, hipEventDisableTiming));
   }
@@ -1351,6 +1362,7 @@ enum { kEvStart = 0, kEvPoseEnd = 1, kEvLaneEnd = 2, kEvGroup0 = 2 + kMaxLanes, 
 static int issue_plan(rtuf_context* c, rtuf_context::Batch& b, const BatchPlan& plan, hipStream_t sp, bool worst_case_grid)
 {
   const bool two = (c->params.flags & RTUF_FLAG_TWO_KERNEL) != 0;
+  worst_case_grid = worst_case_grid || c->force_worst_grid || (c->params.flags & RTUF_FLAG_STRICT_GRID) != 0;
   auto mark = [&](size_t i, hipStream_t s) { hipEventRecord(get_event(b, i), s); };
   if (b.timing) (void)get_event(b, kEvGroup0 + kEvPerGroup * plan.groups.size() - 1);      // (all of the batch's events exist)
   if (b.timing == 1) mark(kEvStart, sp);
@@ -1380,9 +1392,15 @@ static int issue_plan(rtuf_context* c, rtuf_context::Batch& b, const BatchPlan& 
     if (b.timing >= 2) mark(e0, st);                 // (after the wait for the pose stage: set-up time only)
     // The set-up grid is sized from the previous batch's work lists (scaled to this group's streams); the group's list
     // length comes back with its counters, and a batch whose list outgrew the grid is run again (retire_oldest).
+    // A group of the same index and size as in the last retired batch takes ITS OWN list length (work lists are not linear in
+    // the streams: every chunk rounds its visible streams up to whole items, and visibility differs per stream -- a smaller
+    // last group can need more than its share of the largest group's list); any other group the longest list scaled to its
+    // streams plus one item per chunk for that rounding.
     uint32_t hint = 0;
-    if (!worst_case_grid && c->items_hint && c->items_hint_streams > 0)
-      hint = (uint32_t)(((uint64_t)c->items_hint * (uint64_t)gr.sa.group_size + (uint64_t)c->items_hint_streams - 1) / (uint64_t)c->items_hint_streams);
+    if (!worst_case_grid && c->items_hint && c->items_hint_streams > 0) {
+      if (g < c->group_items.size() && c->group_streams[g] == gr.sa.group_size) hint = std::max(c->group_items[g], 1u);
+      else hint = (uint32_t)(((uint64_t)c->items_hint * (uint64_t)gr.sa.group_size + (uint64_t)c->items_hint_streams - 1) / (uint64_t)c->items_hint_streams) + (uint32_t)c->n_chunks;
+    }
     const uint32_t grid = launch_setup(gr.sa, hint, false, st);
     b.setup_grid[g] = worst_case_grid ? 0xffffffffu : grid;
     if (b.timing >= 2) mark(e0 + 1, st);
@@ -1395,10 +1413,11 @@ static int issue_plan(rtuf_context* c, rtuf_context::Batch& b, const BatchPlan& 
   }
   // every lane publishes the counter blocks of its own groups
   const int ng = (int)plan.groups.size();
+  const PublishLimits lim = {c->capacity, c->fcapacity, c->big_capacity};
   for (int l = 0; l < c->n_lanes; l++) {
     if (!(b.lanes_used >> l & 1u)) continue;
-    if (ng == 1) launch_publish_counters(b.d_counters, b.h_counters, 0, 1, 1, c->lane[l].stream);
-    else launch_publish_counters(b.d_counters, b.h_counters, l, c->n_lanes, (ng - l + c->n_lanes - 1) / c->n_lanes, c->lane[l].stream);
+    if (ng == 1) launch_publish_counters(b.d_counters, b.h_counters, 0, 1, 1, b.d_status, lim, c->lane[l].stream);
+    else launch_publish_counters(b.d_counters, b.h_counters, l, c->n_lanes, (ng - l + c->n_lanes - 1) / c->n_lanes, b.d_status, lim, c->lane[l].stream);
     if (b.timing == 1) mark(kEvLaneEnd + l, c->lane[l].stream);
   }
   return RTUF_OK;
@@ -1497,7 +1516,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
   // to_linear_depth's constants exactly as the shader evaluates them (include/shaders/urdf_filter.frag:14-17), in float
   const float zn = c->params.near_plane, zf = c->params.far_plane;
   const float sc_num = (zn * zf) / (zn - zf), sc_off = zf / (zf - zn);
-  pa.bg = b.d_bg; pa.counters = b.d_counters; pa.n_counters = n_groups;
+  pa.bg = b.d_bg; pa.counters = b.d_counters; pa.n_counters = n_groups; pa.status = b.d_status;
   pa.sc_num = sc_num; pa.sc_off = sc_off; pa.max_diff = c->params.depth_distance_threshold;
   pa.n_streams = n; pa.n_draws = c->n_draws; pa.n_links = (int)L; pa.z_far = c->params.far_plane;
   pa.width = c->width; pa.height = c->height;
@@ -1663,6 +1682,12 @@ static int retire_oldest(rtuf_context* c)
                       max_items = 0; } k;
     bool list_over = false;                    // some group's set-up grid was sized too small for its work list
     int group_streams = 0;
+#ifdef RTUF_LANECOUNT
+    for (int i = 0; i < kLaneLoops; i++) c->lane_slots[i] = c->lane_live[i] = 0;
+    for (int g = 0; g < b.n_groups; g++)
+      for (int sh = 0; sh < kCounterShards; sh++)
+        for (int i = 0; i < kLaneLoops; i++) { c->lane_slots[i] += b.h_counters[g].shard[sh].lane_slots[i]; c->lane_live[i] += b.h_counters[g].shard[sh].lane_live[i]; }
+#endif
     for (int g = 0; g < b.n_groups; g++) {
       const Counters& cn = b.h_counters[g];
       k.work_items += cn.work.n_items;
@@ -1681,6 +1706,11 @@ static int retire_oldest(rtuf_context* c)
     group_streams = (b.n + b.n_groups - 1) / std::max(b.n_groups, 1);
     c->items_hint = k.max_items;               // sizes the next batches' set-up grids (the longest list of this batch's groups ...
     c->items_hint_streams = group_streams;     // ... of so many streams each)
+    c->group_items.resize((size_t)b.n_groups); c->group_streams.resize((size_t)b.n_groups);
+    for (int g = 0; g < b.n_groups; g++) {
+      c->group_items[(size_t)g] = b.h_counters[g].work.n_items;
+      c->group_streams[(size_t)g] = std::min(group_streams, b.n - g * group_streams);
+    }
     c->stats.triangles_submitted = (uint64_t)c->n_tris * (uint64_t)b.n;
     c->stats.triangles_binned = k.tris_binned;
     c->stats.bin_entries = k.bin_entries;
@@ -1698,6 +1728,12 @@ static int retire_oldest(rtuf_context* c)
     const bool clip_over = k.clip_overflow != 0;
     const bool big_over = k.max_big_fill > c->big_capacity;
     if (list_over) c->stats.regrowths++;
+    // host mirror of the device status word (rtuf_batch_status_device): what the FIRST run of the batch being retired left there
+    if (attempt == 0) {
+      c->stats.batch_status = (bin_over ? kStatusBinOverflow : 0u) | (clip_over ? kStatusClipOverflow : 0u) | (big_over ? kStatusBigOverflow : 0u) |
+                              (list_over ? kStatusGridShort : 0u) | (k.uncovered ? kStatusUncovered : 0u);
+      c->stats.batch_reruns = 0;
+    }
     if (!bin_over && !clip_over && !list_over && !big_over) {
       if (b.host_io) HIP_TRY(c, hipEventSynchronize(b.downloaded));
       if (b.timing && b.events.size() >= (size_t)(kEvGroup0 + kEvPerGroup * b.n_groups)) {
@@ -1775,12 +1811,17 @@ static int retire_oldest(rtuf_context* c)
       launch_init_headers(c->lane[l].d_bin_hdr, (size_t)c->group * tiles, c->lane[l].stream);
       HIP_TRY(c, hipMemsetAsync(c->lane[l].d_fbin_count, 0, (size_t)c->group * tiles * sizeof(uint32_t), c->lane[l].stream));
     }
+    // (a grid that was too short: the re-run takes the worst-case grid, which no list can outgrow -- the estimate that failed
+    // once would size the same grid again)
+    c->force_worst_grid = list_over;
+    c->stats.batch_reruns++;
     for (int i = 0; i < c->pending; i++) {
       rtuf_context::Batch& r = c->batch[(c->oldest + i) % kMaxInflight];
       int rc = enqueue_batch(c, r, true);
       if (rc == RTUF_OK && r.host_io) rc = enqueue_download(c, r);
-      if (rc != RTUF_OK) { for (auto& o : c->batch) o.active = false; c->pending = 0; return rc; }
+      if (rc != RTUF_OK) { c->force_worst_grid = false; for (auto& o : c->batch) o.active = false; c->pending = 0; return rc; }
     }
+    c->force_worst_grid = false;
   }
   for (auto& o : c->batch) o.active = false;
   c->pending = 0;
@@ -1910,6 +1951,15 @@ int rtuf_sync(rtuf_context* c)
 }
 
 void* rtuf_stream(rtuf_context* c) { return (c && c->kids.empty() && c->n_lanes == 1) ? (void*)c->lane[0].stream : nullptr; }
+
+int rtuf_batch_status_device(rtuf_context* c, const uint32_t** d_status)
+{
+  if (!c || !d_status) return RTUF_ERR_INVALID;
+  if (!c->kids.empty()) c = c->kids[c->last_kid];
+  if (!c->finalized) return c->fail(RTUF_ERR_STATE, "call rtuf_finalize_models first");
+  *d_status = c->batch[c->last_slot].d_status;
+  return RTUF_OK;
+}
 
 int rtuf_order_stream_after_batches(rtuf_context* c, void* hip_stream)
 {
@@ -2136,6 +2186,17 @@ int rtuf_get_stats(rtuf_context* c, rtuf_stats* out)
   out->lanes_side_by_side = c->lanes_share_queue ? 0u : 1u;
   return RTUF_OK;
 }
+
+#ifdef RTUF_LANECOUNT
+// instrumented builds only (scripts/lane_util.sh): lane slots issued / lanes live per instrumented loop, last retired batch
+int rtuf_debug_lane_counts(rtuf_context* c, unsigned long long* slots, unsigned long long* live, int n)
+{
+  if (!c || !slots || !live) return RTUF_ERR_INVALID;
+  if (!c->kids.empty()) c = c->kids[c->last_kid];
+  for (int i = 0; i < n && i < kLaneLoops; i++) { slots[i] = c->lane_slots[i]; live[i] = c->lane_live[i]; }
+  return kLaneLoops;
+}
+#endif
 
 int rtuf_enable_timing(rtuf_context* c, int on)
 {

@@ -168,6 +168,7 @@ struct alignas(16) ClipItem {   // one triangle that crosses a frustum plane; se
 #define RTUF_COUNTER_SHARDS 64
 #endif
 constexpr int kCounterShards = RTUF_COUNTER_SHARDS;
+constexpr int kLaneLoops = 24;           // instrumented loops of a -DRTUF_LANECOUNT build
 struct alignas(128) CounterShard {
   unsigned long long tris_binned;
   unsigned long long bin_entries;
@@ -186,9 +187,22 @@ struct alignas(128) CounterShard {
   unsigned long long raster_atomics;   // RTUF_COUNT builds only: depth tests issued by the tile kernel (LDS atomics)
   unsigned long long drawn_pixels;     // RTUF_COUNT builds only: pixels whose final key is not the background's
   unsigned int pad[10];
+#ifdef RTUF_LANECOUNT
+  // Lane-utilisation builds (scripts/lane_util.sh; never the product): per instrumented loop the lane slots its trips
+  // issued (64 per wave and trip) and the lanes that were live in them, see kLane* in rtuf_kernels.hip.
+  unsigned long long lane_slots[kLaneLoops];
+  unsigned long long lane_live[kLaneLoops];
+#endif
 };
+#ifndef RTUF_LANECOUNT
 static_assert(sizeof(CounterShard) == 128, "CounterShard must be one 128-byte line");
-struct alignas(128) WorkCount { unsigned int n_items; unsigned int pad[31]; };
+#endif
+struct alignas(128) WorkCount {
+  unsigned int n_items;         // length of the launch group's work list (cull_kernel)
+  unsigned int grid;            // work items the group's set-up launch covered (written by the set-up kernel itself: the batch's
+                                // last kernel compares the two on the device, see BatchStatus)
+  unsigned int pad[30];
+};
 struct Counters { CounterShard shard[kCounterShards]; WorkCount work; };
 
 // One set-up workgroup's job: a chunk and up to kStreamsPerBlock stream slots (of the in-flight
@@ -226,6 +240,17 @@ struct alignas(16) BgInfo {
   uint32_t z24;                 // its 24-bit depth-buffer value
 };
 
+// Device-resident status word of a batch slot (rtuf_batch_status_device): the low 16 bits count the launch groups of the batch
+// that have not finished yet (set by pose_kernel, the first kernel of a batch; every group's publish_counters workgroup, the
+// last kernel of its lane, takes one off), the bits above say why the batch's planes are NOT final -- a working buffer was too
+// small, and the host will run the batch again when it retires it.  0 <=> every group finished and nothing overflowed.
+constexpr uint32_t kStatusPendingMask = 0xffffu;
+constexpr uint32_t kStatusBinOverflow = 1u << 16;     // a record or fragment bin was fuller than its capacity
+constexpr uint32_t kStatusClipOverflow = 1u << 17;    // the clip list was too short
+constexpr uint32_t kStatusBigOverflow = 1u << 18;     // the many-tile list was too short
+constexpr uint32_t kStatusGridShort = 1u << 19;       // the set-up grid did not cover the work list
+constexpr uint32_t kStatusUncovered = 1u << 20;       // mask-bits output: a pixel no fragment reached (retiring the batch fails)
+
 // kernel argument blocks (passed by value) and host-callable launchers (rtuf_kernels.hip)
 struct PoseArgs {
   const Camera* cams;        // [n_streams]
@@ -236,6 +261,7 @@ struct PoseArgs {
   float sc_num, sc_off, max_diff;   // to_linear_depth constants (host-computed, see shade_consts) and the threshold
   Counters* counters;        // [n_counters]: one block per launch group of the batch, zeroed by this kernel
   int n_counters;
+  uint32_t* status;          // the batch slot's status word: set to n_counters (launch groups still to finish) by this kernel
   int n_streams, n_draws, n_links;
   float z_far;
   int width, height;
@@ -331,7 +357,9 @@ size_t clip_spill_bytes(uint32_t clip_capacity);
 void launch_bigrec(const SetupArgs& a, bool cover_pass, hipStream_t st);      // cover_pass: bigrec_kernel<0> runs first (and launch_tile gets the same flag)
 void launch_init_headers(BinHeader* hdr, size_t n_bins, hipStream_t st);
 // copies the counter blocks first, first + stride, ... (count of them) of a batch to the same places of the pinned host array
-void launch_publish_counters(const Counters* src, Counters* host_dst, int first, int stride, int count, hipStream_t st);
+// ... and folds what they say about overflows into the batch's status word (PublishLimits: the capacities they are held against)
+struct PublishLimits { uint32_t capacity, fcapacity, big_capacity; };
+void launch_publish_counters(const Counters* src, Counters* host_dst, int first, int stride, int count, uint32_t* status, PublishLimits lim, hipStream_t st);
 void launch_tile(const TileArgs& a, bool two_kernel, bool cover_pass, hipStream_t st);   // a.io_u16 selects the 16UC1 variant
 void launch_compare(const CompareArgs& a, hipStream_t st);
 void launch_spin(unsigned long long ticks, hipStream_t st);      // a one-wave kernel that idles for `ticks` of the 100 MHz clock

@@ -30,6 +30,60 @@
 
 namespace rtuf {
 
+// Lane-utilisation builds (-DRTUF_LANECOUNT, scripts/lane_util.sh; never the product): every instrumented loop counts, per
+// trip of a wave, 64 lane slots and the lanes for which `pred` holds (of those the hardware has active at that point) in two
+// LDS words per workgroup, summed into the batch's counters when the workgroup ends.  In the product the macros are empty.
+enum {
+  kLaneTileLoad = 0,      // tile kernel: a wave's load + unpack of up to 64 bin records (live: lanes that hold one)
+  kLaneWalkTrip,          // lane-per-triangle walk: quad trips (live: lanes whose box still has quads)
+  kLaneWalkFrag,          // ... depth-test bodies the walk executed (live: lanes whose candidate is covered)
+  kLaneQuarterTrip,       // quarter-wave walk: pair trips
+  kLaneQuarterFrag,
+  kLaneWaveTrip,          // whole-wave walk of one record (huge boxes that stay with their wave)
+  kLaneWaveFrag,
+  kLaneParkTrip,          // workgroup-cooperative walks of the parked records
+  kLaneParkFrag,
+  kLaneFragList,          // fragment list: one depth test per 8-byte fragment
+  kLaneResolve,           // resolve passes (4 pixels per lane)
+  kLaneSetupVert,         // set-up kernel: phase 1, a vertex per lane
+  kLaneSetupTri,          // phase 2, a triangle per lane
+  kLaneSetupSmall,        // phase 3a/b trips: coverage of the <= 4x4 boxes (live: lanes with a triangle)
+  kLaneSetupSmallHit,     // ... of which cover a pixel centre (z plane + emission)
+  kLaneSetupFragStore,    // fragment emission: per-lane store loop (trips until the lane with most covered pixels is done)
+  kLaneSetupFragGroup,    // fragment emission: group-finding trips (one per distinct bin of the wave)
+  kLaneSetupRec,          // phase 3c trips: set-up of the records (live: lanes with a triangle)
+  kLaneSetupRecHit,       // ... of which survive orientation / bounding
+  kLaneSetupRecTile,      // record emission: trips over the tiles a record touches
+  kLaneSetupRecGroup,     // record emission: group-finding trips
+  kLaneCount
+};
+static_assert(kLaneCount <= kLaneLoops, "CounterShard holds kLaneLoops pairs");
+#ifdef RTUF_LANECOUNT
+__device__ __forceinline__ uint32_t* lane_words() { __shared__ uint32_t s_lw[2 * kLaneLoops]; return s_lw; }
+#define RTUF_LANES(id, pred)                                                                                          \
+  do {                                                                                                                \
+    const unsigned long long act_ = __ballot(true), m_ = __ballot(pred);                                              \
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)act_) - 1) {                                                    \
+      atomicAdd(&lane_words()[2 * (id)], 64u);                                                                        \
+      atomicAdd(&lane_words()[2 * (id) + 1], (uint32_t)__popcll(m_));                                                 \
+    }                                                                                                                 \
+  } while (0)
+#define RTUF_LANES_INIT()                                                                                             \
+  do { for (int i_ = threadIdx.x; i_ < 2 * kLaneLoops; i_ += blockDim.x) lane_words()[i_] = 0u; __syncthreads(); } while (0)
+#define RTUF_LANES_FLUSH(shard)                                                                                       \
+  do {                                                                                                                \
+    __syncthreads();                                                                                                  \
+    if ((int)threadIdx.x < kLaneLoops && lane_words()[2 * threadIdx.x]) {                                             \
+      atomicAdd(&(shard).lane_slots[threadIdx.x], (unsigned long long)lane_words()[2 * threadIdx.x]);                 \
+      atomicAdd(&(shard).lane_live[threadIdx.x], (unsigned long long)lane_words()[2 * threadIdx.x + 1]);              \
+    }                                                                                                                 \
+  } while (0)
+#else
+#define RTUF_LANES(id, pred) ((void)0)
+#define RTUF_LANES_INIT() ((void)0)
+#define RTUF_LANES_FLUSH(shard) ((void)0)
+#endif
+
 // ---------------------------------------------------------------------------------------
 // float32 matrix stack (GL semantics: every glMultMatrixd rounds its argument to float and
 // multiplies in float32, products accumulated left to right, no fused multiply-add)
@@ -124,6 +178,8 @@ __global__ void pose_kernel(PoseArgs a)
     uint32_t* w = reinterpret_cast<uint32_t*>(a.counters + cb);
     for (int i = threadIdx.x; i < (int)(sizeof(Counters) / 4); i += blockDim.x) w[i] = 0u;
   }
+  // ... and says so in the batch slot's status word: this many launch groups have not finished (see kStatus* in rtuf_device.h)
+  if (gid == 0) *a.status = (uint32_t)a.n_counters;
   if (gid >= a.n_streams * per) return;
   const int s = gid / per, d = gid - s * per;
   const Camera& cam = a.cams[s];
@@ -635,6 +691,7 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int sha
     unsigned long long pending = __ballot(act);
     if (!pending) break;
     const int bin = act ? 2 * (__mul24(slot, tiles) + __mul24(ty, a.tiles_x) + tx) + cls : -1;      // (bin, class) = one counter
+    RTUF_LANES(kLaneSetupRecTile, act);
     if (++tx > tx1) { tx = tx0; ty++; }
     unsigned long long mymask = 0;
     int myleader = lane;
@@ -642,6 +699,7 @@ __device__ __forceinline__ uint32_t emit_record_wave(const SetupArgs& a, int sha
       const int leader = __ffsll((long long)pending) - 1;
       const int lbin = __builtin_amdgcn_readlane(bin, leader);      // leader is wave-uniform: no LDS crossbar round trip
       const unsigned long long m = __ballot(act && bin == lbin);
+      RTUF_LANES(kLaneSetupRecGroup, act && bin == lbin);
       if (act && bin == lbin) { mymask = m; myleader = leader; }
       pending &= ~m;
     }
@@ -756,6 +814,7 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
       const int lbin = __builtin_amdgcn_readlane(bin, leader);      // leader is wave-uniform: no LDS crossbar round trip
       const bool mine = act && bin == lbin;
       const unsigned long long m = __ballot(mine);
+      RTUF_LANES(kLaneSetupFragGroup, mine);
       if (mine) { mymask = m; myleader = leader; }
       pending &= ~m;
     }
@@ -773,6 +832,7 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
       const int lbase = (by0 % kTileH) * kTileW + (bx0 % kTileW);
       uint32_t m = mask;
       while (m) {
+        RTUF_LANES(kLaneSetupFragStore, true);
         const int k = __ffs((int)m) - 1;
         m &= m - 1;
         const int px = bx0 + (k & 3), py = by0 + (k >> 2);
@@ -921,10 +981,14 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
   CounterShard& shard = a.counters->shard[shard_id];
   const float sx = 0.5f * (float)a.width, sy = 0.5f * (float)a.height;
   uint32_t binned = 0, entries = 0, nfrag = 0;
+  RTUF_LANES_INIT();
   // launch_setup sizes the main grid from the previous batch's work-list length: one item per
   // workgroup (STRIDED = false, no loop: keeps the register count at 8 waves/SIMD).  Items beyond that
   // grid, if the list grew, are swept by a small strided launch of the same code.
   const uint32_t n_items = a.counters->work.n_items;
+  // (what this launch covers, for the batch's status word: the main grid takes items [0, gridDim.x); a strided sweep behind
+  // it takes everything)
+  if (blockIdx.x == 0 && tid == 0) a.counters->work.grid = STRIDED ? 0xffffffffu : gridDim.x;
   for (uint32_t item_id = item_base + blockIdx.x; item_id < n_items; item_id += gridDim.x) {
   if (tid == 3) s_nlist = 0;
   if (tid == 4) s_ntiny = 0;
@@ -981,6 +1045,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
     if (!s_on[k]) continue;                              // uniform per workgroup
     // (phase 1 of all three streams before ONE barrier, then phase 2 of all three: measured, no difference)
     // phase 1
+    RTUF_LANES(kLaneSetupVert, have_vert);
     if (have_vert) {
       float M[16];
 #pragma unroll
@@ -998,6 +1063,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
     __syncthreads();
     // phase 2
     bool survive = false, needs_clip = false, tiny = false, small = false;
+    RTUF_LANES(kLaneSetupTri, have_tri);
     if (have_tri) {
       const int2 p0 = s_snap[k][i0], p1 = s_snap[k][i1], p2 = s_snap[k][i2];
       const unsigned m0 = (unsigned)p0.y & 63u, m1 = (unsigned)p1.y & 63u, m2 = (unsigned)p2.y & 63u;
@@ -1081,6 +1147,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
       uint32_t order = 0;
       bool near = false;
       uint32_t ent = 0;
+      RTUF_LANES(kLaneSetupSmall, j < ncls);
       if (j < ncls) {
         Win v0, v1, v2;
         const uint32_t e = s_list2[cls == 0 ? kStreamsPerBlock * kBlock - 1 - j : j];
@@ -1113,6 +1180,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
         s_list[atomicAdd(&s_nlist, 1u)] = (uint16_t)ent;
         mask = 0;
       }
+      RTUF_LANES(kLaneSetupSmallHit, mask != 0);
       if (__ballot(mask != 0) && !RTUF_ABL(a.flags, 0x40000u)) {
         nfrag += cls == 0 ? emit_fragments_wave<true>(a, slot, mask, bx0, by0, a0, dzdx, dzdy, order)
                           : emit_fragments_wave<false>(a, slot, mask, bx0, by0, a0, dzdx, dzdy, order);
@@ -1130,6 +1198,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
     PackedTri pk;
     uint32_t bbx = 0, bby = 0;
     int slot = 0;
+    RTUF_LANES(kLaneSetupRec, j < nlist);
     if (j < nlist) {
       const uint32_t e = s_list[j];
       const int k = (int)(e >> 8), t = (int)(e & 255u);
@@ -1152,6 +1221,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
         bby = (uint32_t)by0 | ((uint32_t)by1 << 16);
       }
     }
+    RTUF_LANES(kLaneSetupRecHit, have);
     if (__ballot(have) && !RTUF_ABL(a.flags, 0x20000u)) {
       entries += emit_record_wave(a, list_shard, slot, have, bbx, bby, pk);
       binned += have ? 1u : 0u;
@@ -1174,6 +1244,7 @@ __global__ __launch_bounds__(kBlock) void setup_kernel(SetupArgs a, uint32_t ite
     atomicAdd(&shard.bin_entries, (unsigned long long)s_stat[1]);
     atomicAdd(&shard.frags, (unsigned long long)s_stat[2]);
   }
+  RTUF_LANES_FLUSH(shard);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1519,9 +1590,10 @@ __device__ __forceinline__ float near_z_from_key(uint32_t z24, uint32_t low, int
 }
 
 template <int MODE, bool LOW>
-__device__ __forceinline__ void fragment(unsigned long long* keys, const TriRec& r, int px, int py, int lidx, const KeyFmt& kf)
+__device__ __forceinline__ void fragment(unsigned long long* keys, const TriRec& r, int px, int py, int lidx, const KeyFmt& kf, int lc = kLaneWalkFrag)
 {
   if (MODE == 0) RTUF_COUNT_TEST();
+  if (MODE == 0) RTUF_LANES(lc, true);
   const float z = __fmaf_rn(r.dzdy, (float)py, __fmaf_rn(r.dzdx, (float)px, r.a0));
   // (r.order holds the draw order already shifted into place)
   const uint32_t lo = LOW ? (r.order | (__float_as_uint(z) & kf.lowmask)) : r.order;
@@ -1589,15 +1661,15 @@ __device__ __forceinline__ TriRec broadcast_record(const TriRec& r, int src_lane
 // box, qy1 inclusive).  Neighbouring lanes take neighbouring columns, so each of the two LDS atomics of a
 // step is conflict-free across the wave; the lower pixel's edge values are the upper one's plus B.
 template <int MODE, bool LOW>
-__device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriRec& q, int x_base, int y_base, int lx, int ly, int qy1, const KeyFmt& kf)
+__device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriRec& q, int x_base, int y_base, int lx, int ly, int qy1, const KeyFmt& kf, int lc = kLaneQuarterFrag)
 {
   const int px = x_base + lx, py = y_base + ly;
   const int e0 = __mul24(q.A[0], px) + __mul24(q.B[0], py) + q.C[0];
   const int e1 = __mul24(q.A[1], px) + __mul24(q.B[1], py) + q.C[1];
   const int e2 = __mul24(q.A[2], px) + __mul24(q.B[2], py) + q.C[2];
   const int lidx = ly * kKeyStride + lx;
-  if (min(e0, min(e1, e2)) > 0) fragment<MODE, LOW>(keys, q, px, py, lidx, kf);
-  if (min(e0 + q.B[0], min(e1 + q.B[1], e2 + q.B[2])) > 0 && ly < qy1) fragment<MODE, LOW>(keys, q, px, py + 1, lidx + kKeyStride, kf);
+  if (min(e0, min(e1, e2)) > 0) fragment<MODE, LOW>(keys, q, px, py, lidx, kf, lc);
+  if (min(e0 + q.B[0], min(e1 + q.B[1], e2 + q.B[2])) > 0 && ly < qy1) fragment<MODE, LOW>(keys, q, px, py + 1, lidx + kKeyStride, kf, lc);
 }
 
 // Rasterises the bin's records into the LDS key tile.  Every wave works on the records it loaded:
@@ -1608,6 +1680,28 @@ __device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriR
 // that lie behind it over their whole part of the tile are dropped when they are loaded.  MODE 1 looks only at records the
 // set-up marked as near (kNearBit) and, of those, only at the ones that can reach the lower half of the depth range here.
 
+// Sort key of a record for the walks below: how many trips its walk takes in this tile.  Records of one window (the
+// workgroup's 256) are dealt to the waves in the order of this key, so that the lanes of a wave -- whose lane-per-triangle
+// walk runs until its LARGEST box is done -- hold boxes of the same size (measured before: 48 % of the lanes live per quad
+// trip on the 256-stream VGA workload, 40 % with the arm in front of the lens; profiles/r05_pmc_lanes.txt).
+//   0          nothing of the box lies in this tile
+//   1 .. 47    lane-per-triangle class: quad trips
+//   48 .. 61   quarter-wave class: trips of 16 vertical pairs
+//   62         larger boxes (whole-wave / parked walks);  63  no record
+__device__ __forceinline__ uint32_t walk_key(int w, int h)
+{
+  if (w <= 0 || h <= 0) return 0u;
+  const int area = w * h;
+  if (area <= kSmallArea) return (uint32_t)min(((w + 1) >> 1) * ((h + 1) >> 1), 47);
+  if (area <= kQuarterArea) return 48u + (uint32_t)min((w * ((h + 1) >> 1) + 15) >> 4, 13);
+  return 62u;
+}
+
+#ifndef RTUF_SORT_WALK
+#define RTUF_SORT_WALK 0          // (1: A/B switch -- windows sorted by box size before the walks; measured slower)
+#endif
+constexpr int kSortWords = 128 + kTileThreads;      // two histograms of 64 keys (windows alternate) + the window's permutation
+
 template <int MODE, bool LOW>
 __device__ __forceinline__ void raster_bin(unsigned long long* keys, const PackedTri* recs, uint32_t n,
                                            int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, uint32_t n_front, uint32_t capacity,
@@ -1616,16 +1710,62 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
 {
   const int lane = tid & 63;
   const uint32_t zdrop = MODE == 1 ? min(zcover, kf.zexact - 1u) : zcover;      // MODE 1: only what can reach a depth that needs the pass
+  // (the sort's scratch lives where the parked records go AFTER this loop's closing barrier; the caller zeroed the histograms)
+  uint32_t* const s_hist = reinterpret_cast<uint32_t*>(s_prec);
+  uint32_t* const s_perm = s_hist + 128;
+  static_assert(kSortWords * 4 <= (int)sizeof(TriRec) * 64, "the sort's scratch must fit the parked-record area");
   for (uint32_t base = 0; base < n; base += kTileThreads) {
-    const uint32_t i = base + tid;
+    uint32_t i = base + tid;
     bool have = i < n;
-    const uint32_t ri = i < n_front ? i : capacity - 1u - (i - n_front);      // small boxes from the front, larger ones from the back
+    uint32_t ri = i < n_front ? i : capacity - 1u - (i - n_front);      // small boxes from the front, larger ones from the back
+    // A window that more than one wave holds records of is SORTED by the size of the boxes first (uniform decision).  Phase A:
+    // every lane takes the coordinates of record i (16 of its 32 bytes), clips the box to the tile and ranks its key in the
+    // workgroup's histogram; phase B: lane t takes the record at sorted position t (a second 32-byte load, a cache hit).
+    const bool sorted = RTUF_SORT_WALK && MODE == 0 && n - base > 64u;
+    bool first_in_regs = have_first && base == 0u;
+    if (sorted) {
+      uint32_t key = 63u;
+      if (have) {
+        const uint4 c4 = first_in_regs ? first0 : *reinterpret_cast<const uint4*>(recs + ri);
+        const unsigned long long v01 = ((unsigned long long)c4.y << 32) | c4.x, v12 = ((unsigned long long)c4.w << 32) | c4.z;
+        const int x0 = (int)(v01 & 0xfffffu) - kCoordBias, y0 = (int)((v01 >> 20) & 0xfffffu) - kCoordBias, x1 = (int)((v01 >> 40) & 0xfffffu) - kCoordBias;
+        const int y1 = (int)(v12 & 0xfffffu) - kCoordBias, x2 = (int)((v12 >> 20) & 0xfffffu) - kCoordBias, y2 = (int)((v12 >> 40) & 0xfffffu) - kCoordBias;
+        const int minx = min(x0, min(x1, x2)), maxx = max(x0, max(x1, x2));
+        const int miny = min(y0, min(y1, y2)), maxy = max(y0, max(y1, y2));
+        // (as edges_from_snapped, then clipped to the tile like the walks do)
+        const int bx0 = max((minx + 255) >> 8, 0), bx1 = min((maxx - 1) >> 8, width - 1);
+        const int by0 = max((miny + 255) >> 8, 0), by1 = min((maxy - 1) >> 8, height - 1);
+        const int w = min(bx1 - x_base, kTileW - 1) - max(bx0 - x_base, 0) + 1, h = min(by1 - y_base, kTileH - 1) - max(by0 - y_base, 0) + 1;
+        key = walk_key(w, h);
+      }
+      const uint32_t win = (base / kTileThreads) & 1u;
+      const uint32_t rank = atomicAdd(&s_hist[win * 64u + key], 1u);
+      if (tid < 64) s_hist[(win ^ 1u) * 64u + tid] = 0u;        // the next window's histogram (nobody touches it in this one)
+      __syncthreads();
+      // every wave scans the 64 counts itself (no second barrier for a table of bases)
+      const uint32_t cnt = s_hist[win * 64u + lane];
+      uint32_t incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += up; }
+      const uint32_t first_of_key = (uint32_t)__shfl((int)(incl - cnt), (int)key);
+      s_perm[first_of_key + rank] = (uint32_t)tid;
+      __syncthreads();
+#ifdef RTUF_SORT_FAKE              // (timing experiments: everything the sort costs, none of what it gives; 2: with a gather of the records as well)
+      i = base + (s_perm[tid] & 0u) + (RTUF_SORT_FAKE == 2 ? (__brev((uint32_t)tid) >> 24) : (uint32_t)tid);
+#else
+      i = base + s_perm[tid];
+#endif
+      have = i < n;
+      ri = i < n_front ? i : capacity - 1u - (i - n_front);
+      first_in_regs = false;
+    }
     TriRec r;
     int lx0 = 0, lx1 = -1, ly0 = 0, ly1 = -1;
     PackedTri pk;
+    if (MODE == 0) RTUF_LANES(kLaneTileLoad, have);
     if (have) {
       uint4* dst = reinterpret_cast<uint4*>(&pk);
-      if (have_first && base == 0u) {
+      if (first_in_regs) {
         dst[0] = first0; dst[1] = first1;      // (the caller asked for this lane's first record before it initialised the key tile)
       } else {
         const uint4* src = reinterpret_cast<const uint4*>(recs + ri);
@@ -1676,6 +1816,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       const int px_lastq = px0 + back;
       int todo = small ? __mul24(qcols, (ly1 - ly0 + 2) >> 1) : 0;
       while (__ballot(todo > 0)) {
+        if (MODE == 0) RTUF_LANES(kLaneWalkTrip, todo > 0);
         if (todo > 0) {
           const bool right = px < px1, below = py < py_last;
           const int f0 = e0 + r.B[0], f1 = e1 + r.B[1], f2 = e2 + r.B[2];
@@ -1729,8 +1870,9 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       const int qw = qx1 - qx0 + 1, npair = qw * ((qy1 - qy0 + 2) >> 1);
       const uint32_t inv = (uint32_t)ceilf(1048576.0f * __builtin_amdgcn_rcpf((float)qw));
       for (int idx = lane; idx < npair; idx += 64) {
+        if (MODE == 0) RTUF_LANES(kLaneWaveTrip, true);
         const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
-        raster_pair<MODE, LOW>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1, kf);
+        raster_pair<MODE, LOW>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1, kf, kLaneWaveFrag);
       }
     }
     unsigned long long big = __ballot(area > kSmallArea && area <= kQuarterArea);
@@ -1760,6 +1902,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       // (checked exhaustively on the CPU, including +-1 ulp of the reciprocal)
       const uint32_t inv = (uint32_t)ceilf(1048576.0f * __builtin_amdgcn_rcpf((float)max(qw, 1)));
       for (int idx = sub; __ballot(idx < npair); idx += 16) {
+        if (MODE == 0) RTUF_LANES(kLaneQuarterTrip, idx < npair);
         if (idx < npair) {
           const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
           raster_pair<MODE, LOW>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1, kf);
@@ -1846,6 +1989,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
         const int px = x_base + lane;
         const float zc = __fmaf_rn(q.dzdx, (float)px, q.a0);
         for (int ly = qy0 + (tid >> 6); ly <= qy1; ly += kTileThreads / 64) {
+          if (MODE == 0) { RTUF_LANES(kLaneParkTrip, true); RTUF_LANES(kLaneParkFrag, true); }
           const float z = __fmaf_rn(q.dzdy, (float)(y_base + ly), zc);
           const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | (LOW ? (q.order | (__float_as_uint(z) & kf.lowmask)) : q.order);
           const int lidx = ly * kKeyStride + lane;
@@ -1858,16 +2002,18 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
         }
       } else if (inside) {
         for (int idx = tid; idx < npair; idx += kTileThreads) {
+          if (MODE == 0) RTUF_LANES(kLaneParkTrip, true);
           const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
           const int lx = qx0 + idx - __mul24(yy, qw), ly = qy0 + 2 * yy;
           const int lidx = ly * kKeyStride + lx;
-          fragment<MODE, LOW>(keys, q, x_base + lx, y_base + ly, lidx, kf);
-          if (ly < qy1) fragment<MODE, LOW>(keys, q, x_base + lx, y_base + ly + 1, lidx + kKeyStride, kf);
+          fragment<MODE, LOW>(keys, q, x_base + lx, y_base + ly, lidx, kf, kLaneParkFrag);
+          if (ly < qy1) fragment<MODE, LOW>(keys, q, x_base + lx, y_base + ly + 1, lidx + kKeyStride, kf, kLaneParkFrag);
         }
       } else {
         for (int idx = tid; idx < npair; idx += kTileThreads) {
+          if (MODE == 0) RTUF_LANES(kLaneParkTrip, true);
           const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
-          raster_pair<MODE, LOW>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1, kf);
+          raster_pair<MODE, LOW>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1, kf, kLaneParkFrag);
         }
       }
     }
@@ -1901,6 +2047,7 @@ __device__ __forceinline__ void apply_frags(unsigned long long* keys, const unsi
     const int lidx = RTUF_KEY_PAD ? fpos + (fpos / kTileW) * RTUF_KEY_PAD : fpos;
     const unsigned long long key = ((f[u] >> 40) << 32) | (((uint32_t)(f[u] >> kFragPosBits) & kMaxOrder) << shift);
     // (zcover == 0xffffffff: no cover, every fragment passes; behind the tile's cover: cannot win)
+    RTUF_LANES(kLaneFragList, i < nf && (uint32_t)(f[u] >> 40) <= zcover);
     if (i < nf && (uint32_t)(f[u] >> 40) <= zcover) { RTUF_COUNT_TEST(); atomicMin(&keys[lidx], key); }
   }
 }
@@ -1968,6 +2115,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   __shared__ uint4 s_pmeta[64];                    //     with {class, smallest depth, largest depth if it covers the whole tile}
 
   const int tid = threadIdx.x;
+  RTUF_LANES_INIT();
   const int tiles = a.tiles_x * a.tiles_y;
   // grid = (tiles_x, tiles_y, streams of the group): no integer divisions to find the tile
   const int txi = blockIdx.x, tyi = blockIdx.y, slot = blockIdx.z;
@@ -2079,6 +2227,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       for (int i = tid; i < kKeyCount; i += kTileThreads) keys[i] = bgkey;
     }
     if (tid == 0) { s_huge[0] = 0; s_huge[1 + kHugeMax] = n <= (uint32_t)kParkBelow ? (uint32_t)kQuarterArea : (uint32_t)kWallArea; }
+    if (RTUF_SORT_WALK && tid < 128) reinterpret_cast<uint32_t*>(s_prec)[tid] = 0u;      // raster_bin's sort histograms
 #ifdef RTUF_COUNT
     if (tid < 2) count_words()[tid] = 0u;
 #endif
@@ -2223,6 +2372,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
     const int r_ly = r_ly0 + ps * kRowsPerPass;
     const bool valid = r_ly < kTileH && y_base + r_ly < a.height && r_px < a.width;
     uint32_t flags4 = 0;
+    RTUF_LANES(kLaneResolve, valid);
     if (valid) {
       if (empty) {                                   // tile without geometry: a streaming compare against the plane
         flags4 = finish(ps, bg_z4, bg_thr4, bg_frag4);
@@ -2272,6 +2422,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
     }
   }
   if (BITS && __syncthreads_or(uncovered) && tid == 0) a.counters->shard[bin % kCounterShards].uncovered = 1u;
+  RTUF_LANES_FLUSH(a.counters->shard[bin % kCounterShards]);
 #ifdef RTUF_COUNT
   __syncthreads();
   if (!empty && tid == 0) {
@@ -2373,12 +2524,34 @@ __global__ __launch_bounds__(kBlock) void compare_kernel(CompareArgs a)
 // A batch's counters (one block per launch group) go to pinned host memory with plain stores from a tiny kernel, one
 // workgroup per block: a hipMemcpyAsync of 8 KB costs a blit launch plus ~10 us of copy-engine set-up on the stream.
 // Every raster lane publishes the blocks of its own groups (first, first + stride, ...) at the end of its part of the batch.
-__global__ void publish_counters_kernel(const Counters* __restrict__ src, Counters* __restrict__ host_dst, int first, int stride)
+// It is the last kernel a lane runs for a launch group, and it sees every counter the host will judge the batch by when it
+// retires it: it makes the same judgement on the device and leaves it in the batch slot's status word, for consumers that read
+// the output planes on a stream of their own (rtuf_order_stream_after_batches) before the host has retired the batch.
+__global__ void publish_counters_kernel(const Counters* __restrict__ src, Counters* __restrict__ host_dst, int first, int stride,
+                                        uint32_t* status, PublishLimits lim)
 {
   const int b = first + (int)blockIdx.x * stride;
   const uint4* s = reinterpret_cast<const uint4*>(src + b);
   uint4* d = reinterpret_cast<uint4*>(host_dst + b);
   for (int i = threadIdx.x; i < (int)(sizeof(Counters) / 16); i += blockDim.x) d[i] = s[i];
+  if (threadIdx.x < 64) {            // the first wave: a shard per lane (kCounterShards <= 64)
+    uint32_t f = 0;
+    for (int i = threadIdx.x; i < kCounterShards; i += 64) {
+      const CounterShard& sh = src[b].shard[i];
+      if (sh.max_bin_fill > lim.capacity || sh.max_fbin_fill > lim.fcapacity) f |= kStatusBinOverflow;
+      if (sh.clip_overflow) f |= kStatusClipOverflow;
+      if (sh.max_big_fill > lim.big_capacity) f |= kStatusBigOverflow;
+      if (sh.uncovered) f |= kStatusUncovered;
+    }
+    if (threadIdx.x == 0 && src[b].work.n_items > src[b].work.grid) f |= kStatusGridShort;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) f |= (uint32_t)__shfl_xor((int)f, o);
+    if (threadIdx.x == 0) {
+      if (f) atomicOr(status, f);
+      __threadfence();               // the flags are visible before this group counts as finished
+      atomicSub(status, 1u);
+    }
+  }
 }
 
 // bin headers of a fresh (or regrown) working set: nothing binned, no cover
@@ -2399,9 +2572,9 @@ __global__ void spin_kernel(unsigned long long ticks)
 void launch_spin(unsigned long long ticks, hipStream_t st) { hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, ticks); }
 
 // host-callable launchers ---------------------------------------------------------------
-void launch_publish_counters(const Counters* src, Counters* host_dst, int first, int stride, int count, hipStream_t st)
+void launch_publish_counters(const Counters* src, Counters* host_dst, int first, int stride, int count, uint32_t* status, PublishLimits lim, hipStream_t st)
 {
-  if (count > 0) hipLaunchKernelGGL(publish_counters_kernel, dim3((unsigned)count), dim3(256), 0, st, src, host_dst, first, stride);
+  if (count > 0) hipLaunchKernelGGL(publish_counters_kernel, dim3((unsigned)count), dim3(256), 0, st, src, host_dst, first, stride, status, lim);
 }
 void launch_init_headers(BinHeader* hdr, size_t n_bins, hipStream_t st)
 {

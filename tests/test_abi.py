@@ -29,8 +29,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_struct_sizes():
     lib = R.load_library()
-    assert lib.rtuf_abi_version() == R.ABI_VERSION == 5
-    assert ctypes.sizeof(_capi.Params) == 48 and ctypes.sizeof(_capi.Stats) == 232
+    assert lib.rtuf_abi_version() == R.ABI_VERSION == 6
+    assert ctypes.sizeof(_capi.Params) == 48 and ctypes.sizeof(_capi.Stats) == 248
     p = R.default_params()
     assert abs(p.near_plane - 0.1) < 1e-7 and p.far_plane == 8.0 and abs(p.depth_distance_threshold - 0.05) < 1e-7
     assert p.filter_replace_value == 0.0 and p.flags == 0

@@ -49,6 +49,29 @@ def test_bench_line_contract():
     assert cb["all_cores"]["cores"] >= 1 and cb["all_cores"]["value"] > 0
 
 
+def test_bench_line_carries_the_other_baseline_configs():
+    """`other_configs` (the driver's default command runs them at full size; here the same legs at the tests' sizes): BASELINE
+    config 2 (one camera: frames/s and the latency of one frame in flight), config 3 with the forearm in front of every lens,
+    rank 0's shares of configs 4 (64 x 720p, robot + walls) and 5 (8 URDFs x 128 cameras) -- each with frames/s, memory, the
+    tile kernel's launch time on a one-lane context and 8 streams (or all) against the oracle."""
+    args = ["--steps", "3", "--warmup", "1", "--streams", "8", "--triangles", "8000", "--cpu-seconds", "0", "--check-frames", "2", "--min-seconds", "0.2",
+            "--isolated-seconds", "0.2", "--host-copy-seconds", "0", "--other-configs", "on", "--other-configs-seconds", "0.3"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    oc = d["other_configs"]
+    assert set(oc) == {"c2_batch1", "c3_near_arm", "c4_share", "c5_share", "note"}, oc.keys()
+    for key, streams, size in (("c2_batch1", 1, [640, 480]), ("c3_near_arm", 8, [640, 480]), ("c4_share", 64, [1280, 720]), ("c5_share", 1024, [640, 480])):
+        leg = oc[key]
+        assert "error" not in leg, leg
+        assert leg["streams"] == streams and leg["size"] == size and leg["frames_per_s"] > 0 and leg["device_memory_bytes"] > 0
+        assert leg["mismatching_values"] == 0 and leg["frames_checked"] == min(8, streams)
+        tk = leg["tile_kernel"]
+        assert tk["avg_launch_ms"] > 0 and 0 < tk["frac"] < 1 and tk["streams_per_launch"] == streams
+    assert oc["c2_batch1"]["latency_us_per_frame"] > 0
+    assert 0 < d["hbm_frac_end_to_end"]["value"] < 1 and d["hbm_frac_end_to_end"]["n_gpus"] == 1
+
+
 def test_bench_line_with_split_batches_and_every_stream_checked():
     """64 streams: the headline context splits every batch into three launch groups, one per raster lane; by default every
     stream of the last timed step is checked against the oracle."""
@@ -97,6 +120,15 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     pr = d["parity"]["per_rank"]
     assert [x["rank"] for x in pr] == [0, 1] and all(x["frames_checked"] == 2 and x["mismatching_values"] == 0 for x in pr)
     assert all(x["frames"] == 8 * d["timed_steps"] for x in pr)
+    # what north_star asks of a multi-rank line: the per-kernel roofline still comes from the one-lane leg (rank 0 measures it
+    # after the timed region while the others wait), the CPU baseline is there, the whole path is priced against N x 8 TB/s,
+    # and every rank's own frames/s shows a straggler
+    rf = d["roofline"]
+    assert "one-lane context" in rf["measured_on"] and rf["frac"] > 0 and rf["one_lane_leg"]["frames_per_s"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    e2e = d["hbm_frac_end_to_end"]
+    assert e2e["n_gpus"] == 2 and abs(e2e["value"] - d["value"] * e2e["bytes_per_frame"] / (2 * 8000e9)) < 1e-12
+    assert all(x["frames_per_s"] > 0 for x in pr) and sum(x["frames_per_s"] for x in pr) >= d["value"] * 0.999
 
 
 def test_bench_two_ranks_rehearsal_config4_and_config5():
