@@ -168,7 +168,7 @@ struct alignas(16) ClipItem {   // one triangle that crosses a frustum plane; se
 #define RTUF_COUNTER_SHARDS 64
 #endif
 constexpr int kCounterShards = RTUF_COUNTER_SHARDS;
-constexpr int kLaneLoops = 24;           // instrumented loops of a -DRTUF_LANECOUNT build
+constexpr int kLaneLoops = 48;           // instrumented loops (and histogram buckets) of a -DRTUF_LANECOUNT build
 struct alignas(128) CounterShard {
   unsigned long long tris_binned;
   unsigned long long bin_entries;

@@ -55,8 +55,13 @@ enum {
   kLaneSetupRecHit,       // ... of which survive orientation / bounding
   kLaneSetupRecTile,      // record emission: trips over the tiles a record touches
   kLaneSetupRecGroup,     // record emission: group-finding trips
-  kLaneCount
+  kLaneCount,
+  // histogram of the tile kernel's bin records (live = records): by quad trips of the lane-per-triangle walk (1, 2, 3, 4, 5, 6,
+  // 7-8, 9-12, 13-16, 17-24, 25+), quarter-wave class, larger, nothing in this tile; and how many records have a WHOLE box of
+  // at most 8 x 8 / 8 x 4 (or 4 x 8) pixel centres inside one tile (what a larger fragment class of the set-up kernel would take)
+  kLaneHist = 24, kLaneHistQuarter = kLaneHist + 11, kLaneHistLarge, kLaneHistNone, kLaneHist8x8, kLaneHist8x4, kLaneHistEnd
 };
+static_assert(kLaneHistEnd <= kLaneLoops, "CounterShard holds kLaneLoops pairs");
 static_assert(kLaneCount <= kLaneLoops, "CounterShard holds kLaneLoops pairs");
 #ifdef RTUF_LANECOUNT
 __device__ __forceinline__ uint32_t* lane_words() { __shared__ uint32_t s_lw[2 * kLaneLoops]; return s_lw; }
@@ -73,7 +78,7 @@ __device__ __forceinline__ uint32_t* lane_words() { __shared__ uint32_t s_lw[2 *
 #define RTUF_LANES_FLUSH(shard)                                                                                       \
   do {                                                                                                                \
     __syncthreads();                                                                                                  \
-    if ((int)threadIdx.x < kLaneLoops && lane_words()[2 * threadIdx.x]) {                                             \
+    if ((int)threadIdx.x < kLaneLoops && (lane_words()[2 * threadIdx.x] | lane_words()[2 * threadIdx.x + 1])) {        \
       atomicAdd(&(shard).lane_slots[threadIdx.x], (unsigned long long)lane_words()[2 * threadIdx.x]);                 \
       atomicAdd(&(shard).lane_live[threadIdx.x], (unsigned long long)lane_words()[2 * threadIdx.x + 1]);              \
     }                                                                                                                 \
@@ -1797,6 +1802,18 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     if (dbg_skip == 2 && area > kSmallArea) area = 0;       // timing experiment: no quarter-wave walk
     if (dbg_skip == 3 && area > kQuarterArea) area = 0;     // timing experiment: no whole-tile walks
     const bool small = area > 0 && area <= kSmallArea;
+#ifdef RTUF_LANECOUNT
+    if (MODE == 0 && have) {
+      const int td = ((lx1 - lx0 + 2) >> 1) * ((ly1 - ly0 + 2) >> 1);
+      const int b = area <= 0 ? kLaneHistNone : (area > kQuarterArea ? kLaneHistLarge : (area > kSmallArea ? kLaneHistQuarter :
+                    kLaneHist + (td <= 6 ? td - 1 : (td <= 8 ? 6 : (td <= 12 ? 7 : (td <= 16 ? 8 : (td <= 24 ? 9 : 10)))))));
+      atomicAdd(&lane_words()[2 * b + 1], 1u);
+      const int fw = (int)(r.bbx >> 16) - (int)(r.bbx & 0xffff) + 1, fh = (int)(r.bby >> 16) - (int)(r.bby & 0xffff) + 1;
+      const bool one_tile = (int)(r.bbx & 0xffff) / kTileW == (int)(r.bbx >> 16) / kTileW && (int)(r.bby & 0xffff) / kTileH == (int)(r.bby >> 16) / kTileH;
+      if (one_tile && fw <= 8 && fh <= 8 && !(pk.order & kNearBit)) atomicAdd(&lane_words()[2 * kLaneHist8x8 + 1], 1u);
+      if (one_tile && ((fw <= 8 && fh <= 4) || (fw <= 4 && fh <= 8)) && !(pk.order & kNearBit)) atomicAdd(&lane_words()[2 * kLaneHist8x4 + 1], 1u);
+    }
+#endif
     // lane-per-triangle: walk the bounding box as one run of 2x2 candidate QUADS, quad row by quad row.
     // The three edge values of a quad's upper left pixel are stepped incrementally (one add each, a
     // different step at the end of a quad row); the other three pixels' are those plus A, B, A + B -- the

@@ -43,14 +43,21 @@ for key, kw in cases:
         share.stage(ctx, step)
         ctx.filter_batch_device(n, d.data_ptr(), m.data_ptr(), k.data_ptr()); ctx.sync()
     st = ctx.stats()
-    slots = (ctypes.c_uint64 * 24)(); live = (ctypes.c_uint64 * 24)()
-    lib.rtuf_debug_lane_counts(ctx._h, slots, live, 24)
+    slots = (ctypes.c_uint64 * 48)(); live = (ctypes.c_uint64 * 48)()
+    lib.rtuf_debug_lane_counts(ctx._h, slots, live, 48)
     rows = {}
     for i, name in enumerate(NAMES):
         if slots[i]:
             rows[name] = {"wave_trips": int(slots[i]) // 64, "live_lanes": int(live[i]), "live_fraction": round(live[i] / slots[i], 4)}
+    hist_names = ["1", "2", "3", "4", "5", "6", "7-8", "9-12", "13-16", "17-24", "25+", "quarter-wave class", "larger", "nothing in this tile",
+                  "whole box <= 8x8 in one tile, not near", "whole box <= 8x4 / 4x8 in one tile, not near"]
+    hist = {hist_names[i]: int(live[24 + i]) for i in range(len(hist_names))}
+    out.setdefault("_hist", {})[key] = hist
     out[key] = {"streams": n, "size": [W, H], "bin_entries": st["bin_entries"], "fragments_binned": st["fragments_binned"],
                 "depth_tests": st["raster_atomics"], "drawn_pixels": st["drawn_pixels"], "loops": rows}
     ctx.close(); del d, m, k
+hist = out.pop("_hist", {})
+for k in hist:
+    out[k]["records_by_quad_trips_of_their_walk"] = hist[k]
 print(json.dumps(out, indent=1))
 PY
