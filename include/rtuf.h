@@ -226,7 +226,12 @@ int rtuf_filter_batch(rtuf_context *ctx, int n_streams, const float *const *dept
  * rtuf_set_link_poses[_batch] -- may be called at any time: their staging is a ring of sets, one per batch in
  * flight plus one being written, so the next frame's poses are staged while the GPU filters this one (only a call
  * that switches a stream between forward kinematics and explicit matrices waits).  Every other setter (parameters,
- * model selection, kinematic trees) waits for the batches in flight.  rtuf_sync() retires everything in flight. */
+ * model selection, kinematic trees) waits for the batches in flight.  rtuf_sync() retires everything in flight.
+ * ORDER OF BATCHES IN FLIGHT: none.  With more than one raster lane (the default) consecutive batches run on different
+ * HIP streams -- a batch of one launch group takes the lanes in turn -- and nothing orders the kernels of one batch behind
+ * those of the batch before it.  Two batches in flight must therefore not share an output plane, and a batch must not read
+ * as its sensor plane what the batch before it writes: retire the first (rtuf_wait_oldest / rtuf_sync) or run the context with
+ * rtuf_params.raster_lanes = 1, where batches execute in the order they were enqueued. */
 int rtuf_filter_batch_device(rtuf_context *ctx, int n_streams, const float *d_depth,
                              float *d_masked, uint8_t *d_mask);
 /* 16UC1 variants: depth in / out as uint16 millimetres with the reference's conversions fused into the
@@ -373,7 +378,10 @@ typedef struct {
   uint32_t batch_reruns;            /* times that batch (and everything in flight behind it) was run again before it was retired */
   uint32_t over_memory_limit;       /* 1: the tile bins exceed rtuf_params.memory_limit_mb (or the automatic third of the free
                                        memory): one stream's bins alone are larger, and launch groups cannot shrink below one   */
-  uint32_t reserved1;
+  uint32_t copy_streams_side_by_side;  /* host-plane calls: 1 once the upload and download streams were measured to run beside the
+                                       raster lanes' (first such call), 0 before that or when they share a hardware queue with a lane
+                                       (copies then wait behind that lane's kernels).  RTUF_QUEUE_PROBE=0 in the environment skips
+                                       all of these measurements (rtuf_create is ~10 ms faster, the flags then read 1 unmeasured)  */
 } rtuf_stats;
 int rtuf_get_stats(rtuf_context *ctx, rtuf_stats *out);
 /* Per-kernel HIP-event timing (off by default: every event costs a few microseconds of stream

@@ -63,7 +63,7 @@ class Stats(ctypes.Structure):
                 ("graphs_enabled", ctypes.c_uint32), ("graph_hits", ctypes.c_uint64), ("graph_misses", ctypes.c_uint64),
                 ("lanes_side_by_side", ctypes.c_uint32),
                 ("batch_status", ctypes.c_uint32), ("batch_reruns", ctypes.c_uint32), ("over_memory_limit", ctypes.c_uint32),
-                ("reserved1", ctypes.c_uint32)]
+                ("copy_streams_side_by_side", ctypes.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}

@@ -441,8 +441,16 @@ static void settle_order(rtuf_context* c, int j, bool accepted)
 // idle kernel of 300 us on each, timed against one alone.  (Found the hard way: with an RCCL communicator in the process the
 // two raster lanes of a context landed on one queue -- 381 k instead of 484 k frames/s, per-launch times those of kernels
 // running alone.)
+// RTUF_QUEUE_PROBE=0 in the environment skips the measurement (every stream is taken as the runtime hands it out): for hosts
+// that share the GPU with other processes, where idle kernels cannot be timed, or that cannot spare the ~10 ms at start-up.
+static bool queue_probe_enabled()
+{
+  static const bool on = [] { const char* e = getenv("RTUF_QUEUE_PROBE"); return !(e && e[0] == '0' && e[1] == 0); }();
+  return on;
+}
 static bool streams_run_side_by_side(hipStream_t a, hipStream_t b)
 {
+  if (!queue_probe_enabled()) return true;
   using clk = std::chrono::steady_clock;
   const unsigned long long ticks = 30000;      // 300 us at 100 MHz
   launch_spin(100, a); launch_spin(100, b);    // (code object load, queue creation)
@@ -455,7 +463,8 @@ static bool streams_run_side_by_side(hipStream_t a, hipStream_t b)
     if (both) (void)hipStreamSynchronize(b);
     return std::chrono::duration<double>(clk::now() - t0).count();
   };
-  const double one = std::min(timed(false), timed(false)), two = std::min(timed(true), timed(true));
+  // (the smallest of three: whatever else the GPU or the host is doing can only make a repetition longer)
+  const double one = std::min(timed(false), std::min(timed(false), timed(false))), two = std::min(timed(true), std::min(timed(true), timed(true)));
   return two < 1.5 * one;
 }
 
@@ -1995,8 +2004,10 @@ static int submit_host_batch(rtuf_context* c, int n, const void* const* depth_in
   if (!c->h2d || !c->d2h) {
     bool beside = true;
     sync_lanes(c);                      // (the probe times idle kernels: nothing else may be running; first host-plane call only)
-    if (!c->h2d) HIP_TRY(c, create_stream_beside(lane_streams(c), &c->h2d, &beside));
+    bool beside_up = true;
+    if (!c->h2d) HIP_TRY(c, create_stream_beside(lane_streams(c), &c->h2d, &beside_up));
     if (!c->d2h) HIP_TRY(c, create_stream_beside(lane_streams(c), &c->d2h, &beside));
+    c->stats.copy_streams_side_by_side = (beside && beside_up) ? 1u : 0u;
   }
   const int limit = (c->params.flags & RTUF_FLAG_TWO_KERNEL) ? 1 : kMaxInflight;
   while (c->pending >= limit) { const int rc = retire_oldest(c); if (rc != RTUF_OK) return rc; }

@@ -1580,6 +1580,7 @@ struct KeyFmt {
   int shift;            // draw order << shift in the key's low word (TileArgs::key_shift)
   uint32_t lowmask;     // (1 << shift) - 1 in tiles that hold near records (or a near cover), else 0
   uint32_t zexact;      // winners with z24 < zexact need the exact-z pass: 2^(26-shift) in near tiles, else 2^23 + 1
+  uint32_t abl;         // RTUF_ABLATE builds: the launch's timing-experiment bits (0x4000: depth tests without their LDS atomic, 0x2000000: strips fetched but not walked)
 };
 
 // float z of a fragment from its 24-bit depth (zexact <= z24 <= 2^23) and the low `shift` bits of its float
@@ -1594,20 +1595,27 @@ __device__ __forceinline__ float near_z_from_key(uint32_t z24, uint32_t low, int
   return __uint_as_float(cand);
 }
 
+// One depth test of a fragment whose window z is already evaluated (`order`: the draw order shifted into place).
 template <int MODE, bool LOW>
-__device__ __forceinline__ void fragment(unsigned long long* keys, const TriRec& r, int px, int py, int lidx, const KeyFmt& kf, int lc = kLaneWalkFrag)
+__device__ __forceinline__ void depth_test(unsigned long long* keys, uint32_t order, float z, int lidx, const KeyFmt& kf, int lc)
 {
   if (MODE == 0) RTUF_COUNT_TEST();
   if (MODE == 0) RTUF_LANES(lc, true);
-  const float z = __fmaf_rn(r.dzdy, (float)py, __fmaf_rn(r.dzdx, (float)px, r.a0));
-  // (r.order holds the draw order already shifted into place)
-  const uint32_t lo = LOW ? (r.order | (__float_as_uint(z) & kf.lowmask)) : r.order;
+  const uint32_t lo = LOW ? (order | (__float_as_uint(z) & kf.lowmask)) : order;
   const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | lo;
+  if (RTUF_ABL(kf.abl, 0x4000u)) { if (key == 0x0123456789abcdefull) keys[lidx] = key; return; }      // timing experiment: everything but the atomic
   if (MODE == 0) {
     atomicMin(&keys[lidx], key);
   } else {
     if (keys[lidx] == key) keys[lidx] = kResolvedBit | (unsigned long long)__float_as_uint(z);
   }
+}
+
+template <int MODE, bool LOW>
+__device__ __forceinline__ void fragment(unsigned long long* keys, const TriRec& r, int px, int py, int lidx, const KeyFmt& kf, int lc = kLaneWalkFrag)
+{
+  // (r.order holds the draw order already shifted into place)
+  depth_test<MODE, LOW>(keys, r.order, __fmaf_rn(r.dzdy, (float)py, __fmaf_rn(r.dzdx, (float)px, r.a0)), lidx, kf, lc);
 }
 
 
@@ -1675,6 +1683,70 @@ __device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriR
   const int lidx = ly * kKeyStride + lx;
   if (min(e0, min(e1, e2)) > 0) fragment<MODE, LOW>(keys, q, px, py, lidx, kf, lc);
   if (min(e0 + q.B[0], min(e1 + q.B[1], e2 + q.B[2])) > 0 && ly < qy1) fragment<MODE, LOW>(keys, q, px, py + 1, lidx + kKeyStride, kf, lc);
+}
+
+// Row-stepped walk of a strip -- columns qx0 .. qx0 + wc - 1 (wc <= 2^team_log) of the record's part of the tile, rows qy0 ..
+// qy0 + h - 1 -- by a TEAM of 2^team_log lanes (`sub` = the lane's number in its team).  The team forms 2^plog columns (the
+// power of two that holds wc) x 2^lr rows; every lane keeps its column and steps DOWN the rows, 2^lr at a time, two steps per
+// trip.  Nothing is evaluated per candidate but what changes: the three edge values move by B << lr per step (integer adds
+// modulo 2^32 of the same integers A*px + B*py + C is made of -- the value at a pixel is the same number whichever way it is
+// reached), the plane's column term fma(dzdx, px, a0) is the lane's constant and the row's float coordinate moves by 2^lr (small
+// integers: exact), so fma(dzdy, py, .) sees the operands fragment() gives it.  A trip costs 16 VALU instructions for 2 x 2^team_log
+// candidates where the linear run of pairs it replaces (raster_pair: index -> column / row by a reciprocal multiply, six 24-bit
+// multiplies per pair) took 42.  EDGES = false: the caller knows that every candidate is covered (classify_box == 2).
+#ifndef RTUF_STRIP_INTROW
+#define RTUF_STRIP_INTROW 0
+#endif
+#ifndef RTUF_STRIP_WALK
+#define RTUF_STRIP_WALK 2          // (A/B switch -- 0: quarter-wave and whole-wave walks as linear runs of candidate pairs, as up to round 4; 2: strips only in tiles with near geometry)
+#endif
+template <int MODE, bool LOW, bool EDGES>
+__device__ __forceinline__ void strip_walk(unsigned long long* keys, const TriRec& q, int x_base, int y_base, int qx0, int wc, int qy0, int h,
+                                           int team_log, int sub, bool on, const KeyFmt& kf, int lc_trip, int lc_frag)
+{
+  const int plog = wc > 1 ? 32 - __clz(wc - 1) : 0, lr = team_log - plog;
+  const int col = sub & ((1 << plog) - 1), row0 = sub >> plog;
+  // rows row0, row0 + 2^lr, ... below h (row0 < 2^lr: the numerator is never negative)
+  int nrow = (on && col < wc) ? (h - 1 - row0 + (1 << lr)) >> lr : 0;
+  const int px = x_base + qx0 + col, py = y_base + qy0 + row0;
+  int e0 = 1, e1 = 1, e2 = 1, d0 = 0, d1 = 0, d2 = 0;
+  if (EDGES) {
+    e0 = __mul24(q.A[0], px) + __mul24(q.B[0], py) + q.C[0];
+    e1 = __mul24(q.A[1], px) + __mul24(q.B[1], py) + q.C[1];
+    e2 = __mul24(q.A[2], px) + __mul24(q.B[2], py) + q.C[2];
+    d0 = (int)((uint32_t)q.B[0] << lr); d1 = (int)((uint32_t)q.B[1] << lr); d2 = (int)((uint32_t)q.B[2] << lr);
+  }
+  const float zc = __fmaf_rn(q.dzdx, (float)px, q.a0);
+#if RTUF_STRIP_INTROW            // (A/B switch: the row as an integer, converted per depth test -- three registers fewer, one conversion more per test)
+  int yy = py;
+  const int rpt = 1 << lr;
+  int lidx = (qy0 + row0) * kKeyStride + qx0 + col;
+  while (__ballot(nrow > 0)) {
+    if (MODE == 0) RTUF_LANES(lc_trip, nrow > 0);
+    const int f0 = e0 + d0, f1 = e1 + d1, f2 = e2 + d2;
+    if (nrow > 0 && (!EDGES || min(e0, min(e1, e2)) > 0)) depth_test<MODE, LOW>(keys, q.order, __fmaf_rn(q.dzdy, (float)yy, zc), lidx, kf, lc_frag);
+    if (nrow > 1 && (!EDGES || min(f0, min(f1, f2)) > 0)) depth_test<MODE, LOW>(keys, q.order, __fmaf_rn(q.dzdy, (float)(yy + rpt), zc), lidx + rpt * kKeyStride, kf, lc_frag);
+    e0 = f0 + d0; e1 = f1 + d1; e2 = f2 + d2;
+    yy += 2 * rpt;
+    lidx += 2 * rpt * kKeyStride;
+    nrow -= 2;
+  }
+#else
+  float fy = (float)py;
+  const float dfy = (float)(1 << lr);
+  int lidx = (qy0 + row0) * kKeyStride + qx0 + col;
+  const int dl = kKeyStride << lr;
+  while (__ballot(nrow > 0)) {
+    if (MODE == 0) RTUF_LANES(lc_trip, nrow > 0);
+    const int f0 = e0 + d0, f1 = e1 + d1, f2 = e2 + d2;
+    if (nrow > 0 && (!EDGES || min(e0, min(e1, e2)) > 0)) depth_test<MODE, LOW>(keys, q.order, __fmaf_rn(q.dzdy, fy, zc), lidx, kf, lc_frag);
+    if (nrow > 1 && (!EDGES || min(f0, min(f1, f2)) > 0)) depth_test<MODE, LOW>(keys, q.order, __fmaf_rn(q.dzdy, __fadd_rn(fy, dfy), zc), lidx + dl, kf, lc_frag);
+    e0 = f0 + d0; e1 = f1 + d1; e2 = f2 + d2;
+    fy = __fadd_rn(fy, __fadd_rn(dfy, dfy));
+    lidx += 2 * dl;
+    nrow -= 2;
+  }
+#endif
 }
 
 // Rasterises the bin's records into the LDS key tile.  Every wave works on the records it loaded:
@@ -1877,6 +1949,49 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       if (parked) s_huge[1 + hs] = ri;
       huge &= ~__ballot(parked);
     }
+    if constexpr (RTUF_STRIP_WALK == 1 || (RTUF_STRIP_WALK == 2 && (LOW || MODE == 1))) {
+    // Everything beyond the lane-per-triangle class that stays with this wave: STRIPS, one per team of lanes.  A strip is up to
+    // 16 columns of a record's part of the tile over all its rows (a wider record is dealt out as two to four strips, to
+    // neighbouring teams or successive rounds); its lanes step down the rows (strip_walk).  With three and more records waiting
+    // a round deals four strips to the four quarters of the wave; the last two share the wave half and half, a single one gets
+    // all 64 lanes (16 columns x 4 rows per step) -- on the 256-stream VGA workload nearly every round is of that kind (a
+    // wave-load there holds one such record in four).  The record travels from the lane that loaded it with 15 shuffles.
+    {
+      unsigned long long big = __ballot(area > kSmallArea && (area <= kQuarterArea || ((huge >> lane) & 1ull) != 0ull));
+      const int nstrip = (lx1 - lx0 + 16) >> 4;
+      int head_strip = 0;                      // (scalar) the next strip of the record at the head of `big`
+      while (big) {
+        const int waiting = __popcll(big);
+        const int team_log = waiting >= 3 ? 4 : (waiting == 2 ? 5 : 6);      // (scalar)
+        const int grp = lane >> team_log, sub = lane & ((1 << team_log) - 1);
+        int src = -1, strip = 0;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          if (g < (64 >> team_log)) {
+            const int sl = big ? __ffsll((long long)big) - 1 : -1;
+            const int si = head_strip;
+            if (big) {
+              if (++head_strip >= __builtin_amdgcn_readlane(nstrip, sl)) { big &= big - 1; head_strip = 0; }
+            }
+            if (g == grp) { src = sl; strip = si; }
+          }
+        }
+        const int srcl = src < 0 ? lane : src;
+        TriRec q;
+        {
+          const int* sp = reinterpret_cast<const int*>(&r);
+          int* dp = reinterpret_cast<int*>(&q);
+#pragma unroll
+          for (int k = 0; k < 15; k++) dp[k] = __shfl(sp[k], srcl);
+        }
+        const int qx0 = max((int)(q.bbx & 0xffff) - x_base, 0) + 16 * strip, qx1 = min((int)(q.bbx >> 16) - x_base, kTileW - 1);
+        const int qy0 = max((int)(q.bby & 0xffff) - y_base, 0), qy1 = min((int)(q.bby >> 16) - y_base, kTileH - 1);
+        if (RTUF_ABL(kf.abl, 0x2000000u)) { if (q.order == 0xdeadbeefu) keys[0] = 0; continue; }      // timing experiment: strips dealt out and fetched, not walked
+        strip_walk<MODE, LOW, true>(keys, q, x_base, y_base, qx0, min(qx1 - qx0 + 1, 16), qy0, qy1 - qy0 + 1, team_log, sub, src >= 0, kf, kLaneQuarterTrip, kLaneQuarterFrag);
+      }
+    }
+    } else {
+    const int grp = lane >> 4, sub = lane & 15;
     while (huge) {
       const int src = __ffsll((long long)huge) - 1;
       huge &= huge - 1;
@@ -1893,7 +2008,6 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
       }
     }
     unsigned long long big = __ballot(area > kSmallArea && area <= kQuarterArea);
-    const int grp = lane >> 4, sub = lane & 15;
     while (big) {
       int src = -1;
 #pragma unroll
@@ -1925,6 +2039,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
           raster_pair<MODE, LOW>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1, kf);
         }
       }
+    }
     }
   }
   // workgroup-cooperative: the parked triangles (those that cover a large part of the tile: walls, close
@@ -2156,6 +2271,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   const bool near_tile = (fraw >> 31) != 0u;              // (wave-uniform: a scalar load of a workgroup-uniform address)
   KeyFmt kf;
   kf.shift = a.key_shift;
+  kf.abl = a.flags;
   kf.lowmask = near_tile ? (1u << a.key_shift) - 1u : 0u;
   kf.zexact = near_tile ? 1u << (26 - a.key_shift) : 8388609u;
   const uint32_t count = count_front + count_back;

@@ -136,7 +136,9 @@ class RosFilter {
       ROS_ERROR_THROTTLE(5.0, "input_depth: malformed image (%ux%u, step %u, %zu bytes)", frame->width, frame->height, frame->step, frame->data.size());
       return;
     }
-    if (camera_info->width != frame->width || camera_info->height != frame->height) {
+    // camera_info's own size fields only count when a driver fills them in (some leave them 0; the reference reads nothing but K / P
+    // from the message, src/urdf_filter.cpp:459-501): a size that is stated and differs from the image is a mismatched pair
+    if (camera_info->width != 0 && camera_info->height != 0 && (camera_info->width != frame->width || camera_info->height != frame->height)) {
       ROS_ERROR_THROTTLE(5.0, "input_depth: camera_info is for %ux%u, the image is %ux%u", camera_info->width, camera_info->height, frame->width, frame->height);
       return;
     }
@@ -148,8 +150,8 @@ class RosFilter {
       pixels = dense_.data();
     }
     CameraInfo info;
-    info.width = (int)camera_info->width;
-    info.height = (int)camera_info->height;
+    info.width = (int)frame->width;
+    info.height = (int)frame->height;
     for (int i = 0; i < 12; i++) info.P[i] = camera_info->P[i];
     double projection[16];
     filter_->getProjectionMatrix(info, projection);

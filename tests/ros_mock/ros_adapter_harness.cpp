@@ -87,6 +87,8 @@ int main(int argc, char** argv)
   // RTUF_MOCK_INFO_WIDTH=<w>: a camera_info that belongs to another image size.  The adapter must refuse both, not read on.
   if (const char* cut = std::getenv("RTUF_MOCK_SHORT_IMAGE")) image->data.resize(image->data.size() - (size_t)std::atoi(cut));
   if (const char* iw = std::getenv("RTUF_MOCK_INFO_WIDTH")) info->width = (uint32_t)std::atoi(iw);
+  // RTUF_MOCK_INFO_UNSIZED=1: a driver that leaves camera_info's width / height at 0 (only K / P filled in): the frame must be filtered
+  if (std::getenv("RTUF_MOCK_INFO_UNSIZED")) info->width = info->height = 0;
   topics["input_depth"].callback(image, info);
 
   for (const std::string& l : ros::mock_log()) std::printf("log %s\n", l.c_str());

@@ -100,6 +100,16 @@ def test_malformed_messages_are_refused_before_anything_is_read(tmp_path, env, w
 
 
 @pytest.mark.gpu
+def test_camera_info_without_a_size_is_filtered_like_the_reference_would(tmp_path):
+    """Some drivers leave camera_info.width / height at 0; the reference reads only K / P from the message
+    (src/urdf_filter.cpp:459-501) and filters such frames: so does the adapter, with the image's own size."""
+    fx = golden_io.Fixture("example_urdf_640x480")
+    r = run(tmp_path, fx.depth.astype(np.float32), "32FC1", "both", env={"RTUF_MOCK_INFO_UNSIZED": "1"})
+    assert r.returncode == 0 and "published depth 1 mask 1" in r.stdout and "log " not in r.stdout, (r.stdout, r.stderr)
+    fx.check(np.fromfile(tmp_path / "o.depth", np.float32).reshape(480, 640), np.fromfile(tmp_path / "o.mask", np.uint8).reshape(480, 640))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("encoding,mode", [("16UC1", "both"), ("16UC1", "mask_only"), ("32FC1", "mask_only"), ("32FC1", "both")])
 def test_callback_width_that_is_not_a_multiple_of_four(tmp_path, encoding, mode):
     """A 322-pixel-wide camera: the fused 16UC1 kernels and the bit-packed mask need width % 4 == 0, so the facade takes such
