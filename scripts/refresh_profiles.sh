@@ -4,7 +4,7 @@
 #   bench.py reads: pmc_counters.json, valu_peak.json; llvmpipe_baseline.json comes from the development container)
 # rocprofv3 passes are separate runs: --kernel-trace --stats, then one --pmc pass per counter group (never together
 # with other trace domains).
-tag=${1:-r04}
+tag=${1:-r05}
 export TMPDIR=/tmp
 root=$PWD
 out=$root/gpurun_out/profiles
@@ -18,7 +18,9 @@ PROF_ARGS="--steps 20 --min-seconds 0 --cpu-seconds 0 --check-frames 0 --lanes 1
 # ---- 1. bench lines ---------------------------------------------------------------------------------------------
 Q="--cpu-seconds 0 --host-copy-seconds 0 --min-seconds 3"       # the side lines: no CPU legs, no host-plane legs, 3 s timed
 $B $Q > /dev/null 2> $out/bench.err      # first run on a fresh box is the slowest: warm-up
+t0=$(date +%s.%N)
 $B > $out/${tag}_bench.json 2>> $out/bench.err                   # THE line: defaults, exactly what the driver runs
+echo "python bench.py (defaults, second run on this box): $(python -c "print(round($(date +%s.%N) - $t0, 1))") s wall" > $out/${tag}_bench_wall_time.txt
 $B $Q --lanes 1 > $out/${tag}_bench_one_lane.json 2>> $out/bench.err
 $B $Q --lanes 2 > $out/${tag}_bench_two_lanes.json 2>> $out/bench.err
 $B $Q --launch-group 43 > $out/${tag}_bench_groups_of_43.json 2>> $out/bench.err
@@ -61,18 +63,22 @@ pmc() {     # output file, bench args, counters...
   { echo "## $*"; python $root/scripts/pmc_summary.py $(find /tmp/rp -name '*counter_collection.csv' | head -1); } >> $f
 }
 hdr="# rocprofv3 --kernel-trace --pmc <group> (one pass per '##' group), command: python bench.py $PROF_ARGS"
-for mode in "" "--two-kernel" "--two-kernel --streams 1024" "--workload c4 --shard-of 8"; do
+for mode in "" "--two-kernel" "--two-kernel --streams 1024" "--workload c4 --shard-of 8" "--near-arm"; do
   suffix=$(echo "$mode" | sed 's/--//g; s/ /_/g; s/-/_/g'); suffix=${suffix:+_$suffix}
   f=$out/${tag}_pmc${suffix}.txt
   echo "$hdr $mode   (values per launch, averaged over the launches of the run; FETCH_SIZE / WRITE_SIZE in KiB)" > $f
   pmc $f "$mode" FETCH_SIZE
   pmc $f "$mode" WRITE_SIZE
-  if [ "$mode" = "--workload c4 --shard-of 8" ]; then pmc $f "$mode" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES; fi
+  if [ "$mode" = "--workload c4 --shard-of 8" ] || [ "$mode" = "--near-arm" ]; then
+    pmc $f "$mode" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES
+    pmc $f "$mode" SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES
+  fi
   if [ -z "$mode" ]; then
     pmc $f "$mode" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES
     pmc $f "$mode" SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES
     pmc $f "$mode" SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM
     pmc $f "$mode" SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY
+    pmc $f "$mode" SQ_THREAD_CYCLES_VALU
   fi
 done
 
@@ -92,6 +98,7 @@ for k, v in agg.items():
     print("%-34s SQ_INSTS_VALU %.4g  SQ_ACTIVE_INST_VALU %.4g  ratio %.3f" % (k.split("(")[0], i, a, a / i if i else 0))
 PY
 cd $root
+bash scripts/lane_util.sh > $out/${tag}_lanes.json 2> $out/lanes.err
 python scripts/pmc_to_json.py $out $tag > $out/pmc_to_json.log 2>&1
 python scripts/valu_mix.py $out/valu_peak.json > $out/valu_mix.log 2>&1 || true
 (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5) > $out/${tag}_gpu_tests.txt
