@@ -600,6 +600,10 @@ def main():
                         mp = (valu_peak.get("static_mix_peak_G_per_s") or {}).get(name)
                         if mp:
                             vi.update({"static_mix_peak_G_per_s": mp, "frac_of_static_mix_peak": g / mp})
+                    if rec.get("live_lane_fraction"):
+                        # SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64): of the 64 lanes an issued VALU instruction could
+                        # serve, how many were live (divergent walks; profiles/r05_pmc_lanes.txt has it per loop)
+                        vi["live_lane_fraction"] = rec["live_lane_fraction"]
                     e["valu_issue"] = vi
             return e
 

@@ -1757,28 +1757,6 @@ __device__ __forceinline__ void strip_walk(unsigned long long* keys, const TriRe
 // that lie behind it over their whole part of the tile are dropped when they are loaded.  MODE 1 looks only at records the
 // set-up marked as near (kNearBit) and, of those, only at the ones that can reach the lower half of the depth range here.
 
-// Sort key of a record for the walks below: how many trips its walk takes in this tile.  Records of one window (the
-// workgroup's 256) are dealt to the waves in the order of this key, so that the lanes of a wave -- whose lane-per-triangle
-// walk runs until its LARGEST box is done -- hold boxes of the same size (measured before: 48 % of the lanes live per quad
-// trip on the 256-stream VGA workload, 40 % with the arm in front of the lens; profiles/r05_pmc_lanes.txt).
-//   0          nothing of the box lies in this tile
-//   1 .. 47    lane-per-triangle class: quad trips
-//   48 .. 61   quarter-wave class: trips of 16 vertical pairs
-//   62         larger boxes (whole-wave / parked walks);  63  no record
-__device__ __forceinline__ uint32_t walk_key(int w, int h)
-{
-  if (w <= 0 || h <= 0) return 0u;
-  const int area = w * h;
-  if (area <= kSmallArea) return (uint32_t)min(((w + 1) >> 1) * ((h + 1) >> 1), 47);
-  if (area <= kQuarterArea) return 48u + (uint32_t)min((w * ((h + 1) >> 1) + 15) >> 4, 13);
-  return 62u;
-}
-
-#ifndef RTUF_SORT_WALK
-#define RTUF_SORT_WALK 0          // (1: A/B switch -- windows sorted by box size before the walks; measured slower)
-#endif
-constexpr int kSortWords = 128 + kTileThreads;      // two histograms of 64 keys (windows alternate) + the window's permutation
-
 template <int MODE, bool LOW>
 __device__ __forceinline__ void raster_bin(unsigned long long* keys, const PackedTri* recs, uint32_t n,
                                            int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, uint32_t n_front, uint32_t capacity,
@@ -1787,55 +1765,14 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
 {
   const int lane = tid & 63;
   const uint32_t zdrop = MODE == 1 ? min(zcover, kf.zexact - 1u) : zcover;      // MODE 1: only what can reach a depth that needs the pass
-  // (the sort's scratch lives where the parked records go AFTER this loop's closing barrier; the caller zeroed the histograms)
-  uint32_t* const s_hist = reinterpret_cast<uint32_t*>(s_prec);
-  uint32_t* const s_perm = s_hist + 128;
-  static_assert(kSortWords * 4 <= (int)sizeof(TriRec) * 64, "the sort's scratch must fit the parked-record area");
+  // (round 5 measured two ways of balancing the walks here and took both out again: windows sorted by box size, branch
+  // sorted-walk-experiment -- fewer trips, slower for its barriers; records behind the cover compacted through a per-wave queue
+  // before the unpack, branch cover-compaction-experiment -- fuller waves, slower for its second load.  DESIGN.md A.5)
   for (uint32_t base = 0; base < n; base += kTileThreads) {
-    uint32_t i = base + tid;
+    const uint32_t i = base + tid;
     bool have = i < n;
-    uint32_t ri = i < n_front ? i : capacity - 1u - (i - n_front);      // small boxes from the front, larger ones from the back
-    // A window that more than one wave holds records of is SORTED by the size of the boxes first (uniform decision).  Phase A:
-    // every lane takes the coordinates of record i (16 of its 32 bytes), clips the box to the tile and ranks its key in the
-    // workgroup's histogram; phase B: lane t takes the record at sorted position t (a second 32-byte load, a cache hit).
-    const bool sorted = RTUF_SORT_WALK && MODE == 0 && n - base > 64u;
-    bool first_in_regs = have_first && base == 0u;
-    if (sorted) {
-      uint32_t key = 63u;
-      if (have) {
-        const uint4 c4 = first_in_regs ? first0 : *reinterpret_cast<const uint4*>(recs + ri);
-        const unsigned long long v01 = ((unsigned long long)c4.y << 32) | c4.x, v12 = ((unsigned long long)c4.w << 32) | c4.z;
-        const int x0 = (int)(v01 & 0xfffffu) - kCoordBias, y0 = (int)((v01 >> 20) & 0xfffffu) - kCoordBias, x1 = (int)((v01 >> 40) & 0xfffffu) - kCoordBias;
-        const int y1 = (int)(v12 & 0xfffffu) - kCoordBias, x2 = (int)((v12 >> 20) & 0xfffffu) - kCoordBias, y2 = (int)((v12 >> 40) & 0xfffffu) - kCoordBias;
-        const int minx = min(x0, min(x1, x2)), maxx = max(x0, max(x1, x2));
-        const int miny = min(y0, min(y1, y2)), maxy = max(y0, max(y1, y2));
-        // (as edges_from_snapped, then clipped to the tile like the walks do)
-        const int bx0 = max((minx + 255) >> 8, 0), bx1 = min((maxx - 1) >> 8, width - 1);
-        const int by0 = max((miny + 255) >> 8, 0), by1 = min((maxy - 1) >> 8, height - 1);
-        const int w = min(bx1 - x_base, kTileW - 1) - max(bx0 - x_base, 0) + 1, h = min(by1 - y_base, kTileH - 1) - max(by0 - y_base, 0) + 1;
-        key = walk_key(w, h);
-      }
-      const uint32_t win = (base / kTileThreads) & 1u;
-      const uint32_t rank = atomicAdd(&s_hist[win * 64u + key], 1u);
-      if (tid < 64) s_hist[(win ^ 1u) * 64u + tid] = 0u;        // the next window's histogram (nobody touches it in this one)
-      __syncthreads();
-      // every wave scans the 64 counts itself (no second barrier for a table of bases)
-      const uint32_t cnt = s_hist[win * 64u + lane];
-      uint32_t incl = cnt;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += up; }
-      const uint32_t first_of_key = (uint32_t)__shfl((int)(incl - cnt), (int)key);
-      s_perm[first_of_key + rank] = (uint32_t)tid;
-      __syncthreads();
-#ifdef RTUF_SORT_FAKE              // (timing experiments: everything the sort costs, none of what it gives; 2: with a gather of the records as well)
-      i = base + (s_perm[tid] & 0u) + (RTUF_SORT_FAKE == 2 ? (__brev((uint32_t)tid) >> 24) : (uint32_t)tid);
-#else
-      i = base + s_perm[tid];
-#endif
-      have = i < n;
-      ri = i < n_front ? i : capacity - 1u - (i - n_front);
-      first_in_regs = false;
-    }
+    const uint32_t ri = i < n_front ? i : capacity - 1u - (i - n_front);      // small boxes from the front, larger ones from the back
+    const bool first_in_regs = have_first && base == 0u;
     TriRec r;
     int lx0 = 0, lx1 = -1, ly0 = 0, ly1 = -1;
     PackedTri pk;
@@ -1954,8 +1891,11 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     // 16 columns of a record's part of the tile over all its rows (a wider record is dealt out as two to four strips, to
     // neighbouring teams or successive rounds); its lanes step down the rows (strip_walk).  With three and more records waiting
     // a round deals four strips to the four quarters of the wave; the last two share the wave half and half, a single one gets
-    // all 64 lanes (16 columns x 4 rows per step) -- on the 256-stream VGA workload nearly every round is of that kind (a
-    // wave-load there holds one such record in four).  The record travels from the lane that loaded it with 15 shuffles.
+    // all 64 lanes (16 columns x 4 rows per step).  The record travels from the lane that loaded it with 15 shuffles.
+    // Taken in tiles with near geometry only (RTUF_STRIP_WALK = 2: the LOW instance and the exact-z pass), where such records
+    // come by the dozen per wave-load and the rounds are full: tile kernel 1.117 -> 1.07 ms with the arm in front of the lens.
+    // Elsewhere a wave-load holds one such record in four, a round is one strip, and the pair runs below measure the same or
+    // better (C3 +0.5 %, C4 / C5 shares +-0.5 %: profiles/r05_experiment_strips.txt).
     {
       unsigned long long big = __ballot(area > kSmallArea && (area <= kQuarterArea || ((huge >> lane) & 1ull) != 0ull));
       const int nstrip = (lx1 - lx0 + 16) >> 4;
@@ -2360,7 +2300,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       for (int i = tid; i < kKeyCount; i += kTileThreads) keys[i] = bgkey;
     }
     if (tid == 0) { s_huge[0] = 0; s_huge[1 + kHugeMax] = n <= (uint32_t)kParkBelow ? (uint32_t)kQuarterArea : (uint32_t)kWallArea; }
-    if (RTUF_SORT_WALK && tid < 128) reinterpret_cast<uint32_t*>(s_prec)[tid] = 0u;      // raster_bin's sort histograms
 #ifdef RTUF_COUNT
     if (tid < 2) count_words()[tid] = 0u;
 #endif

@@ -73,6 +73,9 @@ def main():
             e["wave64_valu_instructions_per_launch"] = c["SQ_INSTS_VALU"]
         if c.get("SQ_INSTS_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
             e["active_over_insts"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"]
+        if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
+            # rocprofv3's derived VALUUtilization: lanes live per issued VALU instruction (a kernel with every lane on reads 1.000)
+            e["live_lane_fraction"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
         return e
 
     def add(a, b):
