@@ -1694,9 +1694,6 @@ __device__ __forceinline__ void raster_pair(unsigned long long* keys, const TriR
 // integers: exact), so fma(dzdy, py, .) sees the operands fragment() gives it.  A trip costs 16 VALU instructions for 2 x 2^team_log
 // candidates where the linear run of pairs it replaces (raster_pair: index -> column / row by a reciprocal multiply, six 24-bit
 // multiplies per pair) took 42.  EDGES = false: the caller knows that every candidate is covered (classify_box == 2).
-#ifndef RTUF_STRIP_INTROW
-#define RTUF_STRIP_INTROW 0
-#endif
 #ifndef RTUF_STRIP_WALK
 #define RTUF_STRIP_WALK 2          // (A/B switch -- 0: quarter-wave and whole-wave walks as linear runs of candidate pairs, as up to round 4; 2: strips only in tiles with near geometry)
 #endif
@@ -1717,21 +1714,6 @@ __device__ __forceinline__ void strip_walk(unsigned long long* keys, const TriRe
     d0 = (int)((uint32_t)q.B[0] << lr); d1 = (int)((uint32_t)q.B[1] << lr); d2 = (int)((uint32_t)q.B[2] << lr);
   }
   const float zc = __fmaf_rn(q.dzdx, (float)px, q.a0);
-#if RTUF_STRIP_INTROW            // (A/B switch: the row as an integer, converted per depth test -- three registers fewer, one conversion more per test)
-  int yy = py;
-  const int rpt = 1 << lr;
-  int lidx = (qy0 + row0) * kKeyStride + qx0 + col;
-  while (__ballot(nrow > 0)) {
-    if (MODE == 0) RTUF_LANES(lc_trip, nrow > 0);
-    const int f0 = e0 + d0, f1 = e1 + d1, f2 = e2 + d2;
-    if (nrow > 0 && (!EDGES || min(e0, min(e1, e2)) > 0)) depth_test<MODE, LOW>(keys, q.order, __fmaf_rn(q.dzdy, (float)yy, zc), lidx, kf, lc_frag);
-    if (nrow > 1 && (!EDGES || min(f0, min(f1, f2)) > 0)) depth_test<MODE, LOW>(keys, q.order, __fmaf_rn(q.dzdy, (float)(yy + rpt), zc), lidx + rpt * kKeyStride, kf, lc_frag);
-    e0 = f0 + d0; e1 = f1 + d1; e2 = f2 + d2;
-    yy += 2 * rpt;
-    lidx += 2 * rpt * kKeyStride;
-    nrow -= 2;
-  }
-#else
   float fy = (float)py;
   const float dfy = (float)(1 << lr);
   int lidx = (qy0 + row0) * kKeyStride + qx0 + col;
@@ -1746,7 +1728,6 @@ __device__ __forceinline__ void strip_walk(unsigned long long* keys, const TriRe
     lidx += 2 * dl;
     nrow -= 2;
   }
-#endif
 }
 
 // Rasterises the bin's records into the LDS key tile.  Every wave works on the records it loaded:
@@ -2354,7 +2335,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       const unsigned long long k = keys[i];
       if (k != bgkey && (uint32_t)(k >> 32) < kf.zexact) need = true;
     }
-    if (__syncthreads_or(need)) {
+    if (__syncthreads_or(need) && !RTUF_ABL(a.flags, 0x4000000u)) {      // (0x4000000: timing experiment, no exact-z pass)
       // which draw-order keys won such a pixel: only their records are walked again
       if (tid < kWinnerWords) s_winners[tid] = 0u;
       if (tid == 0) atomicAdd(&a.counters->shard[bin % kCounterShards].exact_tiles, 1u);
