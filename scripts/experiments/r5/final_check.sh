@@ -3,7 +3,7 @@
 out=gpurun_out/r5z; mkdir -p $out
 (timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4) | tee $out/gpu_tests.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $out/smoke.txt
-t0=$(date +%s.%N); python bench.py > $out/bench.json 2> $out/bench.err; t1=$(date +%s.%N)
+t0=$(date +%s.%N); python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; t1=$(date +%s.%N)
 python - $out/bench.json $t0 $t1 <<'PY' | tee $out/bench_summary.txt
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
