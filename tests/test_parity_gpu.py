@@ -373,6 +373,68 @@ def test_small_triangles_closer_than_twice_the_near_plane():
         assert ctx.stats()["fragments_binned"] > 1000
         ctx.close()
 
+@pytest.mark.parametrize("size,per_cluster", [((517, 389), 1), ((517, 389), 2), ((640, 480), 6), ((322, 242), 12)])
+def test_large_near_triangles_of_every_shape_walked_as_strips(size, per_cluster):
+    """Round 5's strip walk (tile kernel: records of more than 96 pixels in tiles with near geometry are cut into strips of 16
+    columns whose lanes step down the rows) against the oracle on the shapes that decide its geometry: slivers one to three
+    pixels wide and a tile tall, flats a tile wide and two pixels high, boxes of 10-60 pixels a side, triangles larger than a
+    tile -- all closer than twice the near plane (window z <= 0.5: the tiles' keys carry the float's low bits, the path the
+    strips are compiled into), one, two, six or twelve to a neighbourhood (a wave's round deals one strip to all 64 lanes, two to
+    32 each, four to 16 each), at frame sizes whose last tile column and row are partial."""
+    W, H = size
+    rng = np.random.default_rng(1000 * per_cluster + W)
+    f = 525.0 * W / 640
+    P = S.projection(f, f, (W - 1) / 2, (H - 1) / 2, W, H)
+    verts, n_tri = [], 0
+    def tri_px(cx, cy, z, pts):               # a triangle from pixel offsets around (cx, cy) at eye depth z (camera looks along +z)
+        out = []
+        for (dx, dy, dz) in pts:
+            zz = z + dz
+            out.append([(cx + dx - (W - 1) / 2) * zz / f, (cy + dy - (H - 1) / 2) * zz / f, zz])
+        return out
+    shapes = []
+    for _ in range(260 // per_cluster):
+        cx, cy = rng.uniform(0, W), rng.uniform(0, H)
+        for _ in range(per_cluster):
+            z = rng.uniform(0.103, 0.19)
+            kind = rng.integers(0, 5)
+            ox, oy = rng.uniform(-20, 20, 2)
+            if kind == 0:      # vertical sliver
+                w, h = rng.uniform(0.8, 3.0), rng.uniform(20, 40)
+                pts = [(ox, oy, 0.0), (ox + w, oy + rng.uniform(0, 3), rng.uniform(-0.01, 0.01)), (ox + rng.uniform(0, w), oy + h, rng.uniform(-0.02, 0.02))]
+            elif kind == 1:    # horizontal flat
+                w, h = rng.uniform(40, 90), rng.uniform(1.2, 3.0)
+                pts = [(ox, oy, 0.0), (ox + w, oy + rng.uniform(0, h), rng.uniform(-0.02, 0.02)), (ox + rng.uniform(0, w), oy + h, rng.uniform(-0.01, 0.01))]
+            elif kind == 4:    # larger than a tile
+                pts = [(ox - rng.uniform(40, 90), oy - rng.uniform(20, 50), rng.uniform(-0.03, 0.03)), (ox + rng.uniform(40, 90), oy - rng.uniform(-10, 30), rng.uniform(-0.03, 0.03)), (ox + rng.uniform(-30, 30), oy + rng.uniform(30, 70), rng.uniform(-0.03, 0.03))]
+            else:              # boxes of 10-60 pixels a side
+                a, b = rng.uniform(10, 60, 2)
+                pts = [(ox, oy, 0.0), (ox + a, oy + rng.uniform(-5, 5), rng.uniform(-0.02, 0.02)), (ox + rng.uniform(-5, 5), oy + b, rng.uniform(-0.02, 0.02))]
+            verts += tri_px(cx, cy, z, pts)
+            n_tri += 1
+    verts = np.asarray(verts, np.float32)
+    tris = np.arange(3 * n_tri, dtype=np.uint32).reshape(-1, 3)
+    depth = S.sensor_depth(W, H, 0.4)
+    depth[::3] = np.float32(0.15)             # sensor values among the rendered depths: both mask outcomes occur
+    I = S.gl(np.eye(4))
+    om, ok, zwin, prim, _ = O.filter_frame(depth, P, [(I, 0, [0.0, 0.0, 0.0], verts, tris)], I, I, replace_value=5.0, want_debug=True)
+    assert ((zwin <= 0.5) & (prim > 0)).mean() > 0.3                       # the frame is mostly near geometry
+    for two_kernel in (False, True):
+        ctx = R.Context(W, H, 2, 0, params(5.0, 0.05, two_kernel))
+        m = ctx.add_model()
+        ctx.add_draw(m, ctx.add_link(m), verts, tris, 0, [0.0, 0.0, 0.0])
+        ctx.finalize_models()
+        for s in range(2):
+            ctx.set_camera(s, P, I, I)
+            ctx.set_link_poses(s, m, np.stack([I]))
+        masked, mask = ctx.filter_batch(np.stack([depth, depth]))
+        for s in range(2):
+            assert (ok != mask[s]).sum() == 0 and bits_equal(om, masked[s]), (size, per_cluster, two_kernel, s, int((ok != mask[s]).sum()))
+        if two_kernel:
+            assert bits_equal(ctx.read_zsurface(2)[1], zwin)
+        ctx.close()
+
+
 
 def test_cpp_facade_example_matches_reference(tmp_path):
     """examples/example_filter.cpp: the reference's single-camera C++ usage on the facade classes
