@@ -160,6 +160,41 @@ def cases():
 
     # 7. nothing but the background quad
     out.append(Case("background_only_160x120", W, H, S.sensor_depth(W, H, 1.3), P, []))
+
+    # 8. (round 5) large triangles closer than twice the near plane, at a frame size whose last tile column and row are partial:
+    #    slivers one to three pixels wide and a tile tall, flats a tile wide and two pixels high, boxes of 10-60 pixels a side,
+    #    triangles larger than a 64x32 tile, in pairs -- the shapes the HIP tile kernel walks as row-stepped strips
+    W8, H8 = 517, 389
+    f8 = 525.0 * W8 / 640
+    P8 = S.projection(f8, f8, (W8 - 1) / 2, (H8 - 1) / 2, W8, H8)
+    rng = np.random.default_rng(2517)
+    v8 = []
+    def px(cx, cy, z, pts):
+        return [[(cx + dx - (W8 - 1) / 2) * (z + dz) / f8, (cy + dy - (H8 - 1) / 2) * (z + dz) / f8, z + dz] for dx, dy, dz in pts]
+    for _ in range(130):
+        cx, cy = rng.uniform(0, W8), rng.uniform(0, H8)
+        for _ in range(2):
+            z = rng.uniform(0.103, 0.19)
+            kind = rng.integers(0, 5)
+            ox, oy = rng.uniform(-20, 20, 2)
+            if kind == 0:
+                w, h = rng.uniform(0.8, 3.0), rng.uniform(20, 40)
+                pts = [(ox, oy, 0.0), (ox + w, oy + rng.uniform(0, 3), rng.uniform(-0.01, 0.01)), (ox + rng.uniform(0, w), oy + h, rng.uniform(-0.02, 0.02))]
+            elif kind == 1:
+                w, h = rng.uniform(40, 90), rng.uniform(1.2, 3.0)
+                pts = [(ox, oy, 0.0), (ox + w, oy + rng.uniform(0, h), rng.uniform(-0.02, 0.02)), (ox + rng.uniform(0, w), oy + h, rng.uniform(-0.01, 0.01))]
+            elif kind == 4:
+                pts = [(ox - rng.uniform(40, 90), oy - rng.uniform(20, 50), rng.uniform(-0.03, 0.03)), (ox + rng.uniform(40, 90), oy - rng.uniform(-10, 30), rng.uniform(-0.03, 0.03)),
+                       (ox + rng.uniform(-30, 30), oy + rng.uniform(30, 70), rng.uniform(-0.03, 0.03))]
+            else:
+                a, b = rng.uniform(10, 60, 2)
+                pts = [(ox, oy, 0.0), (ox + a, oy + rng.uniform(-5, 5), rng.uniform(-0.02, 0.02)), (ox + rng.uniform(-5, 5), oy + b, rng.uniform(-0.02, 0.02))]
+            v8 += px(cx, cy, z, pts)
+    v8 = np.asarray(v8, np.float32)
+    t8 = np.arange(len(v8), dtype=np.uint32).reshape(-1, 3)
+    d8 = S.sensor_depth(W8, H8, 0.4)
+    d8[::3] = np.float32(0.15)
+    out.append(Case("near_large_shapes_517x389", W8, H8, d8, P8, [(S.gl(np.eye(4)), [("mesh", 0, (0, 0, 0), v8, t8)])], max_diff=0.01))
     return out
 
 
