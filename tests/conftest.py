@@ -25,3 +25,33 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+_paged_in = set()
+
+
+def page_in_rccl():
+    """Reads the RCCL libraries once, front to back, before a test starts a process that links them.
+
+    librccl.so is 0.3-0.6 GB of code objects for every GPU target; on a fresh box its first use faults it in page by page from
+    the image store, and `ncclCommInitAll` (which loads the kernels of this GPU) has been seen to take more than ten minutes
+    that way on some boxes and five seconds on others -- a test that starts RCCL then fails on its time-out, or appears to
+    hang, for reasons that have nothing to do with the code under test.  One sequential read (read-ahead: seconds) takes that
+    out of the picture; the tests' own time-outs stay as they are."""
+    candidates = ["/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"]
+    try:
+        import torch
+        candidates.append(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+    except Exception:
+        pass
+    for path in candidates:
+        real = os.path.realpath(path)
+        if real in _paged_in or not os.path.isfile(real):
+            continue
+        _paged_in.add(real)
+        try:
+            with open(real, "rb", buffering=0) as f:
+                while f.read(16 << 20):
+                    pass
+        except OSError:
+            pass

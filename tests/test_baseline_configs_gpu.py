@@ -244,6 +244,8 @@ def _multi_gpu_example():
     exe = os.path.join(root, "examples", "bin", "multi_gpu_filter")
     if not os.path.exists(exe):
         subprocess.check_call([os.path.join(root, "realtime_urdf_filter_amd", "csrc", "build_facade.sh")])
+    from conftest import page_in_rccl
+    page_in_rccl()              # (the example links librccl: see conftest.page_in_rccl)
     return exe
 
 

@@ -91,6 +91,8 @@ def test_bench_nccl_world1():
     """torch.distributed.run with ONE rank and the real backend: bench.py's RCCL lines -- init_process_group("nccl"), the
     barriers, the MAX all-reduces and the all-gathers of the per-rank counts -- execute on hardware (the test box has one
     GPU; the two-rank rehearsals below share it over gloo)."""
+    from conftest import page_in_rccl
+    page_in_rccl()
     env = {k: v for k, v in os.environ.items() if k not in ("RTUF_BENCH_BACKEND", "RTUF_BENCH_DEVICE")}
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL
