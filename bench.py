@@ -232,6 +232,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            # torch's librccl.so is a third of a gigabyte of code objects; on a fresh box its first use faults it in page by
+            # page (communicator set-up has been seen to take ten minutes that way).  One sequential read first: seconds.
+            try:
+                with open(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "rb", buffering=0) as f:
+                    while f.read(16 << 20):
+                        pass
+            except OSError:
+                pass
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
