@@ -25,6 +25,7 @@
 // is an explicit __f*_rn intrinsic, and the file is built with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "rtuf_device.h"
 
@@ -1738,7 +1739,7 @@ __device__ __forceinline__ void strip_walk(unsigned long long* keys, const TriRe
 // that lie behind it over their whole part of the tile are dropped when they are loaded.  MODE 1 looks only at records the
 // set-up marked as near (kNearBit) and, of those, only at the ones that can reach the lower half of the depth range here.
 
-template <int MODE, bool LOW>
+template <int MODE, bool LOW, int NT>
 __device__ __forceinline__ void raster_bin(unsigned long long* keys, const PackedTri* recs, uint32_t n,
                                            int x_base, int y_base, int tid, bool dbg_load_only, int width, int height, uint32_t n_front, uint32_t capacity,
                                            uint32_t* s_huge, TriRec* s_prec, uint4* s_pmeta, uint32_t zcover, const uint32_t* s_winners, const KeyFmt& kf,
@@ -1749,7 +1750,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
   // (round 5 measured two ways of balancing the walks here and took both out again: windows sorted by box size, branch
   // sorted-walk-experiment -- fewer trips, slower for its barriers; records behind the cover compacted through a per-wave queue
   // before the unpack, branch cover-compaction-experiment -- fuller waves, slower for its second load.  DESIGN.md A.5)
-  for (uint32_t base = 0; base < n; base += kTileThreads) {
+  for (uint32_t base = 0; base < n; base += NT) {
     const uint32_t i = base + tid;
     bool have = i < n;
     const uint32_t ri = i < n_front ? i : capacity - 1u - (i - n_front);      // small boxes from the front, larger ones from the back
@@ -2041,7 +2042,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
         // (the same two roundings as fragment()), the 24-bit conversion and the LDS atomic
         const int px = x_base + lane;
         const float zc = __fmaf_rn(q.dzdx, (float)px, q.a0);
-        for (int ly = qy0 + (tid >> 6); ly <= qy1; ly += kTileThreads / 64) {
+        for (int ly = qy0 + (tid >> 6); ly <= qy1; ly += NT / 64) {
           if (MODE == 0) { RTUF_LANES(kLaneParkTrip, true); RTUF_LANES(kLaneParkFrag, true); }
           const float z = __fmaf_rn(q.dzdy, (float)(y_base + ly), zc);
           const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | (LOW ? (q.order | (__float_as_uint(z) & kf.lowmask)) : q.order);
@@ -2054,7 +2055,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
           }
         }
       } else if (inside) {
-        for (int idx = tid; idx < npair; idx += kTileThreads) {
+        for (int idx = tid; idx < npair; idx += NT) {
           if (MODE == 0) RTUF_LANES(kLaneParkTrip, true);
           const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
           const int lx = qx0 + idx - __mul24(yy, qw), ly = qy0 + 2 * yy;
@@ -2063,7 +2064,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
           if (ly < qy1) fragment<MODE, LOW>(keys, q, x_base + lx, y_base + ly + 1, lidx + kKeyStride, kf, kLaneParkFrag);
         }
       } else {
-        for (int idx = tid; idx < npair; idx += kTileThreads) {
+        for (int idx = tid; idx < npair; idx += NT) {
           if (MODE == 0) RTUF_LANES(kLaneParkTrip, true);
           const int yy = (int)((uint32_t)__mul24(idx, (int)inv) >> 20);
           raster_pair<MODE, LOW>(keys, q, x_base, y_base, qx0 + idx - __mul24(yy, qw), qy0 + 2 * yy, qy1, kf, kLaneParkFrag);
@@ -2083,19 +2084,21 @@ constexpr int kFragUnroll = RTUF_FRAG_UNROLL;
 // trip, ALL their loads issued before the first is used: the loop used to be load -> wait -> one LDS atomic, one exposed
 // global-memory latency per 256 fragments of a tile (a tile of the headline workload holds ~1,000): tile kernel 297 -> 285 us.
 // The first trip's loads are issued by the caller before the key tile is initialised (load_frags / apply_frags).
+template <int NT>
 __device__ __forceinline__ void load_frags(unsigned long long (&f)[kFragUnroll], const unsigned long long* frags, uint32_t nf, uint32_t base, int tid)
 {
 #pragma unroll
   for (int u = 0; u < kFragUnroll; u++) {
-    const uint32_t i = base + (uint32_t)u * kTileThreads + (uint32_t)tid;
+    const uint32_t i = base + (uint32_t)u * NT + (uint32_t)tid;
     f[u] = i < nf ? frags[i] : ~0ull;
   }
 }
+template <int NT>
 __device__ __forceinline__ void apply_frags(unsigned long long* keys, const unsigned long long (&f)[kFragUnroll], uint32_t nf, uint32_t base, int tid, uint32_t zcover, int shift)
 {
 #pragma unroll
   for (int u = 0; u < kFragUnroll; u++) {
-    const uint32_t i = base + (uint32_t)u * kTileThreads + (uint32_t)tid;
+    const uint32_t i = base + (uint32_t)u * NT + (uint32_t)tid;
     const int fpos = (int)((uint32_t)f[u] & ((1u << kFragPosBits) - 1u));      // row * kTileW + column, as the set-up kernel wrote it
     const int lidx = RTUF_KEY_PAD ? fpos + (fpos / kTileW) * RTUF_KEY_PAD : fpos;
     const unsigned long long key = ((f[u] >> 40) << 32) | (((uint32_t)(f[u] >> kFragPosBits) & kMaxOrder) << shift);
@@ -2158,7 +2161,7 @@ __device__ __forceinline__ float shade(float sensor, float z, const ShadeConsts&
 
 // COVER: the batch ran the cover pass (bigrec_kernel<0>), so a bin's header may name a cover.  Without it (the host skips the
 // pass while no scene has triangles that cover whole tiles) the cover code is compiled out: it costs the headline workload 3 %.
-template <bool TWO_KERNEL, bool U16, bool BITS, bool COVER>
+template <bool TWO_KERNEL, bool U16, bool BITS, bool COVER, int NT>
 __device__ __forceinline__ void tile_body(const TileArgs& a)
 {
   __shared__ unsigned long long keys[kKeyCount];
@@ -2211,7 +2214,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   // latency is all there is to such a tile); a tile with geometry requests them after the rasterisation: eight registers
   // held across the walks do not fit the kernel's 80-register budget (they spill, and the spill waits for the load), and
   // requesting them early AND late costs more in traffic than the early request hides (both measured, profiles/README.md).
-  constexpr int kLanesPerRow = kTileW / 4, kRowsPerPass = kTileThreads / kLanesPerRow;
+  constexpr int kLanesPerRow = kTileW / 4, kRowsPerPass = NT / kLanesPerRow;
   constexpr int kPasses = (kTileH + kRowsPerPass - 1) / kRowsPerPass;      // resolve passes per tile (2 for 64x32)
   const bool vec = (a.width & 3) == 0;
   const int r_ly0 = tid / kLanesPerRow, r_lx = (tid % kLanesPerRow) * 4;
@@ -2269,16 +2272,16 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       first_rec0 = src[0]; first_rec1 = src[1];
     }
     unsigned long long first_frags[kFragUnroll];
-    if (RTUF_PRELOAD) load_frags(first_frags, frags, nf, 0u, tid);
+    if (RTUF_PRELOAD) load_frags<NT>(first_frags, frags, nf, 0u, tid);
     if (has_cover) {
       const CoverPlane c = cover_plane();
-      for (int i = tid; i < kKeyCount; i += kTileThreads) {        // (padding columns, if any, hold the background key: the scans below skip them like any pixel nothing was drawn to)
+      for (int i = tid; i < kKeyCount; i += NT) {        // (padding columns, if any, hold the background key: the scans below skip them like any pixel nothing was drawn to)
         const float z = __fmaf_rn(c.dzdy, (float)(y_base + i / kKeyStride), __fmaf_rn(c.dzdx, (float)(x_base + i % kKeyStride), c.a0));
         const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | (c.order << kf.shift) | (__float_as_uint(z) & kf.lowmask);
         keys[i] = (RTUF_KEY_PAD == 0 || i % kKeyStride < kTileW) ? min(key, bgkey) : bgkey;
       }
     } else {
-      for (int i = tid; i < kKeyCount; i += kTileThreads) keys[i] = bgkey;
+      for (int i = tid; i < kKeyCount; i += NT) keys[i] = bgkey;
     }
     if (tid == 0) { s_huge[0] = 0; s_huge[1 + kHugeMax] = n <= (uint32_t)kParkBelow ? (uint32_t)kQuarterArea : (uint32_t)kWallArea; }
 #ifdef RTUF_COUNT
@@ -2310,17 +2313,17 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       do_frags = !(a.flags & 0x400u); do_records = !(a.flags & 0x800u); load_only = (a.flags & 0x200u) != 0; skip = (int)((a.flags >> 12) & 3u);
 #endif
       if (do_frags) {
-        if (!RTUF_PRELOAD) load_frags(first_frags, frags, nf, 0u, tid);
-        apply_frags(keys, first_frags, nf, 0u, tid, zcover, kf.shift);
-        for (uint32_t base = kFragUnroll * kTileThreads; base < nf; base += kFragUnroll * kTileThreads) {
+        if (!RTUF_PRELOAD) load_frags<NT>(first_frags, frags, nf, 0u, tid);
+        apply_frags<NT>(keys, first_frags, nf, 0u, tid, zcover, kf.shift);
+        for (uint32_t base = kFragUnroll * NT; base < nf; base += kFragUnroll * NT) {
           unsigned long long f[kFragUnroll];
-          load_frags(f, frags, nf, base, tid);
-          apply_frags(keys, f, nf, base, tid, zcover, kf.shift);
+          load_frags<NT>(f, frags, nf, base, tid);
+          apply_frags<NT>(keys, f, nf, base, tid, zcover, kf.shift);
         }
       }
       if (do_records) {
-        if (near_tile) raster_bin<0, true>(keys, recs, n, x_base, y_base, tid, load_only, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, first_rec0, first_rec1, RTUF_PRELOAD != 0, skip);
-        else raster_bin<0, false>(keys, recs, n, x_base, y_base, tid, load_only, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, first_rec0, first_rec1, RTUF_PRELOAD != 0, skip);
+        if (near_tile) raster_bin<0, true, NT>(keys, recs, n, x_base, y_base, tid, load_only, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, first_rec0, first_rec1, RTUF_PRELOAD != 0, skip);
+        else raster_bin<0, false, NT>(keys, recs, n, x_base, y_base, tid, load_only, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, first_rec0, first_rec1, RTUF_PRELOAD != 0, skip);
       }
     }
     __syncthreads();
@@ -2331,7 +2334,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
     // keys, which settle everything but the last micrometres in front of the near plane (z24 < zexact); a tile without
     // them has no record that could get there at all (the set-up marks those near) -- the test stays, it costs nothing.
     bool need = false;
-    for (int i = tid; i < kKeyCount; i += kTileThreads) {
+    for (int i = tid; i < kKeyCount; i += NT) {
       const unsigned long long k = keys[i];
       if (k != bgkey && (uint32_t)(k >> 32) < kf.zexact) need = true;
     }
@@ -2340,7 +2343,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
       if (tid < kWinnerWords) s_winners[tid] = 0u;
       if (tid == 0) atomicAdd(&a.counters->shard[bin % kCounterShards].exact_tiles, 1u);
       __syncthreads();
-      for (int i = tid; i < kKeyCount; i += kTileThreads) {
+      for (int i = tid; i < kKeyCount; i += NT) {
         const unsigned long long k = keys[i];
         if (k != bgkey && (uint32_t)(k >> 32) < kf.zexact) {
           const uint32_t h = winner_slot((uint32_t)k >> kf.shift);
@@ -2348,10 +2351,10 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
         }
       }
       __syncthreads();
-      raster_bin<1, true>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, first_rec0, first_rec1, false);
+      raster_bin<1, true, NT>(keys, recs, n, x_base, y_base, tid, false, a.width, a.height, n_front, a.capacity, s_huge, s_prec, s_pmeta, zcover, s_winners, kf, first_rec0, first_rec1, false);
       if (has_cover) {                       // ... and the cover triangle, which is in no bin
         const CoverPlane c = cover_plane();
-        for (int i = tid; i < kKeyCount; i += kTileThreads) {
+        for (int i = tid; i < kKeyCount; i += NT) {
           const float z = __fmaf_rn(c.dzdy, (float)(y_base + i / kKeyStride), __fmaf_rn(c.dzdx, (float)(x_base + i % kKeyStride), c.a0));
           const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | (c.order << kf.shift) | (__float_as_uint(z) & kf.lowmask);
           if (keys[i] == key) keys[i] = kResolvedBit | (unsigned long long)__float_as_uint(z);
@@ -2496,11 +2499,16 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
 #ifndef RTUF_TILE_WAVES_COVER
 #define RTUF_TILE_WAVES_COVER 6
 #endif
-template <bool TWO_KERNEL, bool U16, bool COVER>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(COVER ? RTUF_TILE_WAVES_COVER : RTUF_TILE_WAVES))) void tile_kernel(TileArgs a) { tile_body<TWO_KERNEL, U16, false, COVER>(a); }
+// NT = threads of the workgroup: 256 (four waves per tile) for launches that fill the GPU; 1,024 (sixteen) for the small launches of
+// one or a few camera streams, where the kernel's time is the serial window loop of its fullest tiles -- 150 workgroups for one
+// VGA stream, each walking its bin 256 records at a time -- and more waves per tile shorten exactly that (one stream: raster
+// stage 42 -> 23 us, 14.2 k -> 17.6 k frames/s; eight streams 98 k -> 109 k; profiles/r05_experiment_tile_threads.txt).
+constexpr int kTileThreadsSmall = 1024;
+template <bool TWO_KERNEL, bool U16, bool COVER, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(COVER ? RTUF_TILE_WAVES_COVER : RTUF_TILE_WAVES))) void tile_kernel(TileArgs a) { tile_body<TWO_KERNEL, U16, false, COVER, NT>(a); }
 // mask-only output, one bit per pixel (rtuf_filter_batch_bits*): 4 (2) B/pixel in, 1/8 B/pixel out
-template <bool U16, bool COVER>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(COVER ? RTUF_TILE_WAVES_COVER : RTUF_TILE_WAVES))) void tile_bits_kernel(TileArgs a) { tile_body<false, U16, true, COVER>(a); }
+template <bool U16, bool COVER, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(COVER ? RTUF_TILE_WAVES_COVER : RTUF_TILE_WAVES))) void tile_bits_kernel(TileArgs a) { tile_body<false, U16, true, COVER, NT>(a); }
 
 // ---------------------------------------------------------------------------------------
 // compare_kernel (two-kernel mode): streaming, 13 B/pixel (4 sensor + 4 z + 4 masked + 1 mask)
@@ -2682,21 +2690,36 @@ void launch_bigrec(const SetupArgs& a, bool cover_pass, hipStream_t st)
   if (cover_pass) hipLaunchKernelGGL(bigrec_kernel<0>, dim3(kCounterShards * kBigWavesPerShard / 4), dim3(256), 0, st, a);
   hipLaunchKernelGGL(bigrec_kernel<1>, dim3(kCounterShards * kBigWavesPerShard / 4), dim3(256), 0, st, a);
 }
-template <bool COVER>
+#ifndef RTUF_SMALL_LAUNCH
+#define RTUF_SMALL_LAUNCH 2048     // launches of fewer tile workgroups than this take the 1,024-thread kernels (0: never)
+#endif
+// (RTUF_SMALL_LAUNCH in the environment overrides the built-in threshold: the tests run their small scenes through both kernels)
+static long long small_launch_threshold()
+{
+  static const long long t = [] { const char* e = getenv("RTUF_SMALL_LAUNCH"); return e && *e ? atoll(e) : (long long)RTUF_SMALL_LAUNCH; }();
+  return t;
+}
+template <bool COVER, int NT>
 static void launch_tile_variant(const TileArgs& a, bool two_kernel, hipStream_t st)
 {
   const dim3 grid(a.tiles_x, a.tiles_y, a.group_size);
   if (a.bits) {
-    if (a.io_u16) hipLaunchKernelGGL((tile_bits_kernel<true, COVER>), grid, dim3(kTileThreads), 0, st, a);
-    else hipLaunchKernelGGL((tile_bits_kernel<false, COVER>), grid, dim3(kTileThreads), 0, st, a);
-  } else if (two_kernel) hipLaunchKernelGGL((tile_kernel<true, false, COVER>), grid, dim3(kTileThreads), 0, st, a);
-  else if (a.io_u16) hipLaunchKernelGGL((tile_kernel<false, true, COVER>), grid, dim3(kTileThreads), 0, st, a);
-  else hipLaunchKernelGGL((tile_kernel<false, false, COVER>), grid, dim3(kTileThreads), 0, st, a);
+    if (a.io_u16) hipLaunchKernelGGL((tile_bits_kernel<true, COVER, NT>), grid, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((tile_bits_kernel<false, COVER, NT>), grid, dim3(NT), 0, st, a);
+  } else if (two_kernel) hipLaunchKernelGGL((tile_kernel<true, false, COVER, NT>), grid, dim3(NT), 0, st, a);
+  else if (a.io_u16) hipLaunchKernelGGL((tile_kernel<false, true, COVER, NT>), grid, dim3(NT), 0, st, a);
+  else hipLaunchKernelGGL((tile_kernel<false, false, COVER, NT>), grid, dim3(NT), 0, st, a);
 }
 void launch_tile(const TileArgs& a, bool two_kernel, bool cover_pass, hipStream_t st)
 {
-  if (cover_pass) launch_tile_variant<true>(a, two_kernel, st);
-  else launch_tile_variant<false>(a, two_kernel, st);
+  const bool small = (long long)a.tiles_x * a.tiles_y * a.group_size < small_launch_threshold();
+  if (small) {
+    if (cover_pass) launch_tile_variant<true, kTileThreadsSmall>(a, two_kernel, st);
+    else launch_tile_variant<false, kTileThreadsSmall>(a, two_kernel, st);
+  } else {
+    if (cover_pass) launch_tile_variant<true, kTileThreads>(a, two_kernel, st);
+    else launch_tile_variant<false, kTileThreads>(a, two_kernel, st);
+  }
 }
 void launch_compare(const CompareArgs& a, hipStream_t st)
 {

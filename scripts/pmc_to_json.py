@@ -31,8 +31,19 @@ def parse_pmc(path):
 
 
 def find(d, *needles):
+    """First kernel whose (truncated) name holds every needle.  The tile kernels carry their workgroup size as a last template
+    argument since round 5 (<..., 256> for launches that fill the GPU, <..., 1024> for small ones): a needle that ends in '>' also
+    matches the same arguments followed by ', 256>' -- the profiled launches are the large ones -- or by a truncated name."""
+    def hit(n, k):
+        if n in k:
+            return True
+        if n.endswith(">"):
+            stem = n[:-1]
+            i = k.find(stem)
+            return i >= 0 and (k[i + len(stem):].startswith(", 256>") or ">" not in k[i + len(stem):] and not k[i + len(stem):].startswith(", 1024"))
+        return False
     for k, v in d.items():
-        if all(n in k for n in needles):
+        if all(hit(n, k) for n in needles):
             return v
     return None
 

@@ -19,8 +19,8 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "realtime_urdf_filter_amd", "csrc")
-KERNELS = {"tile_kernel<fused>": "tile_kernelILb0ELb0E", "setup_kernel": "setup_kernelILb0E", "clip_kernel": "clip_kernelE",
-           "tile_kernel<two_kernel>": "tile_kernelILb1ELb0E", "compare_kernel": "compare_kernelILb0E"}
+KERNELS = {"tile_kernel<fused>": "tile_kernelILb0ELb0ELb0ELi256E", "setup_kernel": "setup_kernelILb0E", "clip_kernel": "clip_kernelE",
+           "tile_kernel<two_kernel>": "tile_kernelILb1ELb0ELb0ELi256E", "compare_kernel": "compare_kernelILb0E"}
 TRANSCENDENTAL = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
 
 

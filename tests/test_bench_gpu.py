@@ -162,17 +162,31 @@ def test_bench_min_seconds_floor_and_per_gpu_share_flag():
     assert d["parity"]["mismatching_values"] == 0 and "cpu_baseline" not in d
 
 
-def test_fuzz_parity_sample():
+# Launches of fewer than 2,048 tile workgroups -- every small scene of the tests -- take the tile kernels of 1,024 threads, larger ones
+# those of 256 (csrc/rtuf_kernels.hip, launch_tile).  RTUF_SMALL_LAUNCH=0 in the environment sends everything through the
+# 256-thread kernels: the fuzz samples run both ways, so both instantiations see the small, nasty scenes.
+SMALL_LAUNCH = [pytest.param(None, id="tile_threads_by_launch_size"), pytest.param("0", id="tile_threads_256")]
+
+
+def _env_small_launch(value):
+    return dict(os.environ) if value is None else dict(os.environ, RTUF_SMALL_LAUNCH=value)
+
+
+@pytest.mark.parametrize("small_launch", SMALL_LAUNCH)
+def test_fuzz_parity_sample(small_launch):
     """A sample of scripts/fuzz_parity.py (random resolutions, intrinsics, soups from sub-pixel dust to
     screen-filling triangles, near-plane crossings, both modes, forced bin regrowth) against the oracle."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "80", "777"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "80", "777"], capture_output=True, text=True, cwd=ROOT, timeout=900,
+                       env=_env_small_launch(small_launch))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert "streams with mismatches 0" in r.stdout
 
 
-def test_fuzz_features_sample():
+@pytest.mark.parametrize("small_launch", SMALL_LAUNCH)
+def test_fuzz_features_sample(small_launch):
     """A sample of scripts/fuzz_features.py: streams 1-9, several models with per-stream selection, primitives
     and multi-chunk meshes, 16UC1, optional mask, several launch groups per batch, both modes."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_features.py"), "60", "4242"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_features.py"), "60", "4242"], capture_output=True, text=True, cwd=ROOT, timeout=900,
+                       env=_env_small_launch(small_launch))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert "streams with mismatches 0" in r.stdout
