@@ -189,7 +189,8 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--triangles", type=int, default=250000, help="triangle budget of the PR2-like model")
-    ap.add_argument("--variants", type=int, default=2, help="distinct input batches rotated through the steps")
+    ap.add_argument("--variants", type=int, default=16, help="distinct joint states (and head-camera poses) per stream that the steps cycle through: every step poses every stream anew")
+    ap.add_argument("--depth-variants", type=int, default=2, help="distinct sets of sensor planes resident in HBM that the steps alternate between (a set is one plane per stream: 315 MB for 256 VGA streams)")
     ap.add_argument("--pipelines", type=int, default=1, help="contexts (HIP stream + bins each) per GPU that the batches alternate between: with 2 or 3, one batch's small and low-occupancy kernels overlap another's heavy ones, but kernels then share the GPU and per-launch times (roofline) no longer describe one kernel; default 1")
     ap.add_argument("--launch-group", type=int, default=0, help="rtuf_params.max_inflight_streams: streams rasterised per internal launch group (0 = automatic: the streams divided by the raster lanes, the whole batch up to 1024 with one lane); smaller groups shrink the tile bins and cost a kernel sequence per group")
     ap.add_argument("--overlap-pipelines", type=int, default=0, help="(obsolete, ignored: the overlap is the library default now, rtuf_params.raster_lanes; kept so that older command lines still run)")
@@ -250,8 +251,10 @@ def main():
     job_world = args.shard_of or world
     if rank >= job_world:
         raise SystemExit("--shard-of %d: rank %d has no share" % (job_world, rank))
-    share = CF.build(args.workload, job_world, rank, streams=args.streams, triangles=args.triangles, variants=args.variants,
-                     width=args.width, height=args.height, urdfs=args.urdfs, near_arm=args.near_arm)
+    # (host-side forward kinematics of a variant -- 3 ms per stream in Python -- only where it is needed: --host-poses, and the
+    # one variant of the last timed step that the parity check compares the device's kinematics with)
+    share = CF.build(args.workload, job_world, rank, streams=args.streams, triangles=args.triangles, variants=max(1, args.variants),
+                     width=args.width, height=args.height, urdfs=args.urdfs, near_arm=args.near_arm, host_fk=False)
     n, W, H = share.n, share.width, share.height
     wl0 = share.wl0
     p = R.default_params()
@@ -270,9 +273,10 @@ def main():
     ctx.enable_timing(2)         # HIP events around the big kernels only (each event costs stream time)
     ctxs = [ctx]
     V = share.n_variants()
+    VD = max(1, min(V, args.depth_variants))
 
     d_depth = []
-    for v in range(V):
+    for v in range(VD):
         host = share.depth_host(v)
         if args.u16:
             host = np.clip(np.rint(np.nan_to_num(host, nan=0.0, posinf=0.0) * 1000.0), 0, 65535).astype(np.uint16).view(np.int16)
@@ -291,7 +295,7 @@ def main():
         share.stage(ctx, k)       # joint angles in (forward kinematics on the GPU), or host matrices with --host-poses
 
     def submit(k):
-        (ctx.filter_batch_device_u16 if args.u16 else ctx.filter_batch_device)(n, dptr[k % V], ptrs[k % n_sets][0], ptrs[k % n_sets][1])
+        (ctx.filter_batch_device_u16 if args.u16 else ctx.filter_batch_device)(n, dptr[k % VD], ptrs[k % n_sets][0], ptrs[k % n_sets][1])
 
     def enqueue(k):
         # one step = one batch through the hot path: enqueue it, then stage the NEXT batch's joint positions (host
@@ -341,9 +345,12 @@ def main():
     for c in ctxs:
         c.enable_timing(3)       # (re)starts the library's event sums: set-up, tile (and compare) kernels of every fourth batch (an event costs ~5 us of stream time)
     stage_into(k0)
+    step_clock = np.empty(timed_steps + 1)
     t0 = time.perf_counter()
+    step_clock[0] = t0
     for k in range(k0, k0 + timed_steps):
         enqueue(k)
+        step_clock[k - k0 + 1] = time.perf_counter()      # (the call returns when the context has room: with two batches in flight that is the pace of the GPU)
     for c in ctxs:
         c.sync()
     torch.cuda.synchronize()
@@ -376,7 +383,7 @@ def main():
     except Exception:
         quota = None
     threads = max(1, min(host_threads, int(quota))) if quota else host_threads
-    v_last = k_last % V
+    v_last = k_last % VD
     d_masked, d_mask = d_masked_set[k_last % n_sets], d_mask_set[k_last % n_sets]
     link_dev = cam_dev = None
     fk_err = None
@@ -432,13 +439,19 @@ def main():
 
     if rank == 0:
         value = frames_total / elapsed
+        # pace of the timed region, step by step, on rank 0's host clock: the time between two returns of the enqueue call (which
+        # returns when the context has room again: steady state = one GPU step).  The first steps fill the two in-flight slots.
+        dsteps = np.diff(step_clock)[min(4, max(timed_steps - 1, 0)):] * 1e3
+        step_ms = ({"min": float(dsteps.min()), "median": float(np.median(dsteps)), "p99": float(np.percentile(dsteps, 99)), "max": float(dsteps.max()), "steps": int(dsteps.size),
+                    "note": "host-clock interval between consecutive enqueue returns of the timed region (rank 0), first four steps left out"}
+                   if dsteps.size else None)
         px = W * H
         two = args.two_kernel
         mask_b = 0 if args.no_mask else 1
 
         def fresh_share():
-            return CF.build(args.workload, job_world, rank, streams=args.streams, triangles=args.triangles, variants=args.variants,
-                            width=args.width, height=args.height, urdfs=args.urdfs, near_arm=args.near_arm)
+            return CF.build(args.workload, job_world, rank, streams=args.streams, triangles=args.triangles, variants=max(1, args.variants),
+                            width=args.width, height=args.height, urdfs=args.urdfs, near_arm=args.near_arm, host_fk=False)
 
         # ---- one-lane leg: every kernel alone on the GPU, the whole batch per launch -- what the roofline describes -----
         iso_leg = None
@@ -458,7 +471,7 @@ def main():
 
             def submit1(k):
                 m, kk = sets1[k % 2]
-                (ctx1.filter_batch_device_u16 if args.u16 else ctx1.filter_batch_device)(n, dptr[k % V], m.data_ptr(), kk.data_ptr() if kk is not None else 0)
+                (ctx1.filter_batch_device_u16 if args.u16 else ctx1.filter_batch_device)(n, dptr[k % VD], m.data_ptr(), kk.data_ptr() if kk is not None else 0)
 
             for k in range(max(args.warmup, 2)):
                 share1.stage(ctx1, k)
@@ -495,7 +508,7 @@ def main():
 
             def submit1(k):
                 m, kk = sets1[k % 2]
-                (bctx.filter_batch_device_u16 if args.u16 else bctx.filter_batch_device)(n, dptr[k % V], m.data_ptr(), kk.data_ptr() if kk is not None else 0)
+                (bctx.filter_batch_device_u16 if args.u16 else bctx.filter_batch_device)(n, dptr[k % VD], m.data_ptr(), kk.data_ptr() if kk is not None else 0)
 
         # stage-by-stage breakdown and the raster stage's kernels one by one: a few extra steps, one batch in flight, host
         # waits after every step (on the one-lane context when there is one: nothing else on the GPU)
@@ -643,8 +656,9 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "timed_steps": timed_steps, "min_seconds": args.min_seconds, "timed_seconds": elapsed,
             "ms_per_step": elapsed / max(timed_steps, 1) * 1e3, "higher_is_better": True, "scaling": share.scaling, "vs_baseline": None,
+            "step_ms": step_ms,
             "dtype": "f32", "data": "synthetic", "depth_format": "16UC1" if args.u16 else "32FC1",
-            "config": {"workload": share.describe(),
+            "config": {"workload": share.describe(), "distinct_joint_states_per_stream": V, "distinct_sensor_plane_sets": VD,
                        "streams_per_gpu": n if share.scaling == "weak" else [x["streams"] for x in per_rank], "streams_total": sum(x["streams"] for x in per_rank),
                        "poses": "host matrices" if args.host_poses else "joint positions, forward kinematics on the GPU", "mode": "two-kernel" if two else "fused", "mask_output": (not args.no_mask),
                        "parallelism": ("stream-sharded x%d" % world) + (" (shares of a %d-GPU job)" % job_world if args.shard_of else ""), "pipelines_per_gpu": P,
@@ -691,7 +705,7 @@ def main():
                 h_mask = [] if bits else [ctx.host_alloc((n, H, W), np.uint8) for _ in range(2)]
                 h_bits = [ctx.host_alloc((n, words), np.uint32) for _ in range(2)] if bits else []
                 for v in range(2):
-                    d = d_depth[v % V].cpu().numpy()
+                    d = d_depth[v % VD].cpu().numpy()
                     if args.u16:
                         d = depth_u16_to_f32(d.view(np.uint16))
                     h_in[v][...] = depth_f32_to_u16(np.nan_to_num(d, nan=0.0, posinf=0.0)) if fmt == "16UC1" else d
@@ -702,7 +716,7 @@ def main():
                     else:
                         ctx.filter_batch_async(h_in[k % 2], h_out[k % 2], h_mask[k % 2])
 
-                kq = k_last + 1 + ((-(k_last + 1)) % V)            # variant 0 first: h_in[k % 2] then matches share.stage(k) for V = 2
+                kq = k_last + 1 + ((-(k_last + 1)) % (2 * V))      # an even step number that starts the joint states' cycle: plane set k % 2, joint states k % V
                 for k in range(kq, kq + 2):
                     share.stage(ctx, k)
                     go(k)
@@ -725,9 +739,9 @@ def main():
                     share.stage(ctx, k + 1)
                 ctx.sync()
                 el = time.perf_counter() - th
-                # parity of the last batch, first and last stream (same checker; V == 2 keeps planes and poses in step)
+                # parity of the last batch, first and last stream (same checker: the oracle, fed the poses the device produced)
                 bad = None
-                if V == 2:
+                if True:
                     kl = ks + steps_h - 1
                     lk, ck = (None, None) if args.host_poses else ctx.read_poses(n, share.n_links_total)
                     bad = 0

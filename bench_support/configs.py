@@ -66,14 +66,14 @@ class RankShare:
         if self.workload == "c5":
             tris = [g.variants[0].n_triangles() for g in self.groups]
             return ("C5: %dx%d depth, %d distinct synthetic articulated URDFs x %d cameras each (%d streams in total), "
-                    "this rank: %d URDFs = %d streams, triangles per robot %s, new joint state every step"
-                    % (self.width, self.height, self.total_streams // g0.count, g0.count, self.total_streams, len(self.groups), self.n, tris))
+                    "this rank: %d URDFs = %d streams, triangles per robot %s, every step poses every stream anew (%d distinct joint states per stream, cycled)"
+                    % (self.width, self.height, self.total_streams // g0.count, g0.count, self.total_streams, len(self.groups), self.n, tris, self.n_variants()))
         extra = " + two static wall URDFs (urdf/example.urdf.xml boxes)" if self.workload == "c4" else ""
         extra += ", right forearm 0.1-0.35 m in front of the lens in every stream" if self.near_arm else ""
         return ("%s: %dx%d depth, synthetic PR2-like URDF (%d links with meshes, %d triangles)%s, batch=%d concurrent streams %s, "
-                "new joint state + camera pose every step"
+                "every step poses every stream anew: joint state + head-camera pose (%d distinct states per stream, cycled)"
                 % (self.workload.upper(), self.width, self.height, g0.variants[0].meta["links_with_geometry"], g0.variants[0].n_triangles(), extra,
-                   self.n if self.scaling == "weak" else self.total_streams, "per GPU" if self.scaling == "weak" else "in total, %d on this rank" % self.n))
+                   self.n if self.scaling == "weak" else self.total_streams, "per GPU" if self.scaling == "weak" else "in total, %d on this rank" % self.n, self.n_variants()))
 
     # ---- feeding a context --------------------------------------------------------------------
     def load(self, ctx, on_device_fk=True):
@@ -111,6 +111,8 @@ class RankShare:
         v = k % self.n_variants()
         for g in self.groups:
             wl = g.variants[v]
+            if not self.on_device_fk:
+                wl.ensure_host_fk()
             if not self._cams_staged:
                 ctx.set_cameras(g.first, wl.projection, wl.offset_inv, None if self.on_device_fk else wl.cam_tf)
             if not self._static_staged:
@@ -147,6 +149,8 @@ class RankShare:
         g = self.group_of(s)
         wl = g.variants[k % self.n_variants()]
         j = s - g.first
+        if link_tf_device is None or cam_tf_device is None:
+            wl.ensure_host_fk()               # (a share built with host_fk=False computes a variant's host-side kinematics when first asked)
         draws = []
         for mi, (m, links) in enumerate(zip(g.model_ids, wl.models)):
             for li, dl in enumerate(links):
@@ -161,6 +165,7 @@ class RankShare:
         worst = 0.0
         for g in self.groups:
             wl = g.variants[k % self.n_variants()]
+            wl.ensure_host_fk()
             sl = slice(g.first, g.first + g.count)
             for mi, m in enumerate(g.model_ids):
                 nl = wl.link_tf[mi].shape[1]

@@ -43,6 +43,7 @@ class Workload:
         self.kinematics = None      # arrays for rtuf_set_kinematics (model 0), see urdf.kinematic_arrays
         self.camera_frame_index = -1
         self.joint_q = None         # [N, frames]
+        self.ensure_host_fk = lambda: None      # (pr2_workload(host_fk=False) replaces it: fills link_tf / cam_tf when first needed)
 
     def n_triangles(self):
         return int(sum(len(d.tris) for m in self.models for l in m for d in l))
@@ -174,11 +175,9 @@ def pr2_workload(n_streams, width=640, height=480, total_triangles=250000, seed=
         wall_rd = URDFRenderer(EXAMPLE_URDF, "/walls", robot.camera_frame, robot.fixed_frame, tf0, "visual", 1.0, [])
         w.models.append([r.draws for r in wall_rd.renderables_])
         wall_tf = np.zeros((n_streams, len(wall_rd.renderables_), 16))
-    for s in range(n_streams if host_fk or walls else 0):
+    def fill(s):
+        """Host-side forward kinematics of stream s: link matrices, camera transform (and the static walls)."""
         q = joint_state(first_state_seed + s)
-        if not host_fk and s > 0:
-            wall_tf[s] = wall_tf[0]             # (the walls do not move: posed relative to the fixed frame)
-            continue
         fk = urdf.forward_kinematics(model, q)
         tf = urdf.StaticTransformProvider()
         tf.set_frames(fk, "/")
@@ -192,12 +191,29 @@ def pr2_workload(n_streams, width=640, height=480, total_triangles=250000, seed=
             for k, (x, y, z, yaw) in enumerate(((1.5, -1.5, 1.0, 0.785398163), (-1.5, -1.2, 1.0, -0.785398163))):
                 t = urdf.Transform.from_quaternion((0, 0, math.sin(yaw / 2), math.cos(yaw / 2)), (x + 2.0, y + 1.5, z))
                 wall_tf[s, k] = (t * wall_rd.renderables_[k].link_offset).opengl_matrix()
+
+    if host_fk:
+        for s in range(n_streams):
+            fill(s)
+    elif walls:
+        fill(0)
+        wall_tf[1:] = wall_tf[0]                # (the walls do not move: posed relative to the fixed frame)
+        link_tf[0] = 0.0
+        cam_tf[0] = 0.0
+
+    def ensure_host_fk():
+        """Fills in the host-side forward kinematics a host_fk=False build left out (idempotent)."""
+        if not w.meta["host_fk"]:
+            for s in range(n_streams):
+                fill(s)
+            w.meta["host_fk"] = True
     w.link_tf = [link_tf] + ([wall_tf] if walls else [])
     w.projection = _projection_block(width, height, n_streams)
     w.offset_inv = np.tile(urdf.Transform().opengl_matrix(), (n_streams, 1))
     w.cam_tf = cam_tf
     w.meta = {"robot": "synthetic PR2-like", "links": len(robot.links), "links_with_geometry": L,
               "triangles": w.n_triangles(), "vertices": w.n_vertices(), "host_fk": bool(host_fk)}
+    w.ensure_host_fk = ensure_host_fk
     # on-device forward kinematics inputs: the tree once, joint positions per stream
     strip = lambda n: n[1:] if n.startswith("/") else n
     w.kinematics = urdf.kinematic_arrays(model, [strip(r.name) for r in rd.renderables_], [r.link_offset for r in rd.renderables_])

@@ -4,13 +4,16 @@
 // the bit-packed masks.  What bench.py does over torch.distributed, for hosts that stay C++ (north_star: "the host stays
 // C++/ROS ... independent stream batches shard across 8 GPUs with RCCL only for the trivial gather").
 //
-//   multi_gpu_filter <scene.bin> [--devices N] [--mode block|model] [--steps K] [--dump S PREFIX] [--masks direct|rccl|none]
+//   multi_gpu_filter <scene.bin> [--devices N] [--logical-devices N] [--mode block|model] [--steps K] [--dump S PREFIX] [--masks direct|rccl|none]
 //
 // scene.bin (little endian; written by tests/scene_file.py from a bench workload) holds the job: image size, filter
 // parameters, models (links -> draws -> vertices / triangles), kinematic trees, per-stream model selection, cameras, joint
 // positions or explicit link matrices, and the sensor frames.
 //   --mode block   streams are block-partitioned over the devices, every device loads every model   (BASELINE config 3 / 4)
 //   --mode model   model m and the streams that render it live on device m % N                      (BASELINE config 5)
+//   --logical-devices N   N shares, host threads and contexts mapped onto the visible devices in turn (N = 2 on a box with one GPU:
+//                  both on device 0) -- the N > 1 logic without N GPUs; no RCCL communicator then, the gathers travel as copies
+//                  through the same padding / compaction (multi_gpu.hpp)
 //   --dump S P     writes the job's stream S after the last step: P.masked.f32, P.mask.u8 and the link matrices / camera
 //                  transform the device rendered it with (P.link_tf.f64, P.cam_tf.f64), for a checker
 // Prints one JSON line: frames/s of the job, per-device shares, what RCCL gathered.
@@ -127,12 +130,13 @@ struct Share {
 int main(int argc, char** argv)
 {
   if (argc < 2) { std::fprintf(stderr, "usage: %s scene.bin [--devices N | --all-devices] [--mode block|model] [--steps K] [--dump S PREFIX] [--masks direct|rccl|none]\n", argv[0]); return 2; }
-  int want_devices = 0, steps = 3, dump_stream = -1;
+  int want_devices = 0, logical_devices = 0, steps = 3, dump_stream = -1;
   std::string mode = "block", dump_prefix, masks = "direct";
   for (int i = 2; i < argc; i++) {
     const std::string a = argv[i];
     if (a == "--devices" && i + 1 < argc) want_devices = std::atoi(argv[++i]);
     else if (a == "--all-devices") want_devices = 0;                       // every visible device (also the default)
+    else if (a == "--logical-devices" && i + 1 < argc) logical_devices = std::atoi(argv[++i]);
     else if (a == "--mode" && i + 1 < argc) mode = argv[++i];
     else if (a == "--steps" && i + 1 < argc) steps = std::atoi(argv[++i]);
     else if (a == "--masks" && i + 1 < argc) masks = argv[++i];
@@ -143,10 +147,10 @@ int main(int argc, char** argv)
     const Scene sc = load_scene(argv[1]);
     int visible = 0;
     mg::check_hip(hipGetDeviceCount(&visible), "hipGetDeviceCount");
-    const int N = want_devices > 0 ? want_devices : visible;
-    if (N <= 0 || N > visible) { std::fprintf(stderr, "%d devices requested, %d visible\n", N, visible); return 2; }
+    const int N = logical_devices > 0 ? logical_devices : (want_devices > 0 ? want_devices : visible);
+    if (N <= 0 || visible <= 0 || (logical_devices <= 0 && N > visible)) { std::fprintf(stderr, "%d devices requested, %d visible\n", N, visible); return 2; }
     std::vector<int> devices(N);
-    for (int d = 0; d < N; d++) devices[d] = d;
+    for (int d = 0; d < N; d++) devices[d] = d % visible;                  // (logical devices wrap around the visible ones)
 
     // ---- the partition (no collective needed: streams are independent) ----------------------------------------
     std::vector<Share> share(N);
@@ -333,10 +337,10 @@ int main(int argc, char** argv)
     }
     std::printf("{\"devices\": %d, \"mode\": \"%s\", \"streams\": %d, \"steps\": %d, \"frames\": %.0f, \"seconds_slowest_device\": %.6f, \"frames_per_s\": %.1f, "
                 "\"bits_vs_bytes_mismatches\": %.0f, \"mask_all_gather\": \"%s\", \"mask_all_gather_path\": \"%s\", \"peer_access_everywhere\": %d, "
-                "\"gathered_masks_equal_sources\": %lld, \"per_device\": [",
+                "\"gathered_masks_equal_sources\": %lld, \"logical_devices\": %d, \"per_device\": [",
                 N, mode.c_str(), sc.n_streams, steps, frames, slowest, slowest > 0 ? frames / slowest : 0.0, mismatches, masks.c_str(),
-                masks == "none" ? "none" : (gather_path.direct ? "peer-to-peer copies" : (gather_path.fell_back ? "rccl (fell back: a device pair has no peer access)" : "rccl")),
-                group.peer_access_everywhere() ? 1 : 0, gathered_ok);
+                masks == "none" ? "none" : (gather_path.direct ? "peer-to-peer copies" : (gather_path.fell_back ? "rccl (fell back: a device pair has no peer access)" : (group.logical_devices() ? "padded all-gather by copies (logical devices: no communicator)" : "rccl"))),
+                group.peer_access_everywhere() ? 1 : 0, gathered_ok, group.logical_devices() ? 1 : 0);
     for (int d = 0; d < N; d++)
       std::printf("%s{\"device\": %d, \"streams\": %d, \"frames\": %.0f, \"seconds\": %.6f, \"host_thread_pinned_to_cpus\": %d}", d ? ", " : "", devices[d], per_device[d], all[d].frames, all[d].seconds, group.pinned_cpus(d));
     std::printf("]}\n");

@@ -15,6 +15,11 @@
 //
 // The reference has no multi-GPU notion at all (one GL context, one camera: src/urdf_filter.cpp:207-267); this header is
 // the C++ twin of realtime_urdf_filter_amd/sharding.py + the collective lines of bench.py for hosts that stay C++ / ROS.
+// LOGICAL devices (round 6): the device list may name a physical device more than once ({0, 0}: two shares, two host threads,
+// two contexts, two collective streams on GPU 0).  RCCL refuses two ranks on one GPU, so such a group makes no communicator:
+// its gathers travel as device-to-device copies on the members' own streams (hipMemcpyPeerAsync between members that sit
+// on the same GPU is a plain copy), through the SAME padding, slot arithmetic and compaction as the RCCL path.  That is
+// how the N > 1 logic of this header is exercised on a box with one GPU (tests/test_baseline_configs_gpu.py, "logical2").
 // Header-only; needs the HIP runtime and RCCL headers (hipcc, -lrtuf -lrccl).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -145,8 +150,10 @@ class DeviceGroup {
       const int rc = rtuf_create(&ctx_[i], devices_[i], width, height, streams_per_device[i], &params);
       if (rc != RTUF_OK) throw std::runtime_error("rtuf_create on device " + std::to_string(devices_[i]) + ": " + rtuf_last_error(nullptr));
     }
-    // single-process communicator set: one rank per device, in the order of `devices`
-    check_nccl(ncclCommInitAll(comm_.data(), (int)devices_.size(), devices_.data()), "ncclCommInitAll");
+    for (size_t i = 0; i < devices_.size(); i++)
+      for (size_t e = 0; e < i; e++) if (devices_[e] == devices_[i]) logical_ = true;
+    // single-process communicator set: one rank per device, in the order of `devices` (none for logical devices: see the top)
+    if (!logical_) check_nccl(ncclCommInitAll(comm_.data(), (int)devices_.size(), devices_.data()), "ncclCommInitAll");
     for (size_t i = 0; i < devices_.size(); i++) {
       check_hip(hipSetDevice(devices_[i]), "hipSetDevice");
       check_hip(hipStreamCreateWithFlags(&stream_[i], hipStreamNonBlocking), "hipStreamCreate");
@@ -157,7 +164,7 @@ class DeviceGroup {
     for (size_t i = 0; i < devices_.size(); i++) {
       check_hip(hipSetDevice(devices_[i]), "hipSetDevice");
       for (size_t e = 0; e < devices_.size(); e++) {
-        if (e == i) continue;
+        if (e == i || devices_[e] == devices_[i]) continue;      // (members on one GPU reach each other's memory as it is)
         int can = 0;
         if (hipDeviceCanAccessPeer(&can, devices_[i], devices_[e]) != hipSuccess || !can) { (void)hipGetLastError(); peers_ok_ = false; no_peer_ += " " + std::to_string(devices_[i]) + "->" + std::to_string(devices_[e]); continue; }
         const hipError_t pe = hipDeviceEnablePeerAccess(devices_[e], 0);
@@ -176,6 +183,7 @@ class DeviceGroup {
   int device(int i) const { return devices_[i]; }
   rtuf_context* context(int i) const { return ctx_[i]; }
   bool peer_access_everywhere() const { return peers_ok_; }          // every ordered pair of devices granted peer access
+  bool logical_devices() const { return logical_; }                  // some physical device appears more than once: no RCCL communicator, gathers by copies
   const std::string& pairs_without_peer_access() const { return no_peer_; }
   int pinned_cpus(int i) const { return pinned_cpus_[i]; }          // CPUs device i's host thread was pinned to (0: not pinned)
 
@@ -210,10 +218,7 @@ class DeviceGroup {
       up[3 * i] = mine[i].frames; up[3 * i + 1] = mine[i].seconds; up[3 * i + 2] = mine[i].mismatches;
       check_hip(hipMemcpyAsync(d_report_[i], &up[3 * i], sizeof(double) * 3, hipMemcpyHostToDevice, stream_[i]), "report upload");
     }
-    check_nccl(ncclGroupStart(), "ncclGroupStart");
-    for (size_t i = 0; i < n; i++)
-      check_nccl(ncclAllGather(d_report_[i], d_report_[i] + 3, 3, ncclDouble, comm_[i], stream_[i]), "ncclAllGather(reports)");
-    check_nccl(ncclGroupEnd(), "ncclGroupEnd");
+    all_gather(reinterpret_cast<const char* const*>(d_report_.data()), [&](size_t i) { return reinterpret_cast<char*>(d_report_[i] + 3); }, 3 * sizeof(double), "reports");
     std::vector<DeviceReport> all(n);
     std::vector<double> host(3 * n);
     for (size_t i = 0; i < n; i++) {
@@ -268,10 +273,7 @@ class DeviceGroup {
         if (streams[i] < most) check_hip(hipMemsetAsync(d_pad_[i] + (size_t)streams[i] * words, 0, (size_t)(most - streams[i]) * frame, stream_[i]), "pad");
         if (streams[i]) check_hip(hipMemcpyAsync(d_pad_[i], d_bits[i], (size_t)streams[i] * frame, hipMemcpyDeviceToDevice, stream_[i]), "pad copy");
       }
-      check_nccl(ncclGroupStart(), "ncclGroupStart");
-      for (size_t i = 0; i < n; i++)
-        check_nccl(ncclAllGather(d_pad_[i], d_gather_[i], (size_t)most * words, ncclUint32, comm_[i], stream_[i]), "ncclAllGather(masks)");
-      check_nccl(ncclGroupEnd(), "ncclGroupEnd");
+      all_gather(reinterpret_cast<const char* const*>(d_pad_.data()), [&](size_t i) { return reinterpret_cast<char*>(d_gather_[i]); }, (size_t)most * frame, "masks");
       for (size_t i = 0; i < n; i++) {                   // compact: slice e of the padded table -> its dense place
         check_hip(hipSetDevice(devices_[i]), "hipSetDevice");
         size_t first = 0;
@@ -289,6 +291,32 @@ class DeviceGroup {
   }
 
  private:
+  // Equal contributions of `bytes` from every member (send[i] on member i) into every member's table recv(i), member 0's
+  // first: one ncclAllGather per member inside a group call, or -- logical devices -- every member copying its contribution
+  // into its slot of every table on its own stream (tables are complete once all streams are synchronised, as the callers do).
+  template <typename Recv>
+  void all_gather(const char* const* send, Recv recv, size_t bytes, const char* what)
+  {
+    const size_t n = devices_.size();
+    if (!logical_) {
+      check_nccl(ncclGroupStart(), "ncclGroupStart");
+      for (size_t i = 0; i < n; i++)
+        check_nccl(ncclAllGather(send[i], recv(i), bytes, ncclChar, comm_[i], stream_[i]), what);
+      check_nccl(ncclGroupEnd(), "ncclGroupEnd");
+      return;
+    }
+    for (size_t i = 0; i < n; i++) {
+      check_hip(hipSetDevice(devices_[i]), "hipSetDevice");
+      for (size_t e = 0; e < n; e++)
+        check_hip(hipMemcpyPeerAsync(recv(e) + i * bytes, devices_[e], send[i], devices_[i], bytes, stream_[i]), what);
+    }
+    // (a member's later reads of its own table happen on ITS stream: wait for the others' copies into it)
+    for (size_t i = 0; i < n; i++) {
+      check_hip(hipSetDevice(devices_[i]), "hipSetDevice");
+      check_hip(hipStreamSynchronize(stream_[i]), "hipStreamSynchronize");
+    }
+  }
+
   static void grow(uint32_t*& buf, size_t& have, size_t want)
   {
     if (have >= want) return;
@@ -318,6 +346,7 @@ class DeviceGroup {
   std::vector<size_t> pad_bytes_, gather_bytes_;
   std::vector<int> pinned_cpus_;
   bool peers_ok_ = false;
+  bool logical_ = false;
   std::string no_peer_;
 };
 

@@ -374,7 +374,10 @@ typedef struct {
                                        kernel after the other; raise GPU_MAX_HW_QUEUES (HIP runtime, default 4)  */
   /* ABI 6 */
   uint32_t batch_status;            /* RTUF_STATUS_* bits the FIRST run of the batch retired last left in its device status word
-                                       (0: its planes were final as soon as its kernels had run)                            */
+                                       (0: its planes were final as soon as its kernels had run).  A batch that was run again only
+                                       because an OLDER batch in flight overflowed is retired on its re-run's counters: its mirror
+                                       then reads what that run left (0, batch_reruns 0) although a device-side consumer saw the
+                                       first run's word -- the device word, not this mirror, is what such a consumer goes by       */
   uint32_t batch_reruns;            /* times that batch (and everything in flight behind it) was run again before it was retired */
   uint32_t over_memory_limit;       /* 1: the tile bins exceed rtuf_params.memory_limit_mb (or the automatic third of the free
                                        memory): one stream's bins alone are larger, and launch groups cannot shrink below one   */

@@ -281,7 +281,12 @@ static int groups_for(const rtuf_context* c, int n)
 {
   int k = (n + c->group - 1) / std::max(c->group, 1);
   if (c->n_lanes > 1 && n >= kSplitMin) k = ((std::max(k, 1) + c->n_lanes - 1) / c->n_lanes) * c->n_lanes;      // a multiple of the lanes
-  return std::max(k, 1);
+  k = std::max(k, 1);
+  // ... of ceil(n / k) streams each, which can come to FEWER than k groups (100 streams in 16 groups of 7 are 15): the number
+  // returned is the number enqueue_batch makes -- the batch's status word starts at it and every group takes one off
+  // (round 5 returned k: the word of such a batch never reached 0)
+  const int per_group = (std::max(n, 1) + k - 1) / k;
+  return (std::max(n, 1) + per_group - 1) / per_group;
 }
 
 static void sync_lanes(rtuf_context* c)
@@ -360,7 +365,7 @@ static int grow_bins(rtuf_context* c, uint32_t needed, uint32_t fneeded)
   const size_t budget = std::min((size_t)((double)(free_b + held) * 0.9), c->memory_budget);
   int G = c->group;
   while (G > 1 && (size_t)c->n_lanes * lane_bins_bytes(c, G, cap, fcap) > budget) G = (G + 1) / 2;
-  if ((size_t)c->n_lanes * lane_bins_bytes(c, G, cap, fcap) > c->memory_budget) c->stats.over_memory_limit = 1u;      // (G == 1: one stream's bins alone)
+  c->stats.over_memory_limit = (size_t)c->n_lanes * lane_bins_bytes(c, G, cap, fcap) > c->memory_budget ? 1u : 0u;      // (set: G == 1 and one stream's bins alone exceed it; cleared otherwise)
   for (;;) {
     hipError_t e = hipSuccess;
     for (int l = 0; l < c->n_lanes && e == hipSuccess; l++) {
@@ -817,6 +822,7 @@ static int alloc_frame_buffers(rtuf_context* c)
   c->fcapacity = std::max<uint32_t>(4 * cap, 1024);   // 8-byte fragments of all boxes up to 4x4 pixel centres
   while (G > 1 && (size_t)c->n_lanes * lane_bins_bytes(c, G, c->capacity, c->fcapacity) > c->memory_budget) G = (G + 1) / 2;
   c->group = G;
+  c->stats.over_memory_limit = (size_t)c->n_lanes * lane_bins_bytes(c, G, c->capacity, c->fcapacity) > c->memory_budget ? 1u : 0u;      // (the first allocation can exceed it already)
   c->clip_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 8192 / kCounterShards, 1024), (size_t)1 << 22);   // per shard
   c->big_capacity = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)G * 64, 1024), (size_t)1 << 20);                 // per shard
   for (int l = 0; l < c->n_lanes; l++) {
@@ -1407,8 +1413,12 @@ static int issue_plan(rtuf_context* c, rtuf_context::Batch& b, const BatchPlan& 
     // streams plus one item per chunk for that rounding.
     uint32_t hint = 0;
     if (!worst_case_grid && c->items_hint && c->items_hint_streams > 0) {
-      if (g < c->group_items.size() && c->group_streams[g] == gr.sa.group_size) hint = std::max(c->group_items[g], 1u);
-      else hint = (uint32_t)(((uint64_t)c->items_hint * (uint64_t)gr.sa.group_size + (uint64_t)c->items_hint_streams - 1) / (uint64_t)c->items_hint_streams) + (uint32_t)c->n_chunks;
+      const uint32_t scaled = (uint32_t)(((uint64_t)c->items_hint * (uint64_t)gr.sa.group_size + (uint64_t)c->items_hint_streams - 1) / (uint64_t)c->items_hint_streams);
+      // (its own length, but never below half of what the longest list makes per stream: a group whose cameras saw nearly
+      // nothing last time would otherwise take a grid of a few dozen workgroups, and the robot moving into ITS view would cost
+      // a re-run of everything in flight where the old max-based estimate covered it; idle workgroups of the floor end at once)
+      if (g < c->group_items.size() && c->group_streams[g] == gr.sa.group_size) hint = std::max(std::max(c->group_items[g], scaled / 2u), 1u);
+      else hint = scaled + (uint32_t)c->n_chunks;
     }
     const uint32_t grid = launch_setup(gr.sa, hint, false, st);
     b.setup_grid[g] = worst_case_grid ? 0xffffffffu : grid;
@@ -1570,6 +1580,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     }
   }
   b.n_groups = (int)plan.groups.size();
+  if (b.n_groups != n_groups) return c->fail(RTUF_ERR_STATE, "internal: %d launch groups planned, %d made (the status word counts the former down)", n_groups, b.n_groups);
   b.setup_grid.assign(plan.groups.size(), 0xffffffffu);
   c->last_lane = plan.groups.back().lane;
   // host-plane batches: the lanes' first kernels wait for the upload of the planes

@@ -11,7 +11,8 @@ Q="--cpu-seconds 0 --host-copy-seconds 0 --min-seconds ${SECONDS_EACH:-2} --chec
 line() { python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('%9.0f frames/s  tile %.4f ms  setup-stage %.4f ms  mismatches %s' % (d['value'], r['avg_launch_ms'], d['kernel_ms_per_step']['ms_setup'], d['parity']['mask_mismatch_pixels'] + d['parity']['depth_mismatch_pixels']))"; }
+ra=d['rasteriser']
+print('%9.0f frames/s  tile %.4f ms  setup-stage %.4f ms  mismatches %s  bin entries %d' % (d['value'], r['avg_launch_ms'], d['kernel_ms_per_step']['ms_setup'], d['parity']['mask_mismatch_pixels'] + d['parity']['depth_mismatch_pixels'], ra['bin_entries']))"; }
 for spec in "$@"; do
   name=${spec%%:*}; flags=""; [ "$spec" != "$name" ] && flags=${spec#*:}
   lib=$here/realtime_urdf_filter_amd/lib/librtuf.so

@@ -251,6 +251,21 @@ def _multi_gpu_example():
 
 @pytest.mark.parametrize("mode,masks", [("block", "direct"), ("block", "rccl"), ("model", "direct")])
 def test_cpp_multi_device_host_with_rccl_gather(tmp_path, mode, masks):
+    _run_cpp_multi_device_host(tmp_path, mode, masks, 0, None)
+
+
+@pytest.mark.parametrize("mode,masks,logical", [("block", "direct", 2), ("block", "rccl", 2), ("model", "rccl", 2), ("model", "direct", 3)])
+def test_cpp_multi_device_host_logical_devices(tmp_path, mode, masks, logical):
+    """The same host with N > 1 on a box with ONE GPU: --logical-devices N maps N shares, N host threads and N contexts onto
+    the visible devices in turn.  Unequal shares (6 streams over 2, 3 robots over 2 devices: 6 + 3 streams), the padded
+    all-gather with its compaction, models_for_rank and the report gather all run with N members; RCCL itself is left out
+    (it refuses two ranks on one GPU): the gathers travel as device-to-device copies through the same slot arithmetic.  A
+    stream dumped from EACH logical device equals the oracle."""
+    for pick in ((1, 4) if mode == "block" else (7, 4)):
+        _run_cpp_multi_device_host(tmp_path, mode, masks, logical, pick)
+
+
+def _run_cpp_multi_device_host(tmp_path, mode, masks, logical, pick_override):
     """examples/multi_gpu_filter.cpp over include/realtime_urdf_filter_amd/multi_gpu.hpp: the C++ host of SURVEY.md
     section 8e -- one thread and one rtuf_context per device, block shares (configs 3 / 4) or URDF m on device m % N
     (config 5), forward kinematics on the device, ncclCommInitAll + one ncclAllGather of {frames, seconds, mismatches}
@@ -265,15 +280,25 @@ def test_cpp_multi_device_host_with_rccl_gather(tmp_path, mode, masks):
     else:
         share = CF.build("c5", 1, 0, streams=3, urdfs=3, triangles=15000)                     # 3 robots x 3 cameras
         pick = 7
+    if pick_override is not None:
+        pick = pick_override
     scene = tmp_path / "scene.bin"
     depth = scene_file.write_scene(str(scene), share, k=0)
-    out = subprocess.run([_multi_gpu_example(), str(scene), "--mode", mode, "--steps", "3", "--masks", masks, "--dump", str(pick), str(tmp_path / "s")],
-                         capture_output=True, text=True, timeout=600)
+    cmd = [_multi_gpu_example(), str(scene), "--mode", mode, "--steps", "3", "--masks", masks, "--dump", str(pick), str(tmp_path / "s")]
+    if logical:
+        cmd += ["--logical-devices", str(logical)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
     rep = json.loads(out.stdout.strip().splitlines()[-1])
     assert rep["streams"] == share.n and rep["frames"] == share.n * 3 and rep["bits_vs_bytes_mismatches"] == 0
     assert rep["gathered_masks_equal_sources"] == 1 and sum(d["streams"] for d in rep["per_device"]) == share.n
-    assert rep["mask_all_gather_path"] == ("peer-to-peer copies" if masks == "direct" else "rccl") and rep["peer_access_everywhere"] == 1
+    if logical:
+        assert rep["devices"] == logical and rep["logical_devices"] == 1 and len(rep["per_device"]) == logical
+        per = [d["streams"] for d in rep["per_device"]]
+        assert min(per) >= 1 and (mode == "block" or logical != 2 or sorted(per) == [3, 6]), per      # every member has a share; 3 robots over 2 members: 2 + 1 robots = 6 + 3 streams
+        assert rep["mask_all_gather_path"] == ("peer-to-peer copies" if masks == "direct" else "padded all-gather by copies (logical devices: no communicator)")
+    else:
+        assert rep["mask_all_gather_path"] == ("peer-to-peer copies" if masks == "direct" else "rccl") and rep["peer_access_everywhere"] == 1
     assert all(d["host_thread_pinned_to_cpus"] >= 0 for d in rep["per_device"])
     W, H = share.width, share.height
     masked = np.fromfile(tmp_path / "s.masked.f32", np.float32).reshape(H, W)

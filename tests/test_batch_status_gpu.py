@@ -173,3 +173,38 @@ def test_uneven_last_launch_group_keeps_its_own_grid_estimate(n, group):
         for s in range(n):
             assert np.array_equal(want[s][1], mask[s]) and bits_equal(want[s][0], masked[s]), s
     ctx.close()
+
+
+@pytest.mark.parametrize("n,group,lanes", [(100, 7, 2), (64, 5, 2), (40, 6, 3), (33, 4, 2)])
+def test_status_word_reaches_zero_when_the_groups_do_not_divide_the_batch(n, group, lanes):
+    """Several lanes round the number of launch groups up to a multiple of the lanes, and ceil(n / that) streams per group can
+    then come to FEWER groups than that multiple (100 streams: 16 asked for, 15 groups of 7 made).  The status word starts at
+    the number of groups and every finished group takes one off: it must start at the number MADE, or a device-side consumer
+    never sees 0 (round 5's advisor finding).  Read from a consumer's stream and again after the host has retired the batch."""
+    import torch
+    W, H = 128, 96
+    wl = WL.pr2_workload(n, W, H, total_triangles=3000)
+    ctx = R.Context(W, H, n, 0, params(wl.replace_value, wl.max_diff, max_inflight_streams=group, raster_lanes=lanes))
+    ids = wl.load_into(ctx)
+    depth = wl.depth_batch()
+    wl.stage(ctx, ids)
+    ctx.filter_batch(depth)
+    ctx.filter_batch(depth)                    # (bins and grid estimates settled)
+    dev = torch.device("cuda:0")
+    d = torch.from_numpy(depth).to(dev)
+    masked = torch.zeros((n, H, W), dtype=torch.float32, device=dev)
+    mask = torch.zeros((n, H, W), dtype=torch.uint8, device=dev)
+    user = Consumer(ctx)
+    ctx.filter_batch_device(n, d.data_ptr(), masked.data_ptr(), mask.data_ptr())
+    word, early_m, early_k, word_t = user.read(masked, mask)
+    st_groups = -(-n // -(-n // (-(-(-(-n // group)) // lanes) * lanes)))      # ceil(n / ceil(n / (ceil(n / group) rounded up to the lanes)))
+    assert word == 0, "status word %#x behind the batch's kernels (%d launch groups expected)" % (word, st_groups)
+    ctx.sync()
+    st = ctx.stats()
+    assert st["groups_last_batch"] == st_groups and st["batch_status"] == 0 and st["batch_reruns"] == 0, st
+    torch.cuda.synchronize()
+    assert int(word_t.cpu().numpy()[0]) == 0
+    for s in (0, n // 2, n - 1):
+        om, ok = O.filter_frame(depth[s], wl.projection[s], wl.oracle_draws(s), wl.offset_inv[s], wl.cam_tf[s], max_diff=wl.max_diff, replace_value=wl.replace_value)
+        assert np.array_equal(ok, early_k[s]) and bits_equal(om, early_m[s]), s
+    ctx.close()
