@@ -33,7 +33,10 @@ struct HostDraw {
 };
 struct HostLink { std::vector<HostDraw> draws; };
 static constexpr int kMaxInflight = 2;      // device batches that may be in flight at once
-static constexpr int kMaxLanes = 3;         // raster lanes a context can have (rtuf_params.raster_lanes; the default is kDefaultLanes)
+#ifndef RTUF_MAX_LANES
+#define RTUF_MAX_LANES 3            // (an experiment's build may raise it: more lanes than the runtime has hardware queues -- GPU_MAX_HW_QUEUES, 4 by default -- share queues)
+#endif
+static constexpr int kMaxLanes = RTUF_MAX_LANES;         // raster lanes a context can have (rtuf_params.raster_lanes; the default is kDefaultLanes)
 static constexpr int kDefaultLanes = 3;     // (three lanes + the pose stage's stream = the HIP runtime's four hardware queues)
 static constexpr int kSplitMin = 32;        // batches of at least this many streams are split over the lanes; smaller ones
                                             // take one lane each, in turn (their cost is launches, not kernel time)

@@ -2156,23 +2156,6 @@ __device__ __forceinline__ float shade_threshold(float z, const ShadeConsts& k)
   return __fsub_rn(virt, k.max_diff);
 }
 
-// The same threshold WITHOUT the IEEE division, and how far it can be off: q' = num * rcp(z - off) (v_rcp_f32: one ulp) lies
-// within 2^-22 |q| of the correctly rounded quotient q, the two subtractions of max_diff round to within 2^-24 of their
-// results each -- |thr' - thr| < 2^-21 (|q| + |max_diff|).  `guard` is eight times that plus a subnormal's worth.  A sensor
-// value farther than `guard` from thr' is on the same side of thr: the comparison needs no division.  Inside the band (one pixel
-// in a million of a real depth image; or thr' infinite / not a number: guard is then too) the caller divides after all, so
-// the result is the shader's bit for bit (tests/golden: threshold_ulps_160x120 puts the sensor ON the threshold and one ulp
-// to either side of it).
-#ifndef RTUF_FAST_THRESHOLD
-#define RTUF_FAST_THRESHOLD 1      // (A/B switch -- 0: every drawn pixel pays the division, as up to round 5)
-#endif
-__device__ __forceinline__ float fast_threshold(float z, const ShadeConsts& k, float& guard)
-{
-  const float q = __fmul_rn(k.num, __builtin_amdgcn_rcpf(__fsub_rn(z, k.off)));
-  guard = __fmaf_rn(fabsf(q) + fabsf(k.max_diff), 9.5367431640625e-07f, 7.52316384526264e-37f);      // 2^-20, 2^-120
-  return __fsub_rn(q, k.max_diff);
-}
-
 __device__ __forceinline__ float shade(float sensor, float z, const ShadeConsts& k, bool& filt)
 {
   filt = sensor > shade_threshold(z, k);
@@ -2269,37 +2252,48 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   // most tiles of BASELINE config 4) needs no key tile either: every pixel is the cover's fragment or the background's,
   // decided and shaded from registers -- the same two fused multiply-adds, 24-bit conversion and key comparison the key tile
   // would see, and the fragment's float z at hand instead of rebuilt from the key.  One barrier (before the bin header is reset
-  // for the next batch: every wave must have read it) instead of three, no LDS traffic.
-  const bool cover_only = COVER && has_cover && n == 0 && nf == 0 && !empty && RTUF_COVER_ONLY != 0;
-  struct CoverPlane { float a0, dzdx, dzdy; uint32_t order; };
-  auto cover_plane = [&]() {
-    const uint4 pl = reinterpret_cast<const uint4*>(a.big_list + cover_idx)[1];       // {a0, dzdx, dzdy, order}: same address in every lane
-    CoverPlane c;
-    c.a0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)pl.x));
-    c.dzdx = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)pl.y));
-    c.dzdy = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)pl.z));
-    c.order = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl.w) & kOrderMask;
-    return c;
-  };
-  CoverPlane cov = {0.0f, 0.0f, 0.0f, 0u};
-  if (empty || cover_only) request_sensor();
-  if (cover_only) {
-    cov = cover_plane();
+  // for the next batch: every wave must have read it) instead of three, no LDS traffic.  Only in the kernels that run with the
+  // cover pass: the others' code is what it was (this kernel sits on its register budget: a variable more in scope of the
+  // common path cost the headline workload 20 % when this was first written for all variants).
+  bool cover_only = false;
+  float cov_a0 = 0.0f, cov_dzdx = 0.0f, cov_dzdy = 0.0f;
+  uint32_t cov_order = 0u;
+  if constexpr (COVER && RTUF_COVER_ONLY != 0) {
+    cover_only = has_cover && n == 0 && nf == 0 && !empty;
+    if (cover_only) {
+      request_sensor();
+      const uint4 pl = reinterpret_cast<const uint4*>(a.big_list + cover_idx)[1];       // {a0, dzdx, dzdy, order}: same address in every lane
+      cov_a0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)pl.x));
+      cov_dzdx = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)pl.y));
+      cov_dzdy = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)pl.z));
+      cov_order = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl.w) & kOrderMask;
 #ifdef RTUF_COUNT
-    if (tid < 2) count_words()[tid] = 0u;
+      if (tid < 2) count_words()[tid] = 0u;
 #endif
-    __syncthreads();
-    if (tid == 0) {
-      *reinterpret_cast<uint4*>(a.bin_hdr + bin) = make_uint4(0u, 0u, 0xffffffffu, 0xffffffffu);      // ready for the next batch: nothing binned, no cover
-      a.fbin_count[bin] = 0;                                                                          // (a near cover had set the near flag)
-      atomicAdd(&a.counters->shard[bin % kCounterShards].cover_tiles, 1u);
+      __syncthreads();
+      if (tid == 0) {
+        *reinterpret_cast<uint4*>(a.bin_hdr + bin) = make_uint4(0u, 0u, 0xffffffffu, 0xffffffffu);      // ready for the next batch: nothing binned, no cover
+        a.fbin_count[bin] = 0;                                                                          // (a near cover had set the near flag)
+        atomicAdd(&a.counters->shard[bin % kCounterShards].cover_tiles, 1u);
+      }
     }
   }
+  if (empty) request_sensor();
   if (!empty && !cover_only) {
     // Initial depth keys: the background plane and, where a triangle covers the whole tile, that triangle's fragments --
     // evaluated per pixel exactly as fragment() would (same two fused multiply-adds, same 24-bit conversion, its draw
     // order), but written instead of min'ed: it is the first thing the tile sees, and bigrec_kernel<1> left it out of the bin.
     // (the plane is fetched again by the rare exact-z pass below rather than kept in registers across the rasterisation)
+    struct CoverPlane { float a0, dzdx, dzdy; uint32_t order; };
+    auto cover_plane = [&]() {
+      const uint4 pl = reinterpret_cast<const uint4*>(a.big_list + cover_idx)[1];       // {a0, dzdx, dzdy, order}: same address in every lane
+      CoverPlane c;
+      c.a0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)pl.x));
+      c.dzdx = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)pl.y));
+      c.dzdy = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)pl.z));
+      c.order = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl.w) & kOrderMask;
+      return c;
+    };
     // Ask for the first things this lane will need from the bins BEFORE the key tile is initialised: its first record and
     // its first fragments (their latency then passes under the initialisation and the barrier instead of after it).
 #ifndef RTUF_PRELOAD
@@ -2411,9 +2405,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   // With BITS the only output is one mask bit per pixel: `finish` returns the lane's four mask flags (bit j = pixel j)
   // and stores nothing; the caller packs the flags of 8 neighbouring lanes into one 32-bit word.
   bool uncovered = false;                              // BITS: a pixel no fragment reached (its masked depth would be the clear colour, not the sensor value)
-  // `guard` < 0: thr[j] is the shader's threshold itself; otherwise thr[j] is fast_threshold's and guard[j] its band, and the
-  // few pixels whose sensor value falls inside it are decided by the division after all (approx: the call site's constant)
-  auto finish = [&](int ps, const float (&z)[4], const float (&thr)[4], const bool (&frag)[4], const float (&guard)[4], bool approx) -> uint32_t {
+  auto finish = [&](int ps, const float (&z)[4], const float (&thr)[4], const bool (&frag)[4]) -> uint32_t {
     const int r_ly = r_ly0 + ps * kRowsPerPass, py = y_base + r_ly, px = r_px;
     const size_t gofs = (size_t)stream * ((size_t)a.height * a.width) + (uint32_t)(__mul24(py, a.width) + px);
     const int nvalid = min(4, a.width - px);
@@ -2436,21 +2428,9 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
     }
     float o[4];
     uint32_t mbits = 0;
-    bool filt[4];
-    bool unsure = false;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      filt[j] = s[j] > thr[j];
-      if (approx) unsure = unsure || fabsf(__fsub_rn(s[j], thr[j])) <= guard[j];      // (a NaN sensor value is not: it is unfiltered whatever the threshold)
-    }
-    if (approx && __ballot(unsure)) {              // (uniform; rare) inside the band somewhere in this wave: the shader's own arithmetic
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (guard[j] >= 0.0f) filt[j] = s[j] > shade_threshold(z[j], sc);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      bool f = filt[j];
+      bool f = s[j] > thr[j];
       o[j] = f ? sc.replace_value : s[j];
       if (!frag[j]) { o[j] = 0.0f; f = false; if (BITS) uncovered = true; }     // GL clear colour
       if (f) mbits |= (BITS ? 1u : 0xffu) << ((BITS ? 1 : 8) * j);
@@ -2474,7 +2454,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   };
   // Most pixels of a frame see only the background plane, whose depth is one value per stream: its compare
   // threshold (one IEEE division) is computed once per lane.  Same operations on the same values as per pixel.
-  const float bg_z4[4] = {bgz, bgz, bgz, bgz}, bg_thr4[4] = {thr_bg, thr_bg, thr_bg, thr_bg}, exact4[4] = {-1.0f, -1.0f, -1.0f, -1.0f};
+  const float bg_z4[4] = {bgz, bgz, bgz, bgz}, bg_thr4[4] = {thr_bg, thr_bg, thr_bg, thr_bg};
   const bool bg_frag4[4] = {analytic_bg, analytic_bg, analytic_bg, analytic_bg};
 #pragma unroll
   for (int ps = 0; ps < kPasses; ps++) {
@@ -2484,35 +2464,33 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
     RTUF_LANES(kLaneResolve, valid);
     if (valid) {
       if (empty) {                                   // tile without geometry: a streaming compare against the plane
-        flags4 = finish(ps, bg_z4, bg_thr4, bg_frag4, exact4, false);
-      } else if (cover_only) {                       // nothing but a triangle over the whole tile: its fragment or the background's, from registers
-        float z[4], thr[4], guard[4];
+        flags4 = finish(ps, bg_z4, bg_thr4, bg_frag4);
+      } else if (COVER && RTUF_COVER_ONLY != 0 && cover_only) {      // nothing but a triangle over the whole tile: its fragment or the background's, from registers
+        float z[4], thr[4];
         bool frag[4];
         const float zrow = (float)(y_base + r_ly);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const float zf = __fmaf_rn(cov.dzdy, zrow, __fmaf_rn(cov.dzdx, (float)(r_px + j), cov.a0));
-          const unsigned long long key = ((unsigned long long)z24_of(zf) << 32) | (cov.order << kf.shift) | (__float_as_uint(zf) & kf.lowmask);
+          const float zf = __fmaf_rn(cov_dzdy, zrow, __fmaf_rn(cov_dzdx, (float)(r_px + j), cov_a0));
+          const unsigned long long key = ((unsigned long long)z24_of(zf) << 32) | (cov_order << kf.shift) | (__float_as_uint(zf) & kf.lowmask);
           const bool drawn = key < bgkey;            // (what atomicMin on a key tile initialised with the background would keep)
           z[j] = drawn ? zf : bgz;
           frag[j] = drawn ? true : analytic_bg;
           thr[j] = thr_bg;
-          guard[j] = -1.0f;
-          if (drawn && !TWO_KERNEL) thr[j] = RTUF_FAST_THRESHOLD ? fast_threshold(zf, sc, guard[j]) : shade_threshold(zf, sc);
+          if (drawn && !TWO_KERNEL) thr[j] = shade_threshold(zf, sc);
 #ifdef RTUF_COUNT
           if (drawn && r_px + j < a.width) atomicAdd(&count_words()[1], 1u);
 #endif
         }
-        flags4 = finish(ps, z, thr, frag, guard, RTUF_FAST_THRESHOLD != 0);
+        flags4 = finish(ps, z, thr, frag);
       } else {
-        float z[4], thr[4], guard[4];
+        float z[4], thr[4];
         bool frag[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const unsigned long long k = keys[r_ly * kKeyStride + r_lx + j];
           frag[j] = true;
           thr[j] = thr_bg;
-          guard[j] = -1.0f;
           if (k == bgkey) { z[j] = bgz; frag[j] = analytic_bg; }
           else {                                        // the per-pixel division only runs where something was drawn
 #ifdef RTUF_COUNT
@@ -2530,10 +2508,10 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
                 if (khi <= 8388608u) z[j] = near_z_from_key(khi, (uint32_t)k & kf.lowmask, kf.shift);
               }
             }
-            if (!TWO_KERNEL) thr[j] = RTUF_FAST_THRESHOLD ? fast_threshold(z[j], sc, guard[j]) : shade_threshold(z[j], sc);
+            if (!TWO_KERNEL) thr[j] = shade_threshold(z[j], sc);
           }
         }
-        flags4 = finish(ps, z, thr, frag, guard, RTUF_FAST_THRESHOLD != 0);
+        flags4 = finish(ps, z, thr, frag);
       }
     }
     if (BITS) {
