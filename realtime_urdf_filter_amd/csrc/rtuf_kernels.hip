@@ -2542,13 +2542,14 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
 // Registers: 7 waves/SIMD (72 VGPRs; seven workgroups' key tiles are 159.6 of the CU's 160 KB of LDS) for the variants
 // without the cover pass -- the compiler spills two or three registers there and the kernel is still 5 % faster than at
 // 6 waves/SIMD (80 VGPRs, where it needs 74: tile kernel 275 -> 261 us on the 256-stream VGA workload), the seventh
-// workgroup per CU hides what the lanes wait for; the cover variants (walls: C4) are left at 6, where they measure the
-// same alone and 2 % better beside the other lane's set-up kernel.  Left alone the compiler takes 84 registers = 5 waves/SIMD.
+// workgroup per CU hides what the lanes wait for; the cover variants (walls: C4) were left at 6 up to round 5, where they
+// measured the same alone and 2 % better beside the other lane's set-up kernel -- with the cover-only tiles resolved from
+// registers (round 6) 7 is ahead there as well.  Left alone the compiler takes 84 registers = 5 waves/SIMD.
 #ifndef RTUF_TILE_WAVES
 #define RTUF_TILE_WAVES 7
 #endif
 #ifndef RTUF_TILE_WAVES_COVER
-#define RTUF_TILE_WAVES_COVER 6
+#define RTUF_TILE_WAVES_COVER 7      // (round 6, with the cover-only tiles off the key tile: 7 is 2.7 % ahead of 6 on C4's tile kernel, +0.7 % frames/s; up to round 5: 6)
 #endif
 // NT = threads of the workgroup: 256 (four waves per tile) for launches that fill the GPU; 1,024 (sixteen) for the small launches of
 // one or a few camera streams, where the kernel's time is the serial window loop of its fullest tiles -- 150 workgroups for one
