@@ -4,7 +4,7 @@
 #   bench.py reads: pmc_counters.json, valu_peak.json; llvmpipe_baseline.json comes from the development container)
 # rocprofv3 passes are separate runs: --kernel-trace --stats, then one --pmc pass per counter group (never together
 # with other trace domains).
-tag=${1:-r05}
+tag=${1:-r06}
 export TMPDIR=/tmp
 root=$PWD
 out=$root/gpurun_out/profiles
