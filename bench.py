@@ -270,6 +270,12 @@ def main():
     p.pipelines = P if P > 1 else 0          # rtuf_params.pipelines: the library alternates the batches between P internal pipelines
     ctx = R.Context(W, H, n, local_rank, p)
     share.load(ctx, on_device_fk=not args.host_poses)
+    if args.host_poses:
+        # every variant's host-side kinematics BEFORE the warm-up: computed when first staged (3 ms per stream in Python, 0.8 s per
+        # variant of 256 streams) they fell into the timed region -- round 6's first --host-poses line read 33 k frames/s for it
+        for g in share.groups:
+            for wl in g.variants:
+                wl.ensure_host_fk()
     ctx.enable_timing(2)         # HIP events around the big kernels only (each event costs stream time)
     ctxs = [ctx]
     V = share.n_variants()
