@@ -463,6 +463,10 @@ __global__ __launch_bounds__(kFkMaxFrames) void fk_tree_kernel(FkArgs a)
 // ---------------------------------------------------------------------------------------
 // triangle set-up
 // ---------------------------------------------------------------------------------------
+// (issue classes: see depth_test below)
+#ifndef RTUF_FAST_CLASS
+#define RTUF_FAST_CLASS 1
+#endif
 #ifndef RTUF_SMALL_FRAGS
 #define RTUF_SMALL_FRAGS 1      // resolve <= 4x4 single-tile boxes to fragments in the set-up kernel
 #endif
@@ -487,12 +491,28 @@ __device__ __forceinline__ void edges_from_snapped(int x0, int y0, int x1, int y
     const int j = (i + 1) % 3;
     const int dcdx = ys[i] - ys[j];
     const int dcdy = xs[i] - xs[j];
+    r.A[i] = -dcdx;
+    r.B[i] = dcdy;
+#if RTUF_FAST_CLASS
+    // The same C without 64-bit arithmetic (two 24-bit multiplies with their high halves, four carry operations, a 64-bit
+    // shift and a branch for the bias, all in the 4-cycle class): with x = 256 X + xf, y = 256 Y + yf
+    //   c = 256 (dcdx X - dcdy Y) + t,   t = dcdx xf - dcdy yf + bias   (|t| < 2^29: exact in 32 bits)
+    //   ceil(c / 256) = (dcdx X - dcdy Y) + ceil(t / 256)
+    // and only C's low 32 bits were ever used (the edge value at a pixel of the tile is small; A px + B py + C is evaluated
+    // modulo 2^32).  bias = dcdx < 0 || (dcdx == 0 && dcdy > 0)  <=>  2 dcdx - (dcdy > 0) < 0, as shifts and subtractions.
+    // (400 M random vertex pairs, incl. coincident and nearly coincident ones, against the 64-bit form on the CPU: identical.)
+    {
+      const int X = xs[i] >> 8, Y = ys[i] >> 8, xf = xs[i] & 255, yf = ys[i] & 255;
+      const uint32_t bias = ((uint32_t)(dcdx + dcdx) - ((uint32_t)(0 - dcdy) >> 31)) >> 31;
+      const int t = __mul24(dcdx, xf) - __mul24(dcdy, yf) + (int)bias;
+      r.C[i] = (int)((uint32_t)__mul24(dcdx, X) - (uint32_t)__mul24(dcdy, Y) + (uint32_t)(-((-t) >> 8)));
+    }
+#else
     long long c = (long long)dcdx * xs[i] - (long long)dcdy * ys[i];
     if (dcdx < 0 || (dcdx == 0 && dcdy > 0)) c += 1;   // inclusive on low-x / low-row edges
     // inside <=> c - dcdx*256*px + dcdy*256*py > 0  <=>  ceil(c/256) - dcdx*px + dcdy*py > 0
-    r.A[i] = -dcdx;
-    r.B[i] = dcdy;
     r.C[i] = (int)(-((-c) >> 8));
+#endif
   }
   r.bbx = (uint32_t)bx0 | ((uint32_t)bx1 << 16);
   r.bby = (uint32_t)by0 | ((uint32_t)by1 << 16);
@@ -731,6 +751,16 @@ __device__ __forceinline__ uint32_t z24_of(float z)
   return (uint32_t)__float2int_rn(__fmul_rn(zc, 16777215.0f));
 }
 
+// 24-bit depth of a window z that is KNOWN to be >= 0.5 (tiles without near geometry: every record and fragment there has
+// z >= 0.51 over its whole box, that is what kNearBit / the bin's near flag say): p = clamp(z) * 16777215 then lies in
+// [2^23, 2^24), where a float IS an integer (ulp 1: the product's rounding is the rounding to integer, half to even, that
+// v_rndne_f32 would repeat), and its bit pattern is 0x4B000000 + (p - 2^23): one integer add instead of v_rndne + v_cvt.
+__device__ __forceinline__ uint32_t z24_of_upper_half(float z)
+{
+  const float zc = fminf(fmaxf(z, 0.0f), 1.0f);
+  return __float_as_uint(__fmul_rn(zc, 16777215.0f)) - 0x4A800000u;
+}
+
 // Set-up + coverage of a triangle (snapped coordinates x0..y2 from phase 1) whose pixel-centre bounding box
 // is at most N x N (N <= 4): returns
 // the covered box positions (bit dy*4+dx, origin bx0,by0) and orients v0/v1 like orient_and_bound.
@@ -764,7 +794,7 @@ __device__ __forceinline__ uint32_t small_box_coverage(Win& v0, Win& v1, const W
     const int j = (i + 1) % 3;
     const int dcdx = ys[i] - ys[j], dcdy = xs[i] - xs[j];
     int c = __mul24(dcdx, xs[i]) - __mul24(dcdy, ys[i]);
-    if (dcdx < 0 || (dcdx == 0 && dcdy > 0)) c += 1;
+    if (dcdx < 0 || (dcdx == 0 && dcdy > 0)) c += 1;      // (as shifts and subtractions, like edges_from_snapped: 65 instead of 59 registers, 7 waves/SIMD)
     A[i] = -dcdx; B[i] = dcdy;
     E[i] = -((-c) >> 8) - 1;          // inside <=> E + A*dx + B*dy >= 0 (see edges_from_snapped)
   }
@@ -844,7 +874,8 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
         const int px = bx0 + (k & 3), py = by0 + (k >> 2);
         if (pos < a.fcapacity) {
           const float z = __fmaf_rn(dzdy, (float)py, __fmaf_rn(dzdx, (float)px, a0));
-          const unsigned long long f = ((unsigned long long)z24_of(z) << 40) | ((unsigned long long)order << kFragPosBits) |
+          // (a triangle that may reach z <= 0.51 anywhere in its box never gets here: it was handed to the record pass)
+          const unsigned long long f = ((unsigned long long)(RTUF_FAST_CLASS ? z24_of_upper_half(z) : z24_of(z)) << 40) | ((unsigned long long)order << kFragPosBits) |
                                        (unsigned long long)(lbase + (k >> 2) * kTileW + (k & 3));
           dst[pos] = f;
         }
@@ -862,7 +893,7 @@ __device__ __forceinline__ uint32_t emit_fragments_wave(const SetupArgs& a, int 
       const uint32_t pos = atomicAdd(&a.fbin_count[bin], 1u) & 0x7fffffffu;
       if (pos < a.fcapacity) {
         const float z = __fmaf_rn(dzdy, (float)py, __fmaf_rn(dzdx, (float)px, a0));
-        const unsigned long long f = ((unsigned long long)z24_of(z) << 40) | ((unsigned long long)order << kFragPosBits) |
+        const unsigned long long f = ((unsigned long long)(RTUF_FAST_CLASS ? z24_of_upper_half(z) : z24_of(z)) << 40) | ((unsigned long long)order << kFragPosBits) |
                                      (unsigned long long)((py % kTileH) * kTileW + (px % kTileW));
         reinterpret_cast<unsigned long long*>(a.fbins)[(size_t)bin * a.fcapacity + pos] = f;
       }
@@ -1597,13 +1628,17 @@ __device__ __forceinline__ float near_z_from_key(uint32_t z24, uint32_t low, int
 }
 
 // One depth test of a fragment whose window z is already evaluated (`order`: the draw order shifted into place).
+// Issue classes (profiles/valu_peak.json: gfx950 issues v_fma/mul/add_f32, v_add/sub_u32, v_and/or/xor_b32 and the right shifts
+// in 2 cycles per wave64, everything else -- conversions, v_rndne, min/max, compares, selects, 24-bit multiplies, left shifts --
+// in 4): RTUF_FAST_CLASS = 1 takes the 4-cycle instructions out of the hot walks where a 2-cycle one computes the same number
+// (0: A/B switch, the code of rounds 1-5).
 template <int MODE, bool LOW>
 __device__ __forceinline__ void depth_test(unsigned long long* keys, uint32_t order, float z, int lidx, const KeyFmt& kf, int lc)
 {
   if (MODE == 0) RTUF_COUNT_TEST();
   if (MODE == 0) RTUF_LANES(lc, true);
   const uint32_t lo = LOW ? (order | (__float_as_uint(z) & kf.lowmask)) : order;
-  const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | lo;
+  const unsigned long long key = ((unsigned long long)((RTUF_FAST_CLASS && !LOW && MODE == 0) ? z24_of_upper_half(z) : z24_of(z)) << 32) | lo;
   if (RTUF_ABL(kf.abl, 0x4000u)) { if (key == 0x0123456789abcdefull) keys[lidx] = key; return; }      // timing experiment: everything but the atomic
   if (MODE == 0) {
     atomicMin(&keys[lidx], key);
@@ -1810,6 +1845,55 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
     // different step at the end of a quad row); the other three pixels' are those plus A, B, A + B -- the
     // same integer arithmetic as evaluating A*px + B*py + C at every candidate, at about half the
     // instructions per candidate and a quarter of the loop trips.
+    if constexpr (RTUF_FAST_CLASS != 0) {
+      // The same walk with the pixel position kept as two floats (small integers: every add is exact) -- the plane wants them
+      // as floats, and four conversions per trip were 4-cycle instructions; the key's LDS address is stepped in bytes (no
+      // left shift per trip); the right-hand pixels of a quad lie outside the box only in the last quad column of a box of odd
+      // width, which the wrap test already knows (one compare less).  Same integers, same floats, same order of depth tests.
+      const int qcols = (lx1 - lx0 + 2) >> 1;                              // quads per quad row
+      const int back = 2 * (qcols - 1);                                    // x distance from the last quad of a row to the first
+      const float fpx0 = (float)(x_base + lx0), fpy_last = (float)(y_base + ly1), fpx_lastq = (float)(x_base + lx0 + back);
+      float fpx = fpx0, fpy = (float)(y_base + ly0);
+      uint32_t kofs = (uint32_t)(ly0 * kKeyStride + lx0) * 8u;             // byte offset of the quad's upper left key
+      int e0 = __mul24(r.A[0], x_base + lx0) + __mul24(r.B[0], y_base + ly0) + r.C[0];
+      int e1 = __mul24(r.A[1], x_base + lx0) + __mul24(r.B[1], y_base + ly0) + r.C[1];
+      int e2 = __mul24(r.A[2], x_base + lx0) + __mul24(r.B[2], y_base + ly0) + r.C[2];
+      // a step to the right always; the lanes at the end of a quad row then add what takes them to the start of the next one
+      // (five 2-cycle adds under the wrap's lane mask instead of six selects)
+      const int a0x2 = 2 * r.A[0], a1x2 = 2 * r.A[1], a2x2 = 2 * r.A[2];
+      const int d0 = 2 * r.B[0] - __mul24(back + 2, r.A[0]), d1 = 2 * r.B[1] - __mul24(back + 2, r.A[1]), d2 = 2 * r.B[2] - __mul24(back + 2, r.A[2]);
+      const uint32_t dk = (uint32_t)(2 * kKeyStride - back - 2) * 8u;
+      const bool odd_w = ((lx1 - lx0) & 1) == 0;                           // the last quad column holds one pixel column
+      int todo = small ? __mul24(qcols, (ly1 - ly0 + 2) >> 1) : 0;
+      auto test = [&](float x, float y, uint32_t ofs) {
+        depth_test<MODE, LOW>(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(keys) + ofs), r.order,
+                              __fmaf_rn(r.dzdy, y, __fmaf_rn(r.dzdx, x, r.a0)), 0, kf, kLaneWalkFrag);
+      };
+      while (__ballot(todo > 0)) {
+        if (MODE == 0) RTUF_LANES(kLaneWalkTrip, todo > 0);
+        if (todo > 0) {
+          const bool wrap = fpx == fpx_lastq;
+          const bool no_right = wrap && odd_w, below = fpy < fpy_last;
+          const int f0 = e0 + r.B[0], f1 = e1 + r.B[1], f2 = e2 + r.B[2];
+          const float fx1 = __fadd_rn(fpx, 1.0f), fy1 = __fadd_rn(fpy, 1.0f);
+          if (min(e0, min(e1, e2)) > 0) test(fpx, fpy, kofs);
+          if (min(e0 + r.A[0], min(e1 + r.A[1], e2 + r.A[2])) > 0 && !no_right) test(fx1, fpy, kofs + 8u);
+          if (min(f0, min(f1, f2)) > 0 && below) test(fpx, fy1, kofs + 8u * kKeyStride);
+          if (min(f0 + r.A[0], min(f1 + r.A[1], f2 + r.A[2])) > 0 && !no_right && below) test(fx1, fy1, kofs + 8u * kKeyStride + 8u);
+          e0 += a0x2; e1 += a1x2; e2 += a2x2;
+          kofs += 16u;
+          fpx = __fadd_rn(fpx, 2.0f);
+          todo--;
+          if (wrap) {
+            asm volatile("" ::: "memory");      // (keeps this a masked block: as selects it is six 4-cycle instructions)
+            e0 += d0; e1 += d1; e2 += d2;
+            kofs += dk;
+            fpy = __fadd_rn(fpy, 2.0f);
+            fpx = fpx0;
+          }
+        }
+      }
+    } else
     {
       const int px0 = x_base + lx0, px1 = x_base + lx1, py_last = y_base + ly1;
       int px = px0, py = y_base + ly0, lidx = ly0 * kKeyStride + lx0;

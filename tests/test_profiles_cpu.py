@@ -34,3 +34,14 @@ def test_counter_summary_follows_from_the_committed_counter_text(tmp_path):
         e = committed["kernels"][k]
         assert 0.3 < e["live_lane_fraction"] < 1.0
         assert abs(e["live_lane_fraction"] - e["counters_per_launch"]["SQ_THREAD_CYCLES_VALU"] / (e["counters_per_launch"]["SQ_ACTIVE_INST_VALU"] * 64.0)) < 1e-12
+
+
+def test_profiles_index_is_what_the_committed_files_say():
+    """profiles/INDEX.json maps every figure README.md / DESIGN.md quote to the file that backs it; its values are read out of
+    those files by scripts/profiles_index.py, so a re-taken profile set without a re-made index (or an edited index) fails here."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "profiles_index.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, "profiles/INDEX.json is stale: run python scripts/profiles_index.py\n" + r.stderr[-800:]
+    index = json.load(open(os.path.join(PROFILES, "INDEX.json")))
+    assert len(index["entries"]) >= 30
+    for e in index["entries"]:
+        assert os.path.exists(os.path.join(ROOT, e["file"])), e["file"]
