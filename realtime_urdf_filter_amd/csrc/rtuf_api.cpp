@@ -1538,6 +1538,13 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
   // to_linear_depth's constants exactly as the shader evaluates them (include/shaders/urdf_filter.frag:14-17), in float
   const float zn = c->params.near_plane, zf = c->params.far_plane;
   const float sc_num = (zn * zf) / (zn - zf), sc_off = zf / (zf - zn);
+  // The per-pixel division num / (z - off) needs neither the operand scaling nor the special-case fix-up of the IEEE expansion
+  // when no operand or intermediate can leave the normal range: |num| within 2^+-40, off in [1 + 2^-10, 2^20] (every z the
+  // kernels hand to it lies in [-1, 1 + 2^-11]: |z - off| >= 2^-11).  The kernels then run its eight-instruction core
+  // (shade_threshold; scripts/fdiv_check.hip compares the two forms over every float z of that range); anything else -- a far
+  // plane more than a thousand times the near plane, non-finite parameters -- keeps the full expansion.
+  const float sc_abs = std::fabs(sc_num);
+  const int fast_div = std::isfinite(sc_num) && std::isfinite(sc_off) && sc_abs >= 0x1p-40f && sc_abs <= 0x1p40f && sc_off >= 1.0f + 0x1p-10f && sc_off <= 0x1p20f;
   pa.bg = b.d_bg; pa.counters = b.d_counters; pa.n_counters = n_groups; pa.status = b.d_status;
   pa.sc_num = sc_num; pa.sc_off = sc_off; pa.max_diff = c->params.depth_distance_threshold;
   pa.n_streams = n; pa.n_draws = c->n_draws; pa.n_links = (int)L; pa.z_far = c->params.far_plane;
@@ -1570,6 +1577,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
     ta.sc_num = sc_num; ta.sc_off = sc_off;
     ta.io_u16 = io_u16 ? 1 : 0;
     ta.key_shift = c->key_shift;
+    ta.fast_div = fast_div;
     ta.bits = b.bits;
     gr.compare = two && !b.bits;
     if (gr.compare) {
@@ -1579,7 +1587,7 @@ static int enqueue_batch(rtuf_context* c, rtuf_context::Batch& b, bool rerun)
       ca.io_u16 = io_u16 ? 1 : 0; ca.mask = d_mask ? d_mask + (size_t)base * plane : nullptr;
       ca.n_pixels = (size_t)gs * plane;
       ca.z_near = ta.z_near; ca.z_far = ta.z_far; ca.max_diff = ta.max_diff; ca.replace_value = ta.replace_value;
-      ca.sc_num = sc_num; ca.sc_off = sc_off;
+      ca.sc_num = sc_num; ca.sc_off = sc_off; ca.fast_div = fast_div;
     }
   }
   b.n_groups = (int)plan.groups.size();

@@ -319,6 +319,7 @@ struct TileArgs {
   float sc_num, sc_off;          // z_near*z_far/(z_near-z_far) and z_far/(z_far-z_near) in float, as the shader computes them
   int io_u16;                    // 16UC1 in/out fused into the kernel (src/urdf_filter.cpp:287-288, :309-312)
   int key_shift;                 // depth keys: draw order << key_shift in the low word, the float z's low bits below it (KeyFmt)
+  int fast_div;                  // the threshold's division may run without its scaling / fix-up instructions (host: shade_consts_admit_core)
 };
 
 struct CompareArgs {
@@ -330,6 +331,7 @@ struct CompareArgs {
   float z_near, z_far, max_diff, replace_value;
   float sc_num, sc_off;
   int io_u16;
+  int fast_div;
 };
 
 

@@ -467,6 +467,9 @@ __global__ __launch_bounds__(kFkMaxFrames) void fk_tree_kernel(FkArgs a)
 #ifndef RTUF_FAST_CLASS
 #define RTUF_FAST_CLASS 1
 #endif
+#ifndef RTUF_FAST_RESOLVE
+#define RTUF_FAST_RESOLVE RTUF_FAST_CLASS      // (A/B switch of the second batch: no exact-z look in tiles without near geometry, z of a winner by one add)
+#endif
 #ifndef RTUF_SMALL_FRAGS
 #define RTUF_SMALL_FRAGS 1      // resolve <= 4x4 single-tile boxes to fragments in the set-up kernel
 #endif
@@ -2129,7 +2132,7 @@ __device__ __forceinline__ void raster_bin(unsigned long long* keys, const Packe
         for (int ly = qy0 + (tid >> 6); ly <= qy1; ly += NT / 64) {
           if (MODE == 0) { RTUF_LANES(kLaneParkTrip, true); RTUF_LANES(kLaneParkFrag, true); }
           const float z = __fmaf_rn(q.dzdy, (float)(y_base + ly), zc);
-          const unsigned long long key = ((unsigned long long)z24_of(z) << 32) | (LOW ? (q.order | (__float_as_uint(z) & kf.lowmask)) : q.order);
+          const unsigned long long key = ((unsigned long long)((RTUF_FAST_CLASS && !LOW && MODE == 0) ? z24_of_upper_half(z) : z24_of(z)) << 32) | (LOW ? (q.order | (__float_as_uint(z) & kf.lowmask)) : q.order);
           const int lidx = ly * kKeyStride + lane;
           if (MODE == 0) {
             RTUF_COUNT_TEST();
@@ -2231,12 +2234,37 @@ __device__ __forceinline__ uint32_t metres_to_u16(float m)
 // depend on uniforms only and are evaluated once per thread (same float operations).
 // num = z_near*z_far/(z_near-z_far), off = z_far/(z_far-z_near): evaluated once per batch on the host, in float,
 // exactly as the shader's to_linear_depth does (rtuf_api.cpp, enqueue_batch)
-struct ShadeConsts { float num, off, max_diff, replace_value; };
+struct ShadeConsts { float num, off, max_diff, replace_value; bool core; };
+
+// The IEEE division without the instructions that only matter for operands near the ends of the exponent range: the compiler
+// expands a correctly rounded a / b into v_div_scale_f32 twice (operand pre-scaling), v_rcp_f32, one Newton step, the quotient
+// with two residual corrections (the last as v_div_fmas_f32, which undoes the scaling) and v_div_fixup_f32 (zero / infinite /
+// NaN / denormal operands).  With both operands and the quotient far inside the normal range the scalings are identities and
+// the fix-up returns its input, and what is left is this: one v_rcp_f32 and seven 2-cycle instructions instead of eleven, four
+// of them in the 4-cycle class.  The host admits it per batch (TileArgs::fast_div, rtuf_api.cpp) from the two constants;
+// scripts/fdiv_check.hip compares it with __fdiv_rn for every float z in [-1, 1 + 2^-11] on the GPU: 0 of 5.75e10 quotients differ
+// inside the admitted domain, and the two pairs outside it (z_far 10,000 x z_near) show what the rule is for -- there z - off
+// passes through zero and the fix-up's infinity is not what the core returns (profiles/r06_experiment_fast_class_batches_2_3.txt).
+#ifndef RTUF_FAST_DIV
+#define RTUF_FAST_DIV RTUF_FAST_CLASS
+#endif
+__device__ __forceinline__ float div_core(float n, float d)
+{
+  float r = __builtin_amdgcn_rcpf(d);
+  const float e = __fmaf_rn(-d, r, 1.0f);
+  r = __fmaf_rn(e, r, r);
+  float q = __fmul_rn(n, r);
+  float res = __fmaf_rn(-d, q, n);
+  q = __fmaf_rn(res, r, q);
+  res = __fmaf_rn(-d, q, n);
+  return __fmaf_rn(res, r, q);
+}
 
 // sensor > shade_threshold(z)  <=>  should_filter of include/shaders/urdf_filter.frag:22-23
 __device__ __forceinline__ float shade_threshold(float z, const ShadeConsts& k)
 {
-  const float virt = __fdiv_rn(k.num, __fsub_rn(z, k.off));
+  const float d = __fsub_rn(z, k.off);
+  const float virt = (RTUF_FAST_DIV && k.core) ? div_core(k.num, d) : __fdiv_rn(k.num, d);
   return __fsub_rn(virt, k.max_diff);
 }
 
@@ -2293,7 +2321,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
   const float bgz = bi.z, thr_bg = bi.thr;
   const unsigned long long bgkey = analytic_bg ? ((unsigned long long)bi.z24 << 32) : kNoFragment;
   ShadeConsts sc;
-  sc.num = a.sc_num; sc.off = a.sc_off; sc.max_diff = a.max_diff; sc.replace_value = a.replace_value;
+  sc.num = a.sc_num; sc.off = a.sc_off; sc.max_diff = a.max_diff; sc.replace_value = a.replace_value; sc.core = a.fast_div != 0;
   const uint32_t zcover = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cover >> 32));      // (<= 0xffffff, or all ones: none)
   const uint32_t cover_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cover);
   const bool has_cover = zcover != 0xffffffffu;
@@ -2450,12 +2478,17 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
     // (z24 > 2^23) float z == (z24 + 1) * 2^-24 exactly; below, a tile with near geometry has the float's low bits in its
     // keys, which settle everything but the last micrometres in front of the near plane (z24 < zexact); a tile without
     // them has no record that could get there at all (the set-up marks those near) -- the test stays, it costs nothing.
+    // (round 6: a tile without near geometry does not look -- no record, fragment or cover of it can produce z < 0.51, which is
+    // what its depth tests already rely on (z24_of_upper_half) -- and is spared eight key reads per lane and a barrier)
     bool need = false;
-    for (int i = tid; i < kKeyCount; i += NT) {
-      const unsigned long long k = keys[i];
-      if (k != bgkey && (uint32_t)(k >> 32) < kf.zexact) need = true;
+    if (near_tile || !RTUF_FAST_RESOLVE) {
+      for (int i = tid; i < kKeyCount; i += NT) {
+        const unsigned long long k = keys[i];
+        if (k != bgkey && (uint32_t)(k >> 32) < kf.zexact) need = true;
+      }
+      need = __syncthreads_or(need) != 0;
     }
-    if (__syncthreads_or(need) && !RTUF_ABL(a.flags, 0x4000000u)) {      // (0x4000000: timing experiment, no exact-z pass)
+    if (need && !RTUF_ABL(a.flags, 0x4000000u)) {      // (0x4000000: timing experiment, no exact-z pass)
       // which draw-order keys won such a pixel: only their records are walked again
       if (tid < kWinnerWords) s_winners[tid] = 0u;
       if (tid == 0) atomicAdd(&a.counters->shard[bin % kCounterShards].exact_tiles, 1u);
@@ -2548,7 +2581,12 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
     RTUF_LANES(kLaneResolve, valid);
     if (valid) {
       if (empty) {                                   // tile without geometry: a streaming compare against the plane
-        flags4 = finish(ps, bg_z4, bg_thr4, bg_frag4);
+        if (RTUF_FAST_RESOLVE && analytic_bg) {          // (uniform: with the flags known to be set the four selects on them fall away)
+          const bool all4[4] = {true, true, true, true};
+          flags4 = finish(ps, bg_z4, bg_thr4, all4);
+        } else {
+          flags4 = finish(ps, bg_z4, bg_thr4, bg_frag4);
+        }
       } else if (COVER && RTUF_COVER_ONLY != 0 && cover_only) {      // nothing but a triangle over the whole tile: its fragment or the background's, from registers
         float z[4], thr[4];
         bool frag[4];
@@ -2584,10 +2622,16 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
             // range, or -- only in tiles with near geometry (uniform test: the headline workload never gets there) -- from
             // z24 and the low bits of the float the key carries
             const uint32_t khi = (uint32_t)(k >> 32);
-            if (k & kResolvedBit) {
+            if (RTUF_FAST_RESOLVE && !near_tile) {          // (uniform) no exact-z pass ran here, no depth below 0.51 exists
+              z[j] = __uint_as_float(khi + 0x3E800001u);
+            } else if (k & kResolvedBit) {
               z[j] = __uint_as_float((uint32_t)k);
             } else {
-              z[j] = __fmul_rn((float)(khi + 1u), 5.9604644775390625e-08f);
+              // (z24 + 1) * 2^-24.  For z24 >= 2^23 - 1 that float's bit pattern is z24 + 0x3E800001 (the integer is its own
+              // mantissa, the power of two an exponent offset, and 2^24 carries into the exponent: checked for all 2^23 values
+              // on the CPU) -- one 2-cycle add instead of a conversion and a multiply; smaller depths exist only in tiles
+              // with near geometry and take near_z_from_key below.
+              z[j] = RTUF_FAST_RESOLVE ? __uint_as_float(khi + 0x3E800001u) : __fmul_rn((float)(khi + 1u), 5.9604644775390625e-08f);
               if (near_tile) {
                 if (khi <= 8388608u) z[j] = near_z_from_key(khi, (uint32_t)k & kf.lowmask, kf.shift);
               }
@@ -2658,7 +2702,7 @@ template <bool U16>
 __global__ __launch_bounds__(kBlock) void compare_kernel(CompareArgs a)
 {
   ShadeConsts sc;
-  sc.num = a.sc_num; sc.off = a.sc_off; sc.max_diff = a.max_diff; sc.replace_value = a.replace_value;
+  sc.num = a.sc_num; sc.off = a.sc_off; sc.max_diff = a.max_diff; sc.replace_value = a.replace_value; sc.core = a.fast_div != 0;
   const size_t n4 = a.n_pixels >> 2;
   const uint16_t* in16 = reinterpret_cast<const uint16_t*>(a.depth);
   uint16_t* out16 = reinterpret_cast<uint16_t*>(a.masked);
