@@ -467,6 +467,9 @@ __global__ __launch_bounds__(kFkMaxFrames) void fk_tree_kernel(FkArgs a)
 #ifndef RTUF_FAST_CLASS
 #define RTUF_FAST_CLASS 1
 #endif
+#ifndef RTUF_FAST_COVER
+#define RTUF_FAST_COVER RTUF_FAST_CLASS        // (A/B switch: cover-only tiles compare 24-bit depths instead of composing keys)
+#endif
 #ifndef RTUF_FAST_RESOLVE
 #define RTUF_FAST_RESOLVE RTUF_FAST_CLASS      // (A/B switch of the second batch: no exact-z look in tiles without near geometry, z of a winner by one add)
 #endif
@@ -2594,8 +2597,17 @@ __device__ __forceinline__ void tile_body(const TileArgs& a)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const float zf = __fmaf_rn(cov_dzdy, zrow, __fmaf_rn(cov_dzdx, (float)(r_px + j), cov_a0));
+#if RTUF_FAST_COVER
+          // what atomicMin on a key tile initialised with the background would keep: the cover's key {z24, order << shift | low
+          // bits} against the background's (or "no fragment"'s) {z24, 0} -- its draw order is at least 1, so it is below exactly
+          // when its 24-bit depth is: one 32-bit compare, no key to put together; without near geometry (a near cover marks its
+          // tile) the depth comes from the product's bit pattern like everywhere else
+          const uint32_t cz24 = near_tile ? z24_of(zf) : z24_of_upper_half(zf);
+          const bool drawn = cz24 < (uint32_t)(bgkey >> 32);
+#else
           const unsigned long long key = ((unsigned long long)z24_of(zf) << 32) | (cov_order << kf.shift) | (__float_as_uint(zf) & kf.lowmask);
           const bool drawn = key < bgkey;            // (what atomicMin on a key tile initialised with the background would keep)
+#endif
           z[j] = drawn ? zf : bgz;
           frag[j] = drawn ? true : analytic_bg;
           thr[j] = thr_bg;

@@ -120,6 +120,7 @@ def build(tag):
                            (T + "_experiment_compiler_flags.txt", "compiler flag sweep", ["docs/experiments.md R6.6"]),
                            (T + "_experiment_fast_class.txt", "2-cycle-class instructions in the hot walks (kept)", ["DESIGN.md 4, 8", "docs/experiments.md R6.7"]),
                            (T + "_experiment_fast_class_batches_2_3.txt", "no exact-z look without near geometry, z by one add, the division's core; fdiv_check", ["DESIGN.md 4, 8", "docs/experiments.md R6.7"]),
+                           (T + "_fdiv_check.txt", "the division core equals __fdiv_rn inside the admitted domain (all float z in [-1, 1 + 2^-11])", ["DESIGN.md 4", "docs/experiments.md R6.7"]),
                            (T + "_pcie_probe.txt", "the host link: 56-57 GB/s one way, 40 + 50 both", ["DESIGN.md 5"]),
                            (T + "_pcie_probe_streams.txt", "the host link on 1 / 2 / 4 streams", ["DESIGN.md 5"]),
                            (T + "_same_box_c3_round5_vs_round6.txt", "round 5's tree and round 6's on one box, C3", ["DESIGN.md 4", "docs/experiments.md R6.2"]),

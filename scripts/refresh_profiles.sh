@@ -98,6 +98,8 @@ for k, v in agg.items():
     print("%-34s SQ_INSTS_VALU %.4g  SQ_ACTIVE_INST_VALU %.4g  ratio %.3f" % (k.split("(")[0], i, a, a / i if i else 0))
 PY
 cd $root
+# the compare threshold's division core against the IEEE division, every float z the kernels can hand it (scripts/fdiv_check.hip)
+$root/scripts/bin/fdiv_check 24 > $out/${tag}_fdiv_check.txt 2>&1
 bash scripts/lane_util.sh > $out/${tag}_lanes.json 2> $out/lanes.err
 python scripts/pmc_to_json.py $out $tag > $out/pmc_to_json.log 2>&1
 python scripts/valu_mix.py $out/valu_peak.json > $out/valu_mix.log 2>&1 || true

@@ -251,6 +251,31 @@ def test_set_params_between_frames():
     ctx.close()
 
 
+@pytest.mark.parametrize("two_kernel", [False, True])
+def test_threshold_division_with_and_without_its_core(two_kernel):
+    """The compare threshold divides num = z_near z_far / (z_near - z_far) by z - z_far / (z_far - z_near) per drawn pixel
+    (include/shaders/urdf_filter.frag:14-17).  The library runs the division's eight-instruction core where the two constants
+    admit it (rtuf_api.cpp: off >= 1 + 2^-10, scripts/fdiv_check.hip) and the full IEEE expansion elsewhere: both sides of the
+    rule, and the rule's edge, against the oracle -- which always divides."""
+    fx = golden_io.Fixture("soup_seed11_160x120")
+    seen = set()
+    for near, far in ((0.1, 8.0), (0.3, 3.0), (0.0079, 8.0), (0.0078, 8.0), (0.005, 8.0), (0.02, 500.0), (0.001, 100.0)):
+        zn, zf = np.float32(near), np.float32(far)
+        off = zf / (zf - zn)
+        seen.add(bool(off >= np.float32(1.0) + np.float32(2.0 ** -10)))
+        ctx = R.Context(fx.width, fx.height, 1, 0, params(fx.replace_value, fx.max_diff, two_kernel, near_plane=near, far_plane=far))
+        m, tfs = fx.load_into(ctx)
+        ctx.set_camera(0, None, fx.offset_inv, fx.cam_tf)
+        ctx.set_link_poses(0, m, tfs)
+        masked, mask = ctx.filter(fx.depth, fx.projection)
+        om, ok = O.filter_frame(fx.depth, fx.projection, fx.draws, fx.offset_inv, fx.cam_tf, z_near=near, z_far=far,
+                                max_diff=fx.max_diff, replace_value=fx.replace_value)
+        assert np.array_equal(mask, ok), (near, far, int((mask != ok).sum()))
+        assert np.array_equal(masked.view(np.uint32), om.view(np.uint32)), (near, far)
+        ctx.close()
+    assert seen == {True, False}
+
+
 def test_host_mirror_end_to_end_example_urdf():
     """URDF text -> URDFRenderer -> RealtimeURDFFilter.filter() on the GPU == the reference's output for
     urdf/example.urdf.xml (golden fixture of BASELINE config C1)."""
