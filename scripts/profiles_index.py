@@ -80,6 +80,7 @@ def build(tag):
     bench("BASELINE config 4: rank 0's share of the 8-GPU job (64 x 720p, robot + walls)", ["README.md", "DESIGN.md 4, 8"], T + "_bench_c4_share.json")
     bench("BASELINE config 5: rank 0's share of the 8-GPU job (8 URDFs x 128 cameras)", ["README.md"], T + "_bench_c5_share.json")
     bench("one rank through torch.distributed.run with the nccl (RCCL) backend", ["README.md", "DESIGN.md 5"], T + "_bench_rccl_world1.json")
+    bench("the driver's exact command, first thing on a fresh box: python bench.py --gpus 1 --steps 20 --warmup 5", ["profiles/README.md"], T + "_bench_driver_command.json", others)
 
     for suffix, what, pats in (("", "one-lane launch shape, C3: the roofline's kernel times", (("tile_kernel", r"tile_kernel<false, false, false"), ("setup_kernel", r"setup_kernel<false>"), ("clip_kernel", r"clip_kernel"))),
                                ("_near_arm", "arm in front of the lens", (("tile_kernel", r"tile_kernel<false, false, false"), ("setup_kernel", r"setup_kernel<false>"))),
@@ -121,6 +122,8 @@ def build(tag):
                            (T + "_experiment_fast_class.txt", "2-cycle-class instructions in the hot walks (kept)", ["DESIGN.md 4, 8", "docs/experiments.md R6.7"]),
                            (T + "_experiment_fast_class_batches_2_3.txt", "no exact-z look without near geometry, z by one add, the division's core; fdiv_check", ["DESIGN.md 4, 8", "docs/experiments.md R6.7"]),
                            (T + "_fdiv_check.txt", "the division core equals __fdiv_rn inside the admitted domain (all float z in [-1, 1 + 2^-11])", ["DESIGN.md 4", "docs/experiments.md R6.7"]),
+                           (T + "_final_campaign.txt", "final campaign on the final tree: soak, 27,300 fuzz scenes, clip stress, the driver's command", ["DESIGN.md 2", "profiles/README.md"]),
+                           (T + "_same_box_final_round5_vs_round6.txt", "round 5's tree and the final tree alternating on one box", ["DESIGN.md 8", "profiles/README.md"]),
                            (T + "_pcie_probe.txt", "the host link: 56-57 GB/s one way, 40 + 50 both", ["DESIGN.md 5"]),
                            (T + "_pcie_probe_streams.txt", "the host link on 1 / 2 / 4 streams", ["DESIGN.md 5"]),
                            (T + "_same_box_c3_round5_vs_round6.txt", "round 5's tree and round 6's on one box, C3", ["DESIGN.md 4", "docs/experiments.md R6.2"]),
