@@ -757,7 +757,7 @@ __device__ __forceinline__ uint32_t z24_of(float z)
   return (uint32_t)__float2int_rn(__fmul_rn(zc, 16777215.0f));
 }
 
-// 24-bit depth of a window z that is KNOWN to be >= 0.5 (tiles without near geometry: every record and fragment there has
+// 24-bit depth of a window z that is KNOWN to be above 0.5 (tiles without near geometry: every record and fragment there has
 // z >= 0.51 over its whole box, that is what kNearBit / the bin's near flag say): p = clamp(z) * 16777215 then lies in
 // [2^23, 2^24), where a float IS an integer (ulp 1: the product's rounding is the rounding to integer, half to even, that
 // v_rndne_f32 would repeat), and its bit pattern is 0x4B000000 + (p - 2^23): one integer add instead of v_rndne + v_cvt.
