@@ -50,7 +50,7 @@ int main(int argc, char** argv)
 {
   const int n_random = argc > 1 ? atoi(argv[1]) : 24;
   unsigned long long* d_bad; uint32_t* d_first;
-  hipMalloc(&d_bad, 8); hipMalloc(&d_first, 4);
+  (void)hipMalloc(&d_bad, 8); (void)hipMalloc(&d_first, 4);
   struct Pair { float num, off; const char* what; bool admitted; };
   std::vector<Pair> pairs;
   // (the host's rule, rtuf_api.cpp: |num| within 2^+-40, off in [1 + 2^-10, 2^20]; pairs outside it are checked as well, to show
@@ -75,12 +75,12 @@ int main(int argc, char** argv)
   unsigned long long total_bad = 0, total = 0, outside_bad = 0;
   for (const Pair& p : pairs) {
     unsigned long long bad = 0; uint32_t first = 0xffffffffu;
-    hipMemcpy(d_bad, &bad, 8, hipMemcpyHostToDevice); hipMemcpy(d_first, &first, 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_bad, &bad, 8, hipMemcpyHostToDevice); (void)hipMemcpy(d_first, &first, 4, hipMemcpyHostToDevice);
     // z in [0, 1 + 2^-11]: bit patterns 0 .. 0x3F801000, and the negatives -1 .. -0 (0x80000000 .. 0xBF800000)
     hipLaunchKernelGGL(check_kernel, dim3(4096), dim3(256), 0, 0, p.num, p.off, 0u, 0x3F801001u, d_bad, d_first);
     hipLaunchKernelGGL(check_kernel, dim3(4096), dim3(256), 0, 0, p.num, p.off, 0x80000000u, 0x3F800001u, d_bad, d_first);
-    hipDeviceSynchronize();
-    hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost); hipMemcpy(&first, d_first, 4, hipMemcpyDeviceToHost);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("device error\n"); return 2; }
+    (void)hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&first, d_first, 4, hipMemcpyDeviceToHost);
     printf("num %.9g off %.9g (%s%s): %llu differing of %llu", p.num, p.off, p.what, p.admitted ? "" : "; OUTSIDE the admitted domain: the library keeps the full expansion", bad, 0x3F801001ull + 0x3F800001ull);
     if (bad) printf("  first z bits 0x%08x", first);
     printf("\n");
