@@ -398,6 +398,52 @@ def test_small_triangles_closer_than_twice_the_near_plane():
         assert ctx.stats()["fragments_binned"] > 1000
         ctx.close()
 
+@pytest.mark.parametrize("wall_at", [None, 0.2060, 0.2030])
+def test_geometry_around_the_near_flag_threshold(wall_at):
+    """Round 6's tile kernel takes the 24-bit depth of a fragment from the bit pattern of clamp(z) * 16777215 and skips the
+    exact-z look wherever a tile holds no NEAR geometry -- a record, fragment or cover whose plane may reach window z 0.51
+    somewhere in its box (kNearBit; eye distance 0.2047 m at the default planes).  Triangles of every size class between 0.196
+    and 0.214 m (window z 0.49 .. 0.54), tiles with and without near ones side by side, with a wall over the whole frame just
+    behind / just in front of the threshold (a cover plane that is / is not near): bit-exact in both modes."""
+    W, H = 320, 240
+    rng = np.random.default_rng(606 + (0 if wall_at is None else int(wall_at * 1e4)))
+    P = S.projection(525.0 * W / 640, 525.0 * W / 640, (W - 1) / 2, (H - 1) / 2, W, H)
+    verts, n = [], 0
+    for count, lo, hi in ((4000, 0.003, 0.012), (600, 0.02, 0.06), (60, 0.1, 0.3)):      # 1-4 px, up to a tile, several tiles
+        zc = rng.uniform(0.196, 0.214, count)
+        centre = np.stack([rng.uniform(-0.55, 0.55, count) * zc, rng.uniform(-0.42, 0.42, count) * zc, zc], axis=1)
+        size = rng.uniform(lo, hi, count) * zc
+        jitter = rng.normal(size=(count, 3, 3)) * size[:, None, None]
+        jitter[:, :, 2] *= 0.02                                                             # nearly fronto-parallel: z stays around the threshold
+        verts.append((centre[:, None, :] + jitter).reshape(-1, 3))
+        n += count
+    if wall_at is not None:
+        verts.append(np.array([[-3.0, -3.0, wall_at], [3.0, -3.0, wall_at + 0.0004], [0.0, 4.0, wall_at + 0.0002]]))
+        n += 1
+    verts = np.concatenate(verts).astype(np.float32)
+    tris = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    depth = S.sensor_depth(W, H, 0.7)
+    depth[::2] = np.float32(0.205)               # sensor values around the rendered depths: both mask outcomes occur
+    I = S.gl(np.eye(4))
+    draws = [(I, 0, [0.0, 0.0, 0.0], verts, tris)]
+    om, ok, zwin, prim, _ = O.filter_frame(depth, P, draws, I, I, replace_value=5.0, want_debug=True)
+    drawn = prim > 0
+    assert (drawn & (zwin < 0.51)).sum() > 2000 and (drawn & (zwin > 0.51)).sum() > 2000      # the scene straddles the threshold
+    for two_kernel in (True, False):
+        ctx = R.Context(W, H, 1, 0, params(5.0, 0.05, two_kernel))
+        m = ctx.add_model()
+        ctx.add_draw(m, ctx.add_link(m), verts, tris, 0, [0.0, 0.0, 0.0])
+        ctx.finalize_models()
+        ctx.set_camera(0, P, I, I)
+        ctx.set_link_poses(0, m, np.stack([I]))
+        for _ in range(2):                       # (second batch: the cover pass has switched itself on where the wall covers tiles)
+            masked, mask = ctx.filter_batch(depth[None])
+            assert (ok != mask[0]).sum() == 0 and bits_equal(om, masked[0])
+        if two_kernel:
+            assert bits_equal(ctx.read_zsurface(1)[0], zwin)
+        ctx.close()
+
+
 @pytest.mark.parametrize("size,per_cluster", [((517, 389), 1), ((517, 389), 2), ((640, 480), 6), ((322, 242), 12)])
 def test_large_near_triangles_of_every_shape_walked_as_strips(size, per_cluster):
     """Round 5's strip walk (tile kernel: records of more than 96 pixels in tiles with near geometry are cut into strips of 16
